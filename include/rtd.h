@@ -1,0 +1,133 @@
+/*
+ * rtd.h -- C ABI of the MI355X discrete-ordinate radiative-transfer engine (librtd.so).
+ *
+ * This is the drop-in boundary for the hot path of LDEO-CREW/Pythonic-DISORT:
+ *
+ *   _assemble_intensity_and_fluxes   src/PythonicDISORT/_assemble_intensity_and_fluxes.py:8-32
+ *     -> _solve_for_gen_and_part_sols   src/PythonicDISORT/_solve_for_gen_and_part_sols.py:5-16
+ *     -> _solve_for_coeffs              src/PythonicDISORT/_solve_for_coeffs.py:8-29
+ *     -> closures u / u0 / flux_up / flux_down   _assemble_intensity_and_fluxes.py:170,334,446,527
+ *
+ * The reference has no FFI of its own (it is pure Python over NumPy/SciPy); the entry points
+ * below are what a ctypes binding of that path binds.  They take the *prepared* arguments of
+ * `_assemble_intensity_and_fluxes` (delta-M scaled, source-rescaled; pydisort.py:184-372), with a
+ * leading column axis C added to every per-atmosphere array so that many independent
+ * atmospheric columns are solved in one call.  C = 1 reproduces one `pydisort()` call.
+ *
+ * Conventions: plain C, all arrays contiguous row-major float64, caller-allocated HOST memory
+ * unless a name says "dev"; sizes are int32; every function returns 0 on success or a nonzero
+ * status (rtd_last_error() gives the text).  No exceptions cross the boundary.  A plan owns its
+ * device buffers and one HIP stream; plans are independent and may be used from different host
+ * threads (one thread per plan).
+ */
+#ifndef RTD_H
+#define RTD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtd_plan rtd_plan; /* opaque */
+
+typedef struct {
+  int32_t ncols;    /* C : independent atmospheric columns                                  */
+  int32_t nlayers;  /* NLayers                                                              */
+  int32_t nquad;    /* NQuad (streams, even; N = NQuad/2 per hemisphere)                    */
+  int32_t nleg;     /* NLeg  (phase-function moments used, <= NQuad)                        */
+  int32_t nfourier; /* NFourier (1 when only fluxes are wanted)                             */
+  int32_t nscoeffs; /* Nscoeffs: polynomial order+1 of the isotropic source (0 = none)      */
+  int32_t nbdrf;    /* NBDRF: number of tabulated BDRF Fourier modes (0 = black surface)    */
+  int32_t beam;     /* there_is_beam_source (any I0 > 0)                                    */
+} rtd_dims;
+
+/* --- library / device ------------------------------------------------------------------- */
+int rtd_version(void);
+const char* rtd_last_error(void);
+int rtd_device_count(int32_t* count);
+
+/* --- plan life cycle ---------------------------------------------------------------------- */
+/* Allocates every device buffer the path needs for `dims` on HIP device `device`. */
+int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** plan);
+int rtd_plan_destroy(rtd_plan* plan);
+int rtd_plan_synchronize(rtd_plan* plan);
+/* bytes of device memory held by the plan */
+int rtd_plan_device_bytes(rtd_plan* plan, int64_t* bytes);
+
+/* --- inputs (host -> device) -------------------------------------------------------------- */
+/* Quadrature of one hemisphere: mu_arr_pos[N], W[N]  (pydisort.py:304-306). */
+int rtd_plan_set_quadrature(rtd_plan* plan, const double* mu_pos, const double* weights);
+
+/* Per-column prepared arguments of _assemble_intensity_and_fluxes (_assemble.py:8-32):
+ *   scaled_omega      [C][L]        scaled_omega_arr
+ *   tau               [C][L]        tau_arr (unscaled lower boundaries, for layer lookup)
+ *   scaled_tau_with_0 [C][L+1]      scaled_tau_arr_with_0
+ *   scale_tau         [C][L]        scale_tau
+ *   wleg              [C][L][NLeg]  weighted_scaled_Leg_coeffs
+ *   mu0, I0, phi0, rescale [C]      beam parameters (I0 already divided by rescale_factor)
+ *   b_pos, b_neg      [C][M][N]     Dirichlet BCs per Fourier mode (NULL = 0); _coeffs.py:142-158
+ *   s_poly            [C][L][Ns]    scaled_s_poly_coeffs (NULL when Ns = 0)
+ *   bdrf_q            [C][NBDRF][N][N]  q^m(mu_i, mu_j)     } BDRF_Fourier_modes evaluated on the
+ *   bdrf_q0           [C][NBDRF][N]     q^m(mu_i, mu0)      } quadrature grid; _coeffs.py:121-134
+ */
+int rtd_plan_set_columns(rtd_plan* plan, const double* scaled_omega, const double* tau,
+                         const double* scaled_tau_with_0, const double* scale_tau, const double* wleg,
+                         const double* mu0, const double* I0, const double* phi0, const double* rescale,
+                         const double* b_pos, const double* b_neg, const double* s_poly,
+                         const double* bdrf_q, const double* bdrf_q0);
+
+/* --- solve: _solve_for_gen_and_part_sols + _solve_for_coeffs on the device ---------------- */
+/* Asynchronous on the plan's stream. */
+int rtd_plan_solve(rtd_plan* plan);
+
+/* --- evaluators: the closures of _assemble_intensity_and_fluxes --------------------------- */
+/* tau: [C][ntau] optical depths (0 <= tau <= tau_arr[-1]); phi: [nphi].
+ * u      [C][NQuad][ntau][nphi]   (axes mu, tau, phi as the reference's u(tau, phi))
+ * u0     [C][NQuad][ntau]
+ * fluxes [C][ntau]: flux_up, flux_down diffuse, flux_down direct
+ * ulast  [C][NQuad][ntau]: last Fourier mode u^{M-1} (for return_Fourier_error), may be NULL
+ * antiderivative != 0 switches every output to the tau-antiderivative (is_antiderivative_wrt_tau).
+ * Any output pointer may be NULL.  Synchronous (returns when the host arrays are filled).
+ * Returns RTD_ERR_TAU_RANGE if some tau lies outside its column (the reference raises ValueError). */
+int rtd_plan_evaluate(rtd_plan* plan, int32_t ntau, const double* tau, int32_t nphi, const double* phi,
+                      int32_t antiderivative, double* u, double* u0, double* flux_up,
+                      double* flux_down_diffuse, double* flux_down_direct, double* ulast);
+
+/* Throughput form: evaluation points are uploaded once, results stay in HBM. */
+int rtd_plan_set_eval_points(rtd_plan* plan, int32_t ntau, const double* tau, int32_t nphi, const double* phi);
+/* solve + evaluate at the stored points, asynchronous on the plan's stream */
+int rtd_plan_run(rtd_plan* plan);
+/* copy the results of the last rtd_plan_run to the host (any pointer may be NULL) */
+int rtd_plan_fetch(rtd_plan* plan, double* u, double* u0, double* flux_up, double* flux_down_diffuse,
+                   double* flux_down_direct);
+/* device pointers of the result buffers of rtd_plan_run (for a device-side collective) */
+int rtd_plan_result_dev_ptrs(rtd_plan* plan, void** u_dev, int64_t* u_bytes, void** flux_dev, int64_t* flux_bytes);
+
+/* --- the reference's tensors for one column (layout of the reference) ---------------------- */
+/* GC [M][L][Q][Q], K [M][L][Q], B [M][L][Q], G_inv_mu_inv [L][Q], G [M][L][Q][Q]; any may be NULL.
+ * These are what _solve_for_coeffs returns (_coeffs.py:390) and what the closures capture. */
+int rtd_plan_get_tensors(rtd_plan* plan, int32_t column, double* GC, double* K, double* B,
+                         double* G_inv_mu_inv, double* G);
+
+/* --- measurement --------------------------------------------------------------------------- */
+/* When enabled, rtd_plan_run/solve bracket each kernel with HIP events on the plan's stream. */
+int rtd_plan_enable_timing(rtd_plan* plan, int32_t enable);
+/* accumulated milliseconds since the last reset: [0] Legendre tables, [1] eigen stage,
+ * [2] boundary-condition solve, [3] evaluation; launches counted in nlaunch[4]. Synchronises. */
+int rtd_plan_get_timing(rtd_plan* plan, double ms[4], int64_t nlaunch[4], int32_t reset);
+/* maximum Jacobi sweeps used by any eigenproblem of the last solve (diagnostic) */
+int rtd_plan_max_sweeps(rtd_plan* plan, int32_t* sweeps);
+
+enum {
+  RTD_OK = 0,
+  RTD_ERR_ARG = 1,        /* bad argument / unsupported size */
+  RTD_ERR_HIP = 2,        /* HIP runtime failure             */
+  RTD_ERR_TAU_RANGE = 3,  /* tau outside [0, tau_arr[-1]]    */
+  RTD_ERR_STATE = 4       /* call order (e.g. evaluate before solve) */
+};
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTD_H */

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Builds librtd.so (the HIP kernels + C ABI of include/rtd.h) for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU.  Objects are rebuilt only when their sources changed.
+Usage: python pythonic-disort_amd/build.py [--force]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "pydisort_amd")
+OBJ_DIR = os.path.join(HERE, "build")
+LIB = os.path.join(OUT_DIR, "librtd.so")
+SOURCES = ["rtd_api.hip", "rtd_eig.hip", "rtd_bc.hip", "rtd_eval.hip"]
+HEADERS = [os.path.join(CSRC, "rtd_device.h"), os.path.join(HERE, "..", "include", "rtd.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+    path = os.path.join(CSRC, src)
+    if _stale(obj, [path] + HEADERS):
+        subprocess.run([HIPCC] + FLAGS + ["-c", path, "-o", obj], check=True)
+    return obj
+
+
+def build(force=False):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ_DIR):
+            os.remove(os.path.join(OBJ_DIR, f))
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    if _stale(LIB, objs):
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

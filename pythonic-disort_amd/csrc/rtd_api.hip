@@ -1,0 +1,465 @@
+// rtd_api.hip -- host side of the C ABI declared in include/rtd.h (plan life cycle, uploads, launches).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtd.h"
+#include "rtd_device.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(RTD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+  } while (0)
+
+int pad_pow2(int n) {
+  int p = 4;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+}  // namespace
+
+struct rtd_plan {
+  rtd_dims dims{};
+  int device = 0;
+  int NP = 0;
+  hipStream_t stream = nullptr;
+  RtdDev d{};
+  std::vector<void*> allocs;
+  int64_t bytes = 0;
+  bool have_quad = false, have_cols = false, solved = false, tables_ready = false;
+  // evaluation buffers (grown on demand)
+  int ev_ntau = 0, ev_nphi = 0;
+  double *ev_tau = nullptr, *ev_phi = nullptr, *ev_u = nullptr, *ev_u0 = nullptr, *ev_fl = nullptr,
+         *ev_ulast = nullptr;
+  int64_t cap_tau = 0, cap_phi = 0, cap_u = 0, cap_u0 = 0, cap_fl = 0;
+  // export buffers
+  double* ex_buf = nullptr;
+  // timing
+  bool timing = false;
+  hipEvent_t evt[6] = {};
+  double ms[4] = {0, 0, 0, 0};
+  int64_t nlaunch[4] = {0, 0, 0, 0};
+  bool pending[4] = {false, false, false, false};
+
+  template <typename T>
+  int alloc(T** p, int64_t n) {
+    void* q = nullptr;
+    if (n <= 0) n = 1;
+    hipError_t e = hipMalloc(&q, (size_t)n * sizeof(T));
+    if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    allocs.push_back(q);
+    bytes += n * (int64_t)sizeof(T);
+    *p = (T*)q;
+    return 0;
+  }
+};
+
+namespace {
+
+int grow(rtd_plan* p, double** buf, int64_t* cap, int64_t need) {
+  if (need <= *cap) return 0;
+  if (*buf) {
+    for (auto& a : p->allocs)
+      if (a == *buf) a = nullptr;
+    (void)hipFree(*buf);
+    p->bytes -= *cap * 8;
+  }
+  *buf = nullptr;
+  *cap = 0;
+  int rc = p->alloc(buf, need);
+  if (rc) return rc;
+  *cap = need;
+  return 0;
+}
+
+// collect timing of stage `k` if an event pair is pending
+void harvest(rtd_plan* p) {
+  for (int k = 0; k < 4; ++k) {
+    if (!p->pending[k]) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, p->evt[k], p->evt[k + 1]) == hipSuccess) {
+      p->ms[k] += t;
+      p->nlaunch[k] += 1;
+    }
+    p->pending[k] = false;
+  }
+}
+
+int launch_solve(rtd_plan* p, bool with_eval, const RtdEval* ev) {
+  hipStream_t s = p->stream;
+  if (p->timing) {
+    (void)hipStreamSynchronize(s);
+    harvest(p);
+  }
+  const bool tm = p->timing;
+  if (tm) (void)hipEventRecord(p->evt[0], s);
+  (void)hipMemsetAsync(p->d.sweeps, 0, sizeof(int), s);
+  rtd_launch_tables(p->d, s);
+  if (tm) (void)hipEventRecord(p->evt[1], s);
+  rtd_launch_eig(p->d, s);
+  if (tm) (void)hipEventRecord(p->evt[2], s);
+  rtd_launch_bc(p->d, s);
+  if (tm) (void)hipEventRecord(p->evt[3], s);
+  if (with_eval) {
+    rtd_launch_eval(p->d, *ev, s);
+    if (tm) (void)hipEventRecord(p->evt[4], s);
+  }
+  if (tm) {
+    p->pending[0] = p->pending[1] = p->pending[2] = true;
+    p->pending[3] = with_eval;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  p->solved = true;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtd_version(void) { return 100; }
+
+const char* rtd_last_error(void) { return g_err.c_str(); }
+
+int rtd_device_count(int32_t* count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(RTD_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *count = n;
+  return 0;
+}
+
+int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** out) {
+  if (!dims || !out) return fail(RTD_ERR_ARG, "null argument");
+  const int N = dims->nquad / 2;
+  if (dims->ncols < 1 || dims->nlayers < 1 || dims->nquad < 2 || (dims->nquad & 1) || dims->nleg < 1 ||
+      dims->nfourier < 1 || dims->nfourier > dims->nleg || dims->nscoeffs < 0 || dims->nbdrf < 0)
+    return fail(RTD_ERR_ARG, "invalid dimensions");
+  if (N > 32) return fail(RTD_ERR_ARG, "NQuad > 64 is not supported by this build (N = NQuad/2 <= 32)");
+  HIP_TRY(hipSetDevice(device));
+  rtd_plan* p = new rtd_plan();
+  p->dims = *dims;
+  p->device = device;
+  p->NP = pad_pow2(N);
+  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  for (auto& e : p->evt) HIP_TRY(hipEventCreate(&e));
+  RtdDev& d = p->d;
+  const int64_t C = dims->ncols, L = dims->nlayers, M = dims->nfourier, P = dims->nleg, NP = p->NP,
+                Ns = dims->nscoeffs, NB = dims->nbdrf, Q2 = 2 * NP;
+  d.C = (int)C; d.L = (int)L; d.N = N; d.NP = (int)NP; d.P = (int)P; d.M = (int)M; d.Ns = (int)Ns;
+  d.NBDRF = (int)NB; d.beam = dims->beam ? 1 : 0;
+  int rc = 0;
+  double *mu, *w, *invmu, *S, *T, *omega, *tau, *taus0, *scale, *wleg, *mu0, *I0, *phi0, *rescale, *bpos, *bneg,
+      *spoly, *bq, *bq0;
+#define A(ptr, n) if ((rc = p->alloc(&ptr, (n)))) { rtd_plan_destroy(p); return rc; }
+  A(mu, NP) A(w, NP) A(invmu, NP) A(S, NP) A(T, NP)
+  A(d.Y, M * P * NP) A(d.Y0, C * M * P)
+  A(omega, C * L) A(tau, C * L) A(taus0, C * (L + 1)) A(scale, C * L) A(wleg, C * L * P)
+  A(mu0, C) A(I0, C) A(phi0, C) A(rescale, C)
+  A(bpos, C * M * NP) A(bneg, C * M * NP) A(spoly, C * L * Ns) A(bq, C * NB * NP * NP) A(bq0, C * NB * NP)
+  A(d.Gp, C * M * L * NP * NP) A(d.Gm, C * M * L * NP * NP) A(d.kk, C * M * L * NP) A(d.Bv, C * M * L * Q2)
+  A(d.dq, C * L * Ns * Q2) A(d.zneg, C * L * NP) A(d.coef, C * M * L * Q2)
+  A(d.Lw, C * M * L * NP * NP) A(d.Qw, C * M * L * NP * NP)
+  A(d.Fws, C * M * (L - 1) * Q2 * Q2) A(d.yws, C * M * (L - 1) * Q2)
+  A(d.sweeps, 1) A(d.status, 1)
+#undef A
+  d.mu = mu; d.w = w; d.invmu = invmu; d.S = S; d.T = T;
+  d.omega = omega; d.tau = tau; d.taus0 = taus0; d.scale = scale; d.wleg = wleg;
+  d.mu0 = mu0; d.I0 = I0; d.phi0 = phi0; d.rescale = rescale; d.bpos = bpos; d.bneg = bneg;
+  d.spoly = spoly; d.bdrfq = bq; d.bdrfq0 = bq0;
+  HIP_TRY(hipMemsetAsync(d.status, 0, sizeof(int), p->stream));
+  HIP_TRY(hipMemsetAsync(d.sweeps, 0, sizeof(int), p->stream));
+  HIP_TRY(hipMemsetAsync(d.Bv, 0, (size_t)(C * M * L * Q2) * 8, p->stream));
+  if (Ns > 0) HIP_TRY(hipMemsetAsync(d.dq, 0, (size_t)(C * L * Ns * Q2) * 8, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  *out = p;
+  return 0;
+}
+
+int rtd_plan_destroy(rtd_plan* p) {
+  if (!p) return 0;
+  (void)hipSetDevice(p->device);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  for (void* a : p->allocs)
+    if (a) (void)hipFree(a);
+  for (auto& e : p->evt)
+    if (e) (void)hipEventDestroy(e);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+  return 0;
+}
+
+int rtd_plan_synchronize(rtd_plan* p) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+int rtd_plan_device_bytes(rtd_plan* p, int64_t* bytes) {
+  if (!p || !bytes) return fail(RTD_ERR_ARG, "null argument");
+  *bytes = p->bytes;
+  return 0;
+}
+
+int rtd_plan_set_quadrature(rtd_plan* p, const double* mu_pos, const double* weights) {
+  if (!p || !mu_pos || !weights) return fail(RTD_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  const int N = p->d.N, NP = p->NP;
+  std::vector<double> mu(NP), w(NP), im(NP), S(NP), T(NP);
+  for (int i = 0; i < NP; ++i) {
+    if (i < N) {
+      if (!(mu_pos[i] > 0.0) || !(weights[i] > 0.0)) return fail(RTD_ERR_ARG, "quadrature nodes/weights must be positive");
+      mu[i] = mu_pos[i]; w[i] = weights[i];
+      S[i] = std::sqrt(w[i] / mu[i]); T[i] = std::sqrt(w[i] * mu[i]);
+    } else {  // padding stream: decoupled, never the beam direction (1/mu = 0.5 < 1/mu0)
+      mu[i] = 2.0; w[i] = 0.0; S[i] = 0.0; T[i] = 1.0;
+    }
+    im[i] = 1.0 / mu[i];
+  }
+  const size_t nb = (size_t)NP * 8;
+  HIP_TRY(hipMemcpyAsync((void*)p->d.mu, mu.data(), nb, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync((void*)p->d.w, w.data(), nb, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync((void*)p->d.invmu, im.data(), nb, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync((void*)p->d.S, S.data(), nb, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync((void*)p->d.T, T.data(), nb, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->have_quad = true;
+  p->solved = false;
+  return 0;
+}
+
+int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* tau, const double* taus0,
+                         const double* scale_tau, const double* wleg, const double* mu0, const double* I0,
+                         const double* phi0, const double* rescale, const double* b_pos, const double* b_neg,
+                         const double* s_poly, const double* bdrf_q, const double* bdrf_q0) {
+  if (!p || !scaled_omega || !tau || !taus0 || !scale_tau || !wleg || !mu0 || !I0 || !phi0 || !rescale)
+    return fail(RTD_ERR_ARG, "null argument");
+  const RtdDev& d = p->d;
+  if (d.Ns > 0 && !s_poly) return fail(RTD_ERR_ARG, "s_poly is required when nscoeffs > 0");
+  if (d.NBDRF > 0 && (!bdrf_q || !bdrf_q0)) return fail(RTD_ERR_ARG, "BDRF tables are required when nbdrf > 0");
+  HIP_TRY(hipSetDevice(p->device));
+  const int64_t C = d.C, L = d.L, M = d.M, P = d.P, N = d.N, NP = d.NP, Ns = d.Ns, NB = d.NBDRF;
+  hipStream_t s = p->stream;
+#define UP(dst, src, n) HIP_TRY(hipMemcpyAsync((void*)(dst), (src), (size_t)(n) * 8, hipMemcpyHostToDevice, s))
+  UP(d.omega, scaled_omega, C * L);
+  UP(d.tau, tau, C * L);
+  UP(d.taus0, taus0, C * (L + 1));
+  UP(d.scale, scale_tau, C * L);
+  UP(d.wleg, wleg, C * L * P);
+  UP(d.mu0, mu0, C);
+  UP(d.I0, I0, C);
+  UP(d.phi0, phi0, C);
+  UP(d.rescale, rescale, C);
+  if (Ns > 0) UP(d.spoly, s_poly, C * L * Ns);
+  // pad the per-stream arrays from N to NP
+  std::vector<double> bp((size_t)(C * M * NP), 0.0), bn((size_t)(C * M * NP), 0.0);
+  for (int64_t cm = 0; cm < C * M; ++cm)
+    for (int64_t i = 0; i < N; ++i) {
+      if (b_pos) bp[cm * NP + i] = b_pos[cm * N + i];
+      if (b_neg) bn[cm * NP + i] = b_neg[cm * N + i];
+    }
+  UP(d.bpos, bp.data(), C * M * NP);
+  UP(d.bneg, bn.data(), C * M * NP);
+  std::vector<double> q, q0;
+  if (NB > 0) {
+    q.assign((size_t)(C * NB * NP * NP), 0.0);
+    q0.assign((size_t)(C * NB * NP), 0.0);
+    for (int64_t cb = 0; cb < C * NB; ++cb)
+      for (int64_t i = 0; i < N; ++i) {
+        q0[cb * NP + i] = bdrf_q0[cb * N + i];
+        for (int64_t j = 0; j < N; ++j) q[(cb * NP + i) * NP + j] = bdrf_q[(cb * N + i) * N + j];
+      }
+    UP(d.bdrfq, q.data(), C * NB * NP * NP);
+    UP(d.bdrfq0, q0.data(), C * NB * NP);
+  }
+#undef UP
+  HIP_TRY(hipStreamSynchronize(s));  // host staging vectors go out of scope
+  p->have_cols = true;
+  p->solved = false;
+  return 0;
+}
+
+int rtd_plan_solve(rtd_plan* p) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  if (!p->have_quad || !p->have_cols) return fail(RTD_ERR_STATE, "set_quadrature and set_columns must precede solve");
+  HIP_TRY(hipSetDevice(p->device));
+  return launch_solve(p, false, nullptr);
+}
+
+int rtd_plan_set_eval_points(rtd_plan* p, int32_t ntau, const double* tau, int32_t nphi, const double* phi) {
+  if (!p || !tau || ntau < 1 || nphi < 0 || (nphi > 0 && !phi)) return fail(RTD_ERR_ARG, "bad evaluation points");
+  HIP_TRY(hipSetDevice(p->device));
+  const int64_t C = p->d.C, Qr = 2 * p->d.N;
+  int rc;
+  if ((rc = grow(p, &p->ev_tau, &p->cap_tau, C * ntau))) return rc;
+  if ((rc = grow(p, &p->ev_phi, &p->cap_phi, nphi > 0 ? nphi : 1))) return rc;
+  if ((rc = grow(p, &p->ev_u, &p->cap_u, C * Qr * ntau * (nphi > 0 ? nphi : 1)))) return rc;
+  if ((rc = grow(p, &p->ev_u0, &p->cap_u0, 2 * C * Qr * ntau))) return rc;  // u0 and ulast
+  if ((rc = grow(p, &p->ev_fl, &p->cap_fl, 3 * C * ntau))) return rc;
+  HIP_TRY(hipMemcpyAsync(p->ev_tau, tau, (size_t)(C * ntau) * 8, hipMemcpyHostToDevice, p->stream));
+  if (nphi > 0) HIP_TRY(hipMemcpyAsync(p->ev_phi, phi, (size_t)nphi * 8, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->ev_ntau = ntau;
+  p->ev_nphi = nphi;
+  return 0;
+}
+
+static RtdEval make_eval(rtd_plan* p, int antider, bool want_u) {
+  RtdEval e{};
+  const int64_t C = p->d.C, Qr = 2 * p->d.N;
+  e.ntau = p->ev_ntau;
+  e.nphi = p->ev_nphi;
+  e.antider = antider;
+  e.tau = p->ev_tau;
+  e.phi = p->ev_phi;
+  e.u = (want_u && p->ev_nphi > 0) ? p->ev_u : nullptr;
+  e.u0 = p->ev_u0;
+  e.ulast = p->ev_u0 + C * Qr * p->ev_ntau;
+  e.fup = p->ev_fl;
+  e.fdn = p->ev_fl + C * p->ev_ntau;
+  e.fdir = p->ev_fl + 2 * C * p->ev_ntau;
+  return e;
+}
+
+int rtd_plan_run(rtd_plan* p) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  if (!p->have_quad || !p->have_cols || p->ev_ntau < 1) return fail(RTD_ERR_STATE, "inputs or evaluation points missing");
+  HIP_TRY(hipSetDevice(p->device));
+  RtdEval e = make_eval(p, 0, true);
+  return launch_solve(p, true, &e);
+}
+
+int rtd_plan_fetch(rtd_plan* p, double* u, double* u0, double* flux_up, double* fdn, double* fdir) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  if (p->ev_ntau < 1 || !p->solved) return fail(RTD_ERR_STATE, "nothing to fetch");
+  HIP_TRY(hipSetDevice(p->device));
+  const int64_t C = p->d.C, Qr = 2 * p->d.N, nt = p->ev_ntau, np = p->ev_nphi;
+  hipStream_t s = p->stream;
+  if (u && np > 0) HIP_TRY(hipMemcpyAsync(u, p->ev_u, (size_t)(C * Qr * nt * np) * 8, hipMemcpyDeviceToHost, s));
+  if (u0) HIP_TRY(hipMemcpyAsync(u0, p->ev_u0, (size_t)(C * Qr * nt) * 8, hipMemcpyDeviceToHost, s));
+  if (flux_up) HIP_TRY(hipMemcpyAsync(flux_up, p->ev_fl, (size_t)(C * nt) * 8, hipMemcpyDeviceToHost, s));
+  if (fdn) HIP_TRY(hipMemcpyAsync(fdn, p->ev_fl + C * nt, (size_t)(C * nt) * 8, hipMemcpyDeviceToHost, s));
+  if (fdir) HIP_TRY(hipMemcpyAsync(fdir, p->ev_fl + 2 * C * nt, (size_t)(C * nt) * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  int st = 0;
+  HIP_TRY(hipMemcpy(&st, p->d.status, sizeof(int), hipMemcpyDeviceToHost));
+  if (st & 1) {
+    HIP_TRY(hipMemset(p->d.status, 0, sizeof(int)));
+    return fail(RTD_ERR_TAU_RANGE, "tau input outside the tau range specified for the atmosphere");
+  }
+  return 0;
+}
+
+int rtd_plan_result_dev_ptrs(rtd_plan* p, void** u_dev, int64_t* u_bytes, void** flux_dev, int64_t* flux_bytes) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  const int64_t C = p->d.C, Qr = 2 * p->d.N, nt = p->ev_ntau, np = p->ev_nphi;
+  if (u_dev) *u_dev = p->ev_u;
+  if (u_bytes) *u_bytes = C * Qr * nt * np * 8;
+  if (flux_dev) *flux_dev = p->ev_fl;
+  if (flux_bytes) *flux_bytes = 3 * C * nt * 8;
+  return 0;
+}
+
+int rtd_plan_evaluate(rtd_plan* p, int32_t ntau, const double* tau, int32_t nphi, const double* phi,
+                      int32_t antiderivative, double* u, double* u0, double* flux_up, double* fdn, double* fdir,
+                      double* ulast) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  if (!p->solved) return fail(RTD_ERR_STATE, "evaluate before solve");
+  int rc = rtd_plan_set_eval_points(p, ntau, tau, nphi, phi);
+  if (rc) return rc;
+  RtdEval e = make_eval(p, antiderivative, u != nullptr);
+  if (p->timing) {
+    (void)hipStreamSynchronize(p->stream);
+    harvest(p);
+    (void)hipEventRecord(p->evt[3], p->stream);
+  }
+  rtd_launch_eval(p->d, e, p->stream);
+  if (p->timing) {
+    (void)hipEventRecord(p->evt[4], p->stream);
+    p->pending[3] = true;
+  }
+  hipError_t er = hipGetLastError();
+  if (er != hipSuccess) return fail(RTD_ERR_HIP, std::string("eval launch: ") + hipGetErrorString(er));
+  rc = rtd_plan_fetch(p, u, u0, flux_up, fdn, fdir);
+  if (rc) return rc;
+  if (ulast) {
+    const int64_t C = p->d.C, Qr = 2 * p->d.N;
+    HIP_TRY(hipMemcpy(ulast, p->ev_u0 + C * Qr * ntau, (size_t)(C * Qr * ntau) * 8, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+int rtd_plan_get_tensors(rtd_plan* p, int32_t column, double* GC, double* K, double* B, double* Gim, double* G) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  if (!p->solved) return fail(RTD_ERR_STATE, "get_tensors before solve");
+  if (column < 0 || column >= p->d.C) return fail(RTD_ERR_ARG, "column out of range");
+  HIP_TRY(hipSetDevice(p->device));
+  const int64_t M = p->d.M, L = p->d.L, Qr = 2 * p->d.N;
+  const int64_t nG = M * L * Qr * Qr, nK = M * L * Qr, nZ = L * Qr;
+  if (!p->ex_buf) {
+    int rc = p->alloc(&p->ex_buf, 2 * nG + 2 * nK + nZ);
+    if (rc) return rc;
+  }
+  double *dGC = p->ex_buf, *dG = dGC + nG, *dK = dG + nG, *dB = dK + nK, *dZ = dB + nK;
+  HIP_TRY(hipMemsetAsync(dZ, 0, (size_t)nZ * 8, p->stream));
+  rtd_launch_export(p->d, column, dGC, dK, dB, dZ, dG, p->stream);
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  if (GC) HIP_TRY(hipMemcpy(GC, dGC, (size_t)nG * 8, hipMemcpyDeviceToHost));
+  if (G) HIP_TRY(hipMemcpy(G, dG, (size_t)nG * 8, hipMemcpyDeviceToHost));
+  if (K) HIP_TRY(hipMemcpy(K, dK, (size_t)nK * 8, hipMemcpyDeviceToHost));
+  if (B) HIP_TRY(hipMemcpy(B, dB, (size_t)nK * 8, hipMemcpyDeviceToHost));
+  if (Gim) HIP_TRY(hipMemcpy(Gim, dZ, (size_t)nZ * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int rtd_plan_enable_timing(rtd_plan* p, int32_t enable) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  p->timing = enable != 0;
+  return 0;
+}
+
+int rtd_plan_get_timing(rtd_plan* p, double ms[4], int64_t nlaunch[4], int32_t reset) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  harvest(p);
+  for (int k = 0; k < 4; ++k) {
+    if (ms) ms[k] = p->ms[k];
+    if (nlaunch) nlaunch[k] = p->nlaunch[k];
+    if (reset) {
+      p->ms[k] = 0;
+      p->nlaunch[k] = 0;
+    }
+  }
+  return 0;
+}
+
+int rtd_plan_max_sweeps(rtd_plan* p, int32_t* sweeps) {
+  if (!p || !sweeps) return fail(RTD_ERR_ARG, "null argument");
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  int v = 0;
+  HIP_TRY(hipMemcpy(&v, p->d.sweeps, sizeof(int), hipMemcpyDeviceToHost));
+  *sweeps = v;
+  return 0;
+}
+
+}  // extern "C"

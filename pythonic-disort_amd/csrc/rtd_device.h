@@ -1,0 +1,52 @@
+// rtd_device.h -- shared declarations of the HIP kernels behind include/rtd.h (gfx950 only).
+//
+// Device-side layout (all float64, NP = per-hemisphere stream count padded to a power of two,
+// Q2 = 2*NP; padded streams have mu = 2, w = 0 and decouple exactly):
+//   Gp, Gm   [C][M][L][NP][NP]  the two distinct blocks of the reference's eigenvector matrix
+//                               G = [[Gp, Gm],[Gm, Gp]]  (_solve_for_gen_and_part_sols.py:192-198),
+//                               row = stream, column = eigen-index
+//   kk       [C][M][L][NP]      positive eigenvalues k;   K = [-k, +k]      (:186-187)
+//   Bv       [C][M][L][Q2]      beam particular solution  [B+ ; B-]         (:209-231)
+//   dq       [C][L][Ns][Q2]     isotropic-source particular solution as polynomial coefficient
+//                               vectors: v(tau) = sum_q dq[q] tau^q         (subroutines.py:746-862)
+//   zneg     [C][L][NP]         first half of G^-1 [1/mu ; -1/mu]  (second half is its negative)
+//   coef     [C][M][L][Q2]      BC coefficients [C- ; C+]                   (_solve_for_coeffs.py)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct RtdDev {
+  // sizes
+  int C, L, N, NP, P, M, Ns, NBDRF, beam;
+  // quadrature (padded to NP)
+  const double *mu, *w, *invmu, *S, *T;  // S = sqrt(w/mu), T = sqrt(w*mu) (1 for padding)
+  // Legendre tables
+  double* Y;   // [M][P][NP]   normalised associated Legendre functions at the quadrature nodes
+  double* Y0;  // [C][M][P]    the same at -mu0 of each column
+  // per-column inputs
+  const double *omega, *tau, *taus0, *scale, *wleg, *mu0, *I0, *phi0, *rescale;
+  const double *bpos, *bneg;  // [C][M][NP]
+  const double* spoly;        // [C][L][Ns]
+  const double *bdrfq, *bdrfq0;  // [C][NBDRF][NP][NP], [C][NBDRF][NP]
+  // intermediates
+  double *Gp, *Gm, *kk, *Bv, *dq, *zneg, *coef;
+  double *Lw, *Qw;    // eigen-stage workspace [C][M][L][NP][NP]: Cholesky factor L, symmetrised Qm
+  double *Fws, *yws;  // BC workspace: [C][M][L-1][Q2][Q2] (column-major per block), [C][M][L-1][Q2]
+  int* sweeps;        // [1] max Jacobi sweeps (diagnostic)
+  int* status;        // [1] device-side status flags (bit 0: tau out of range)
+};
+
+struct RtdEval {
+  int ntau, nphi, antider;
+  const double* tau;  // [C][ntau]
+  const double* phi;  // [nphi]
+  double *u, *u0, *fup, *fdn, *fdir, *ulast;  // device outputs (may be null)
+};
+
+// launchers (one per translation unit)
+void rtd_launch_tables(const RtdDev& d, hipStream_t s);
+void rtd_launch_eig(const RtdDev& d, hipStream_t s);
+void rtd_launch_bc(const RtdDev& d, hipStream_t s);
+void rtd_launch_eval(const RtdDev& d, const RtdEval& e, hipStream_t s);
+void rtd_launch_export(const RtdDev& d, int col, double* GC, double* K, double* B, double* Gim, double* G,
+                       hipStream_t s);

@@ -1,0 +1,549 @@
+// rtd_eig.hip -- per (column, Fourier mode, layer) eigen stage on gfx950.
+//
+// Replaces _solve_for_gen_and_part_sols (src/PythonicDISORT/_solve_for_gen_and_part_sols.py:5-243):
+//   Legendre tables (:96-109)  -> rtd_tables_* kernels (normalised three-term recurrences)
+//   D+/D-, alpha, beta (:123-135), eig((alpha-beta)(alpha+beta)) (:179-183), G blocks (:186-198),
+//   beam particular solution (:143-152, :209-231), G^-1 [1/mu;-1/mu] (:203-205 + _assemble.py:124)
+//   and the isotropic-source particular solution coefficients (subroutines.py:746-862)
+//   -> rtd_eig_kernel<NP>.
+//
+// Algorithm (own design, not the reference's LAPACK calls): with T = diag(sqrt(mu w)) the matrices
+// -(T(alpha+beta)T^-1) = Pm and -(T(alpha-beta)T^-1) = Qm are symmetric positive definite, so with
+// the Cholesky factor Pm = L L^T the non-symmetric problem (alpha-beta)(alpha+beta) v = k^2 v becomes
+// the symmetric H z = k^2 z, H = L^T Qm L, solved by a parallel-order (XOR round-robin) cyclic
+// Jacobi iteration.  One problem occupies NP lanes of a wavefront (64/NP problems per wave); lane j
+// owns column j of every matrix in registers; columns are exchanged with cross-lane swizzles,
+// rotation parameters and small vectors through LDS.
+#include "rtd_device.h"
+
+namespace {
+
+// compiler-only barrier: keeps the scheduler from hoisting a whole unrolled loop's LDS loads
+#define RTD_FENCE() asm volatile("" ::: "memory")
+
+template <int MASK>
+__device__ __forceinline__ double xor_lane(double v) {
+  // value of lane (lane ^ MASK); MASK < 32.  ds_swizzle bit-mode: and=0x1f, or=0, xor=MASK
+  constexpr int pat = (MASK << 10) | 0x1F;
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_ds_swizzle(lo, pat);
+  hi = __builtin_amdgcn_ds_swizzle(hi, pat);
+  return __hiloint2double(hi, lo);
+}
+
+constexpr __host__ __device__ int high_bit(int t) {
+  int b = 1;
+  while ((b << 1) <= t) b <<= 1;
+  return b;
+}
+
+// One parallel Jacobi step: all pairs (j, j^T) are rotated at once.
+// hx[s] = H[j^s][j] (XOR-relative rows), zc[i] = Z[i][j].
+template <int NP, int T>
+struct JacobiStep {
+  static __device__ __forceinline__ void run(double (&hx)[NP], double (&zc)[NP], const int j, double* cs,
+                                             double& offacc) {
+    const double app = hx[0];
+    const double aqq = xor_lane<T>(app);
+    const bool lo = (j & high_bit(T)) == 0;  // j < j^T
+    // both lanes of a pair use the lower lane's copy of H[p][q] so that (c, s) are bitwise identical
+    const double apq_own = hx[T];
+    const double apq_oth = xor_lane<T>(apq_own);
+    const double apq = lo ? apq_own : apq_oth;
+    double c = 1.0, sg = 0.0;
+    if (apq != 0.0) {
+      const double alo = lo ? app : aqq, ahi = lo ? aqq : app;
+      const double zeta = (ahi - alo) / (2.0 * apq);
+      const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+      c = 1.0 / sqrt(1.0 + tt * tt);
+      const double s = tt * c;
+      sg = lo ? -s : s;
+    }
+    offacc += apq * apq;
+    // opaque copy of the lane index: stops the compiler from hoisting the 8 x 15 LDS addresses of the
+    // (c, sg) look-ups out of the sweep loop (they would occupy > 100 VGPRs)
+    int jv = j;
+    asm volatile("" : "+v"(jv));
+    // publish (c, sg) of this lane's pair for the row rotations
+    cs[2 * j] = c;
+    cs[2 * j + 1] = sg;
+    __syncthreads();
+    // H <- J^T (H J), two registers at a time: column rotation W[:, j] = c H[:, j] + sg H[:, j^T],
+    // then the row rotation of rows (i, i^T), i = j^s, with that pair's parameters
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      if (s < (s ^ T)) {
+        const double wa = c * hx[s] + sg * xor_lane<T>(hx[s ^ T]);
+        const double wb = c * hx[s ^ T] + sg * xor_lane<T>(hx[s]);
+        const int i = jv ^ s;
+        const double ci = cs[2 * i], sgi = cs[2 * i + 1];
+        hx[s] = ci * wa + sgi * wb;
+        hx[s ^ T] = ci * wb - sgi * wa;
+        __builtin_amdgcn_sched_barrier(0);  // bound the live swizzle results (register pressure)
+      }
+    }
+    // eigenvector accumulation Z <- Z J
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      zc[i] = c * zc[i] + sg * xor_lane<T>(zc[i]);
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    JacobiStep<NP, T + 1>::run(hx, zc, j, cs, offacc);
+  }
+};
+template <int NP>
+struct JacobiStep<NP, NP> {
+  static __device__ __forceinline__ void run(double (&)[NP], double (&)[NP], const int, double*, double&) {}
+};
+
+// sum over the NP lanes of a group (result in every lane)
+template <int NP>
+__device__ __forceinline__ double group_sum(double v) {
+  if (NP > 1) v += xor_lane<1>(v);
+  if (NP > 2) v += xor_lane<2>(v);
+  if (NP > 4) v += xor_lane<4>(v);
+  if (NP > 8) v += xor_lane<8>(v);
+  if (NP > 16) v += xor_lane<16>(v);
+  return v;
+}
+
+// problem index of this lane's group; invalid groups redo the last problem and skip their stores
+struct ProbId {
+  long pid;
+  int c, m, l;
+  bool valid;
+};
+template <int NP>
+__device__ __forceinline__ ProbId locate(const RtdDev& d) {
+  constexpr int GPW = 64 / NP;
+  const long nprob = (long)d.C * d.M * d.L;
+  ProbId p;
+  p.pid = (long)blockIdx.x * GPW + threadIdx.x / NP;
+  p.valid = p.pid < nprob;
+  if (!p.valid) p.pid = nprob - 1;
+  p.l = (int)(p.pid % d.L);
+  p.m = (int)((p.pid / d.L) % d.M);
+  p.c = (int)(p.pid / ((long)d.L * d.M));
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 1: assemble Pm, Qm (symmetrised alpha+-beta), Cholesky Pm = L L^T, H = L^T Qm L.
+// Workspace written: Lw [prob][NP][NP] (row-major L), Qw [prob][NP][NP] (Qm),
+//                    Hx (aliases Gp) [prob][s][j] = H[j^s][j].
+// ------------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_asm_kernel(RtdDev d) {
+  constexpr int GPW = 64 / NP;
+  constexpr int LD = NP + 1;
+  __shared__ double sL[GPW][NP * LD];
+  __shared__ double sQ[GPW][NP * LD];
+  const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
+  const ProbId id = locate<NP>(d);
+  const int P = d.P, m = id.m;
+  double* L_ = sL[grp];
+  double* Q_ = sQ[grp];
+  const double* wl = d.wleg + ((long)id.c * d.L + id.l) * P;
+  const double om = d.omega[(long)id.c * d.L + id.l];
+  const double* Ym = d.Y + (long)m * P * NP;
+
+  // D+/D- split by parity of (l - m): Ae = 2 sum_even c_l Y_l Y_l^T, Ao likewise (:123-125)
+  double acc_e[NP], acc_o[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) acc_e[i] = acc_o[i] = 0.0;
+  double cmax = 0.0;
+  for (int ell = m; ell < P; ell += 2) {
+    {
+      const double cl = 0.5 * om * wl[ell];
+      cmax = fmax(cmax, fabs(cl));
+      const double* Yr = Ym + (long)ell * NP;
+      const double coef = 2.0 * cl * Yr[j];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) acc_e[i] += coef * Yr[i];
+    }
+    if (ell + 1 < P) {
+      const double cl = 0.5 * om * wl[ell + 1];
+      cmax = fmax(cmax, fabs(cl));
+      const double* Yr = Ym + (long)(ell + 1) * NP;
+      const double coef = 2.0 * cl * Yr[j];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) acc_o[i] += coef * Yr[i];
+    }
+  }
+  // "shortcut" of the reference when multiple scattering is insignificant (:119, :162-168): the layer
+  // is treated as non-scattering; the general path then gives G = [[0,D],[D,0]], k = 1/mu, B = 0.
+  if (!(cmax > 1e-8)) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) acc_e[i] = acc_o[i] = 0.0;
+  }
+  const double invmu_j = d.invmu[j], S_j = d.S[j];
+  double pcol[NP];
+  double* Qw = d.Qw + id.pid * NP * NP;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const double Si = d.S[i];
+    pcol[i] = (i == j ? invmu_j : 0.0) - Si * acc_e[i] * S_j;  // Pm = M^-1 - S Ae S
+    const double qv = (i == j ? invmu_j : 0.0) - Si * acc_o[i] * S_j;  // Qm = M^-1 - S Ao S
+    Q_[i * LD + j] = qv;
+    if (id.valid) Qw[i * NP + j] = qv;
+  }
+  // Cholesky Pm = L L^T, column j in lane j (trailing matrix kept symmetric)
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const double akk = __shfl(pcol[k], k, NP);
+    const double rinv = 1.0 / sqrt(akk);
+    const double ljk = pcol[k] * rinv;  // L[j][k] by symmetry (meaningful for j > k)
+#pragma unroll
+    for (int i = k + 1; i < NP; ++i) {
+      const double lik = __shfl(pcol[i], k, NP) * rinv;
+      if (j > k) pcol[i] -= lik * ljk;
+      if (j == k) pcol[i] = lik;
+    }
+    if (j == k) pcol[k] = akk * rinv;
+  }
+  double* Lw = d.Lw + id.pid * NP * NP;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const double v = (i >= j) ? pcol[i] : 0.0;
+    pcol[i] = v;
+    L_[i * LD + j] = v;
+    if (id.valid) Lw[i * NP + j] = v;
+  }
+  __syncthreads();
+  // H = L^T Qm L; lane j: w = Qm L[:, j], then hx[s] = H[j^s][j] = sum_r L[r][j^s] w[r]
+  double wv[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    double a = 0.0;
+#pragma unroll
+    for (int r = 0; r < NP; ++r) a += Q_[i * LD + r] * pcol[r];
+    wv[i] = a;
+  }
+  double* Hx = d.Gp + id.pid * NP * NP;
+#pragma unroll
+  for (int s = 0; s < NP; ++s) {
+    const int col = j ^ s;
+    double a = 0.0;
+#pragma unroll
+    for (int r = 0; r < NP; ++r) a += L_[r * LD + col] * wv[r];
+    if (id.valid) Hx[s * NP + j] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 2: cyclic Jacobi (XOR round-robin ordering) on H; k^2 -> kk (squared, fixed up in stage 3),
+// Z -> Zw (aliases Gm) [prob][i][j].
+// ------------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(64, (NP <= 8 ? 4 : (NP == 16 ? 2 : 1))) void rtd_jacobi_kernel(RtdDev d) {
+  constexpr int GPW = 64 / NP;
+  __shared__ double sCS[GPW][2 * NP];
+  const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
+  const ProbId id = locate<NP>(d);
+  double* cs = sCS[grp];
+  const double* Hx = d.Gp + id.pid * NP * NP;
+  double hx[NP], zc[NP];
+#pragma unroll
+  for (int s = 0; s < NP; ++s) {
+    hx[s] = Hx[s * NP + j];
+    zc[s] = (s == j) ? 1.0 : 0.0;
+  }
+  int nsweep = 0;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double offacc = 0.0;
+    JacobiStep<NP, 1>::run(hx, zc, j, cs, offacc);
+    ++nsweep;
+    const double off = group_sum<NP>(offacc);
+    const double dg = group_sum<NP>(hx[0] * hx[0]);
+    // the off-diagonal mass seen during this sweep was already negligible -> converged
+    if (__all(off <= 1e-26 * dg)) break;
+  }
+  if (threadIdx.x == 0 && nsweep > *(volatile int*)d.sweeps) atomicMax(d.sweeps, nsweep);
+  if (id.valid) {
+    d.kk[id.pid * NP + j] = hx[0];
+    double* Zw = d.Gm + id.pid * NP * NP;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) Zw[i * NP + j] = zc[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 3: eigenvector blocks Gp/Gm, k, isotropic-source coefficients, beam particular solution.
+// ------------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev d) {
+  constexpr int GPW = 64 / NP;
+  constexpr int LD = NP + 1;
+  __shared__ double sL[GPW][NP * LD];
+  __shared__ double sQ[GPW][NP * LD];
+  __shared__ double sV[GPW][3][NP];
+  const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
+  const ProbId id = locate<NP>(d);
+  const int P = d.P, m = id.m, c = id.c, l = id.l;
+  const bool valid = id.valid;
+  double* L_ = sL[grp];
+  double* Q_ = sQ[grp];
+  double* v0 = sV[grp][0];
+  double* v1 = sV[grp][1];
+  double* v2 = sV[grp][2];
+  const long base = id.pid;
+  double zc[NP];
+  {
+    const double* Lw = d.Lw + base * NP * NP;
+    const double* Qw = d.Qw + base * NP * NP;
+    const double* Zw = d.Gm + base * NP * NP;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      L_[i * LD + j] = Lw[i * NP + j];
+      Q_[i * LD + j] = Qw[i * NP + j];
+      zc[i] = Zw[i * NP + j];
+    }
+  }
+  const double k2 = d.kk[base * NP + j];
+  const double kj = sqrt(k2);
+  const double invmu_j = d.invmu[j], T_j = d.T[j];
+  __syncthreads();
+
+  // eigenvector blocks: Vt = T^-1 L^-T Z, Ut = -T^-1 L Z / k ; Gp = Vt + Ut, Gm = Vt - Ut (:190-198)
+  double gp[NP], gm[NP];
+  {
+    double y[NP];
+#pragma unroll
+    for (int i = NP - 1; i >= 0; --i) {
+      double a = zc[i];
+#pragma unroll
+      for (int r = i + 1; r < NP; ++r) a -= L_[r * LD + i] * y[r];
+      y[i] = a / L_[i * LD + i];
+      RTD_FENCE();
+    }
+    const double rk = 1.0 / kj;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      double a = 0.0;
+#pragma unroll
+      for (int r = 0; r <= i; ++r) a += L_[i * LD + r] * zc[r];
+      const double rT = 1.0 / d.T[i];
+      const double vt = y[i] * rT, ut = -a * rk * rT;
+      gp[i] = vt + ut;
+      gm[i] = vt - ut;
+      RTD_FENCE();
+    }
+  }
+  if (valid) {
+    double* Gp = d.Gp + base * NP * NP;
+    double* Gm = d.Gm + base * NP * NP;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      Gp[i * NP + j] = gp[i];
+      Gm[i * NP + j] = gm[i];
+    }
+    d.kk[base * NP + j] = kj;
+  }
+
+  // isotropic (thermal) source, Fourier mode 0 only (subroutines.py:746-862, _assemble.py:124).
+  // Every group runs the barriers below; only groups with m == 0 store.
+  if (d.Ns > 0) {
+    const bool act = (m == 0);
+    // q = L^-1 (T / mu) by forward substitution distributed over the lanes
+    double cur = T_j * invmu_j, q_j = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const double qi = __shfl(cur, i, NP) / L_[i * LD + i];
+      if (j == i) q_j = qi;
+      if (j > i) cur -= L_[j * LD + i] * qi;
+    }
+    v0[j] = q_j;
+    __syncthreads();
+    double zn = 0.0;  // zneg_j = -k_j/2 sum_i Z[i][j] q[i]
+#pragma unroll
+    for (int i = 0; i < NP; ++i) zn += zc[i] * v0[i];
+    zn *= -0.5 * kj;
+    if (valid && act) d.zneg[((long)c * d.L + l) * NP + j] = zn;
+    const double* sp = d.spoly + ((long)c * d.L + l) * d.Ns;
+    const double rk = 1.0 / kj;
+    for (int q = 0; q < d.Ns; ++q) {
+      // b_q(K) = sum_{jj>=q} jj!/q! a_jj K^-(jj-q+1), K = -k (first N eigen-columns) and +k
+      double bneg = 0.0, bpos = 0.0, ratio = 1.0, pw_pos = rk, pw_neg = -rk;
+      for (int jj = q; jj < d.Ns; ++jj) {
+        bpos += ratio * sp[jj] * pw_pos;
+        bneg += ratio * sp[jj] * pw_neg;
+        ratio *= (double)(jj + 1);
+        pw_pos *= rk;
+        pw_neg *= -rk;
+      }
+      const double a = zn * bneg, b = -zn * bpos;
+      // up-streams: Gp a + Gm b ; down-streams: Gm a + Gp b  (sum over eigen-index = lanes)
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NP; ++i) Q_[i * LD + j] = gp[i] * a + gm[i] * b;
+      __syncthreads();
+      double up = 0.0;
+#pragma unroll
+      for (int r = 0; r < NP; ++r) up += Q_[j * LD + r];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NP; ++i) Q_[i * LD + j] = gm[i] * a + gp[i] * b;
+      __syncthreads();
+      double dn = 0.0;
+#pragma unroll
+      for (int r = 0; r < NP; ++r) dn += Q_[j * LD + r];
+      if (valid && act) {
+        double* dq = d.dq + (((long)c * d.L + l) * d.Ns + q) * 2 * NP;
+        dq[j] = up;
+        dq[NP + j] = dn;
+      }
+    }
+    __syncthreads();
+    // Qm is needed again by the beam stage
+    if (d.beam) {
+      const double* Qw = d.Qw + base * NP * NP;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) Q_[i * LD + j] = Qw[i * NP + j];
+      __syncthreads();
+    }
+  }
+
+  // beam particular solution (:143-152, :226-231) through the spectral decomposition:
+  //  s = B+ + B-, dd = B+ - B- ;  (I/mu0^2 - Qm Pm) T s = T(x+ + x-)/mu0 - Qm T (x+ - x-)
+  //  T dd = mu0 [ T (x+ - x-) - Pm T s ],  Qm Pm = L^-T Z k^2 Z^T L^T
+  if (d.beam) {
+    const double mu0 = d.mu0[c];
+    const double om = d.omega[(long)c * d.L + l];
+    const double* wl = d.wleg + ((long)c * d.L + l) * P;
+    const double* Ym = d.Y + (long)m * P * NP;
+    const double fac = d.I0[c] / (4.0 * M_PI) * (m == 0 ? 1.0 : 2.0) * om;
+    const double* Y0 = d.Y0 + ((long)c * d.M + m) * P;
+    double xe = 0.0, xo = 0.0, cmax = 0.0;  // X^e_j, X^o_j of this lane's stream
+    for (int ell = m; ell < P; ell += 2) {
+      cmax = fmax(cmax, fabs(0.5 * om * wl[ell]));
+      xe += fac * wl[ell] * Y0[ell] * Ym[(long)ell * NP + j];
+      if (ell + 1 < P) {
+        cmax = fmax(cmax, fabs(0.5 * om * wl[ell + 1]));
+        xo += fac * wl[ell + 1] * Y0[ell + 1] * Ym[(long)(ell + 1) * NP + j];
+      }
+    }
+    if (!(cmax > 1e-8)) xe = xo = 0.0;
+    const double txd = 2.0 * T_j * xe * invmu_j;  // T (x+ - x-)
+    v0[j] = txd;
+    __syncthreads();
+    double qv = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) qv += Q_[i * LD + j] * v0[i];
+    const double rhat = 2.0 * T_j * xo * invmu_j / mu0 - qv;
+    v1[j] = rhat;
+    __syncthreads();
+    double g = 0.0;  // g = L^T rhat
+#pragma unroll
+    for (int r = 0; r < NP; ++r) g += L_[r * LD + j] * v1[r];
+    v2[j] = g;
+    __syncthreads();
+    double h = 0.0;  // h = Z^T g / (1/mu0^2 - k^2)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) h += zc[i] * v2[i];
+    h /= (1.0 / (mu0 * mu0) - k2);
+    // e = Z h (cross-lane sum through LDS; Qm is no longer needed)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) Q_[i * LD + j] = zc[i] * h;
+    __syncthreads();
+    double e = 0.0;
+#pragma unroll
+    for (int r = 0; r < NP; ++r) e += Q_[j * LD + r];
+    // shat = L^-T e by back substitution distributed over the lanes
+    double sh = 0.0;
+#pragma unroll
+    for (int i = NP - 1; i >= 0; --i) {
+      const double si = __shfl(e, i, NP) / L_[i * LD + i];
+      if (j == i) sh = si;
+      if (j < i) e -= L_[i * LD + j] * si;
+    }
+    v1[j] = sh;
+    __syncthreads();
+    double tv = 0.0;  // t = L^T shat
+#pragma unroll
+    for (int r = 0; r < NP; ++r) tv += L_[r * LD + j] * v1[r];
+    v2[j] = tv;
+    __syncthreads();
+    double ps = 0.0;  // Pm shat = L t
+#pragma unroll
+    for (int r = 0; r < NP; ++r) ps += L_[j * LD + r] * v2[r];
+    const double rT = 1.0 / T_j;
+    const double s_j = sh * rT;
+    const double d_j = mu0 * (txd - ps) * rT;
+    if (valid) {
+      d.Bv[base * 2 * NP + j] = 0.5 * (s_j + d_j);
+      d.Bv[base * 2 * NP + NP + j] = 0.5 * (s_j - d_j);
+    }
+  }
+}
+
+// ---- Legendre tables: Ybar_l^m(x) = sqrt((l-m)!/(l+m)!) P_l^m(x) without the Condon-Shortley sign
+//      (it cancels in every product the path forms); replaces scipy.special.lpmv/poch (:96-109).
+__device__ __forceinline__ void ybar_column(int m, int P, double x, double* out, long stride) {
+  double v = 1.0;
+  const double sx = sqrt(fmax(0.0, 1.0 - x * x));
+  for (int jj = 1; jj <= m; ++jj) v *= sqrt((2.0 * jj - 1.0) / (2.0 * jj)) * sx;
+  for (int ell = 0; ell < m && ell < P; ++ell) out[ell * stride] = 0.0;
+  if (m >= P) return;
+  double ym1 = 0.0, y = v;
+  out[m * stride] = y;
+  for (int ell = m; ell + 1 < P; ++ell) {
+    const double yn = ((2.0 * ell + 1.0) * x * y - sqrt((double)(ell + m) * (double)(ell - m)) * ym1) /
+                      sqrt((double)(ell + 1 - m) * (double)(ell + 1 + m));
+    ym1 = y;
+    y = yn;
+    out[(ell + 1) * stride] = y;
+  }
+}
+
+__global__ void rtd_tables_quad_kernel(RtdDev d) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // (m, i)
+  if (t >= d.M * d.NP) return;
+  const int m = t / d.NP, i = t % d.NP;
+  double* out = d.Y + (long)m * d.P * d.NP + i;
+  if (i >= d.N) {
+    for (int ell = 0; ell < d.P; ++ell) out[(long)ell * d.NP] = 0.0;
+    return;
+  }
+  ybar_column(m, d.P, d.mu[i], out, d.NP);
+}
+
+__global__ void rtd_tables_mu0_kernel(RtdDev d) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (c, m)
+  if (t >= (long)d.C * d.M) return;
+  const int c = (int)(t / d.M), m = (int)(t % d.M);
+  ybar_column(m, d.P, -d.mu0[c], d.Y0 + t * d.P, 1);
+}
+
+}  // namespace
+
+void rtd_launch_tables(const RtdDev& d, hipStream_t s) {
+  {
+    const int n = d.M * d.NP;
+    hipLaunchKernelGGL(rtd_tables_quad_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d);
+  }
+  if (d.beam) {
+    const long n = (long)d.C * d.M;
+    hipLaunchKernelGGL(rtd_tables_mu0_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, d);
+  }
+}
+
+void rtd_launch_eig(const RtdDev& d, hipStream_t s) {
+  const long nprob = (long)d.C * d.M * d.L;
+  const int gpw = 64 / d.NP;
+  const dim3 grid((unsigned)((nprob + gpw - 1) / gpw));
+#define RTD_EIG_CASE(NPV)                                                        \
+  case NPV:                                                                      \
+    hipLaunchKernelGGL(rtd_asm_kernel<NPV>, grid, dim3(64), 0, s, d);            \
+    hipLaunchKernelGGL(rtd_jacobi_kernel<NPV>, grid, dim3(64), 0, s, d);         \
+    hipLaunchKernelGGL(rtd_post_kernel<NPV>, grid, dim3(64), 0, s, d);           \
+    break;
+  switch (d.NP) {
+    RTD_EIG_CASE(4)
+    RTD_EIG_CASE(8)
+    RTD_EIG_CASE(16)
+    RTD_EIG_CASE(32)
+    default: break;
+  }
+#undef RTD_EIG_CASE
+}

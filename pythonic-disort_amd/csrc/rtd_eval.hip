@@ -1,0 +1,191 @@
+// rtd_eval.hip -- evaluation of the solution at user (tau, phi) points and export of the reference's tensors.
+//
+// Replaces the closures u, u0, flux_up, flux_down of _assemble_intensity_and_fluxes
+// (src/PythonicDISORT/_assemble_intensity_and_fluxes.py:170-330, :334-433, :446-524, :527-613):
+// layer lookup (:185), delta-M tau mapping (:190-195), non-positive exponents (:197-203),
+// GC exp(K dtau) + B exp(-tau*/mu0) + v(tau*) (:221-254), Fourier sum (:256-260), fluxes (:519, :601),
+// rescale (:262), and their is_antiderivative_wrt_tau variants.  One workgroup per (column, tau point);
+// the M x Q x Q temporary of the reference is never formed: G rows are streamed once per point.
+#include "rtd_device.h"
+
+namespace {
+
+constexpr int EVAL_THREADS = 256;
+
+template <int NP>
+__device__ __forceinline__ double group_reduce(double v) {
+#pragma unroll
+  for (int o = NP / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, NP);
+  return v;
+}
+
+template <int NP>
+__global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEval ev) {
+  constexpr int Q = 2 * NP;
+  extern __shared__ double smem[];
+  const int M = d.M, L = d.L, N = d.N;
+  double* e_s = smem;           // [M][Q] scaled exponentials times BC coefficients
+  double* um = smem + M * Q;    // [M][Q] Fourier modes of the intensity at this point
+  __shared__ int s_l;
+  __shared__ double s_ts;
+  const int t = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+  const double tau = ev.tau[(long)c * ev.ntau + t];
+  const double* tau_arr = d.tau + (long)c * L;
+  const double* ts0 = d.taus0 + (long)c * (L + 1);
+  if (tid == 0) {
+    int l = 0;
+    while (l < L - 1 && !(tau <= tau_arr[l])) ++l;  // argmax(tau <= tau_arr)  (:185)
+    if (!(tau >= 0.0) || !(tau <= tau_arr[L - 1])) atomicOr(d.status, 1);
+    s_l = l;
+    s_ts = ts0[l + 1] - (tau_arr[l] - tau) * d.scale[(long)c * L + l];  // (:190-195)
+  }
+  __syncthreads();
+  const int l = s_l;
+  const double ts = s_ts;
+  const double sc = d.scale[(long)c * L + l];
+  const bool antider = ev.antider != 0;
+  const double dtop = ts - ts0[l], dbot = ts0[l + 1] - ts;
+  // exponent * coefficient, both halves non-positive exponents (:197-203)
+  for (int idx = tid; idx < M * NP; idx += EVAL_THREADS) {
+    const int m = idx / NP, jj = idx % NP;
+    const long ml = ((long)c * M + m) * L + l;
+    const double k = d.kk[ml * NP + jj];
+    double en = exp(-k * dtop) * d.coef[ml * Q + jj];
+    double ep = exp(-k * dbot) * d.coef[ml * Q + NP + jj];
+    if (antider) {  // / (scale_tau K), K = -k | +k  (:221-227)
+      en /= (-k * sc);
+      ep /= (k * sc);
+    }
+    e_s[m * Q + jj] = en;
+    e_s[m * Q + NP + jj] = ep;
+  }
+  __syncthreads();
+  const bool beam = d.beam != 0;
+  const double mu0 = beam ? d.mu0[c] : 1.0;
+  double bfac = beam ? exp(-ts / mu0) : 0.0;
+  if (antider) bfac /= (-sc / mu0);
+  // u^m_i = sum_j G_ij e_j + B_i exp(-tau*/mu0) (+ v_i for m = 0): NP lanes per (m, i)
+  const int grp = tid / NP, jj = tid % NP;
+  constexpr int NGRP = EVAL_THREADS / NP;
+  for (int item = grp; item < M * Q; item += NGRP) {
+    const int m = item / Q, i2 = item % Q;
+    const bool up = i2 < NP;
+    const int i = up ? i2 : i2 - NP;
+    const long ml = ((long)c * M + m) * L + l;
+    const double* gp = d.Gp + (ml * NP + i) * NP;
+    const double* gm = d.Gm + (ml * NP + i) * NP;
+    const double en = e_s[m * Q + jj], ep = e_s[m * Q + NP + jj];
+    double part = up ? (gp[jj] * en + gm[jj] * ep) : (gm[jj] * en + gp[jj] * ep);
+    part = group_reduce<NP>(part);
+    if (jj == 0) {
+      double v = part;
+      if (beam) v += d.Bv[ml * Q + i2] * bfac;
+      if (m == 0 && d.Ns > 0) {  // isotropic-source particular solution (subroutines.py:786-862)
+        const double* dq = d.dq + ((long)c * L + l) * d.Ns * Q;
+        double tp = antider ? ts : 1.0;
+        for (int q = 0; q < d.Ns; ++q) {
+          v += dq[q * Q + i2] * (antider ? tp / ((q + 1) * sc) : tp);
+          tp *= ts;
+        }
+      }
+      um[m * Q + i2] = v;
+    }
+  }
+  __syncthreads();
+  const double rescale = d.rescale[c];
+  const int Qr = 2 * N;
+  // intensity: Fourier sum over m with cos(m (phi0 - phi))  (:256-262)
+  if (ev.u != nullptr) {
+    const double phi0 = d.phi0[c];
+    for (int idx = tid; idx < Qr * ev.nphi; idx += EVAL_THREADS) {
+      const int ir = idx / ev.nphi, p = idx % ev.nphi;
+      const int i2 = ir < N ? ir : NP + (ir - N);
+      const double dl = phi0 - ev.phi[p];
+      const double c1 = cos(dl);
+      double ckm1 = 1.0, ck = c1;  // cos(0), cos(dl); Chebyshev recurrence for cos(m dl)
+      double acc = um[i2];
+      for (int m = 1; m < M; ++m) {
+        acc += um[m * Q + i2] * ck;
+        const double cn = 2.0 * c1 * ck - ckm1;
+        ckm1 = ck;
+        ck = cn;
+      }
+      ev.u[(((long)c * Qr + ir) * ev.ntau + t) * ev.nphi + p] = rescale * acc;
+    }
+  }
+  if (tid < Qr) {
+    const int i2 = tid < N ? tid : NP + (tid - N);
+    if (ev.u0 != nullptr) ev.u0[((long)c * Qr + tid) * ev.ntau + t] = rescale * um[i2];
+    if (ev.ulast != nullptr) ev.ulast[((long)c * Qr + tid) * ev.ntau + t] = rescale * um[(M - 1) * Q + i2];
+  }
+  // fluxes from the zeroth mode (:519, :568-601)
+  if (tid == 0 && (ev.fup != nullptr || ev.fdn != nullptr || ev.fdir != nullptr)) {
+    double fu = 0.0, fd = 0.0;
+    for (int i = 0; i < N; ++i) {
+      const double mw = d.mu[i] * d.w[i];
+      fu += mw * um[i];
+      fd += mw * um[NP + i];
+    }
+    double direct = 0.0, direct_s = 0.0;
+    if (beam) {
+      const double I0 = d.I0[c];
+      direct = I0 * mu0 * exp(-tau / mu0);
+      direct_s = I0 * mu0 * exp(-ts / mu0);
+      if (antider) {
+        direct *= -mu0;
+        direct_s /= (-sc / mu0);
+      }
+    }
+    const long o = (long)c * ev.ntau + t;
+    if (ev.fup != nullptr) ev.fup[o] = rescale * 2.0 * M_PI * fu;
+    if (ev.fdn != nullptr) ev.fdn[o] = rescale * (2.0 * M_PI * fd + direct_s - direct);
+    if (ev.fdir != nullptr) ev.fdir[o] = rescale * direct;
+  }
+}
+
+// the reference's tensors of one column, in the reference's layout (unpadded)
+__global__ void rtd_export_kernel(RtdDev d, int col, double* GC, double* K, double* B, double* Gim, double* G) {
+  const int N = d.N, NP = d.NP, Qr = 2 * N, Q = 2 * NP, M = d.M, L = d.L;
+  const long total = (long)M * L * Qr * Qr;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cj = (int)(idx % Qr), ri = (int)((idx / Qr) % Qr);
+    const long ml = idx / ((long)Qr * Qr);
+    const long mlg = (long)col * M * L + ml;
+    const bool rup = ri < N, cneg = cj < N;
+    const int i = rup ? ri : ri - N, j = cneg ? cj : cj - N;
+    // G = [[Gp, Gm],[Gm, Gp]]
+    const double* blk = (rup == cneg) ? d.Gp : d.Gm;
+    const double g = blk[(mlg * NP + i) * NP + j];
+    const double cf = d.coef[mlg * Q + (cneg ? j : NP + j)];
+    if (G) G[idx] = g;
+    if (GC) GC[idx] = g * cf;
+    if (ri == 0) {
+      const double k = d.kk[mlg * NP + j];
+      if (K) K[ml * Qr + cj] = cneg ? -k : k;
+      if (B) B[ml * Qr + cj] = d.beam ? d.Bv[mlg * Q + (cneg ? j : NP + j)] : 0.0;
+      if (Gim && ml < L && d.Ns > 0) {
+        const double z = d.zneg[((long)col * L + ml) * NP + j];
+        Gim[ml * Qr + cj] = cneg ? z : -z;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+void rtd_launch_eval(const RtdDev& d, const RtdEval& e, hipStream_t s) {
+  const dim3 grid((unsigned)e.ntau, (unsigned)d.C);
+  const size_t shm = (size_t)2 * d.M * 2 * d.NP * sizeof(double);
+  switch (d.NP) {
+    case 4: hipLaunchKernelGGL(rtd_eval_kernel<4>, grid, dim3(EVAL_THREADS), shm, s, d, e); break;
+    case 8: hipLaunchKernelGGL(rtd_eval_kernel<8>, grid, dim3(EVAL_THREADS), shm, s, d, e); break;
+    case 16: hipLaunchKernelGGL(rtd_eval_kernel<16>, grid, dim3(EVAL_THREADS), shm, s, d, e); break;
+    case 32: hipLaunchKernelGGL(rtd_eval_kernel<32>, grid, dim3(EVAL_THREADS), shm, s, d, e); break;
+    default: break;
+  }
+}
+
+void rtd_launch_export(const RtdDev& d, int col, double* GC, double* K, double* B, double* Gim, double* G,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(rtd_export_kernel, dim3(256), dim3(256), 0, s, d, col, GC, K, B, Gim, G);
+}

@@ -1,0 +1,11 @@
+"""pydisort_amd -- MI355X-native discrete-ordinate radiative-transfer solver.
+
+Drop-in for the hot path of LDEO-CREW/Pythonic-DISORT: ``pydisort`` keeps the reference's signature and
+returned callables; ``pydisort_batch`` solves many independent atmospheric columns per call.  All
+numerics run in hand-written HIP kernels (librtd.so) reached through the C ABI of include/rtd.h.
+"""
+from .pydisort import pydisort  # noqa: F401
+from .batch import pydisort_batch, BatchSolution  # noqa: F401
+from . import subroutines  # noqa: F401
+
+__all__ = ["pydisort", "pydisort_batch", "BatchSolution", "subroutines"]

@@ -1,0 +1,133 @@
+"""Thin object wrapper over a device plan (include/rtd.h): uploads prepared columns, launches the HIP
+path, evaluates at (tau, phi).  Host arrays are NumPy float64; nothing here computes on the CPU."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Plan:
+    def __init__(self, prep, device=0):
+        """prep: dict from _prepare.prepare_columns."""
+        lib = _lib.load()
+        self._lib = lib
+        self.prep = prep
+        self.C, self.L, self.N, self.Q = prep["C"], prep["L"], prep["N"], 2 * prep["N"]
+        self.M = prep["M"]
+        dims = _lib.rtd_dims(prep["C"], prep["L"], 2 * prep["N"], prep["P"], prep["M"], prep["Ns"],
+                             prep["NBDRF"], int(prep["beam"]))
+        h = C.c_void_p()
+        _lib.check(lib.rtd_plan_create(C.byref(dims), device, C.byref(h)))
+        self._h = h
+        mu, w = _f64(prep["mu"]), _f64(prep["W"])
+        _lib.check(lib.rtd_plan_set_quadrature(h, _lib.dptr(mu), _lib.dptr(w)))
+        keys = ["omega_s", "tau", "tau_s0", "scale_tau", "wleg", "mu0", "I0", "phi0", "rescale",
+                "b_pos", "b_neg", "s_s", "bdrf_q", "bdrf_q0"]
+        arrs = [_f64(prep[k]) for k in keys]
+        _lib.check(lib.rtd_plan_set_columns(h, *[_lib.dptr(a) for a in arrs]))
+        self.solved = False
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.rtd_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self):
+        _lib.check(self._lib.rtd_plan_solve(self._h))
+        self.solved = True
+
+    def synchronize(self):
+        _lib.check(self._lib.rtd_plan_synchronize(self._h))
+
+    def device_bytes(self):
+        b = C.c_int64()
+        _lib.check(self._lib.rtd_plan_device_bytes(self._h, C.byref(b)))
+        return b.value
+
+    def evaluate(self, tau, phi=None, antiderivative=False, want=("u", "u0", "flux")):
+        """tau [C, ntau]; phi [nphi] or None -> dict of arrays (u [C,Q,ntau,nphi], u0 [C,Q,ntau],
+        flux_up / flux_down_diffuse / flux_down_direct [C,ntau], ulast [C,Q,ntau])."""
+        tau = _f64(np.atleast_2d(tau))
+        assert tau.shape[0] == self.C
+        ntau = tau.shape[1]
+        phi = _f64(np.atleast_1d(phi)) if phi is not None else None
+        nphi = 0 if phi is None else len(phi)
+        out = {}
+        u = np.empty((self.C, self.Q, ntau, nphi)) if ("u" in want and nphi > 0) else None
+        u0 = np.empty((self.C, self.Q, ntau)) if "u0" in want else None
+        ul = np.empty((self.C, self.Q, ntau)) if "ulast" in want else None
+        fl = [np.empty((self.C, ntau)) for _ in range(3)] if "flux" in want else [None] * 3
+        _lib.check(self._lib.rtd_plan_evaluate(self._h, ntau, _lib.dptr(tau), nphi, _lib.dptr(phi),
+                                               int(bool(antiderivative)), _lib.dptr(u), _lib.dptr(u0),
+                                               _lib.dptr(fl[0]), _lib.dptr(fl[1]), _lib.dptr(fl[2]),
+                                               _lib.dptr(ul)))
+        out.update(u=u, u0=u0, ulast=ul, flux_up=fl[0], flux_down_diffuse=fl[1], flux_down_direct=fl[2])
+        return out
+
+    # ---- throughput form (results stay in HBM until fetch) ----
+    def set_eval_points(self, tau, phi):
+        tau = _f64(np.atleast_2d(tau))
+        phi = _f64(np.atleast_1d(phi))
+        self._ev_shape = (tau.shape[1], len(phi))
+        _lib.check(self._lib.rtd_plan_set_eval_points(self._h, tau.shape[1], _lib.dptr(tau), len(phi),
+                                                      _lib.dptr(phi)))
+
+    def run(self):
+        _lib.check(self._lib.rtd_plan_run(self._h))
+        self.solved = True
+
+    def fetch(self):
+        ntau, nphi = self._ev_shape
+        u = np.empty((self.C, self.Q, ntau, nphi))
+        u0 = np.empty((self.C, self.Q, ntau))
+        fl = [np.empty((self.C, ntau)) for _ in range(3)]
+        _lib.check(self._lib.rtd_plan_fetch(self._h, _lib.dptr(u), _lib.dptr(u0), *[_lib.dptr(a) for a in fl]))
+        return dict(u=u, u0=u0, flux_up=fl[0], flux_down_diffuse=fl[1], flux_down_direct=fl[2])
+
+    def result_dev_ptrs(self):
+        up, fp = C.c_void_p(), C.c_void_p()
+        ub, fb = C.c_int64(), C.c_int64()
+        _lib.check(self._lib.rtd_plan_result_dev_ptrs(self._h, C.byref(up), C.byref(ub), C.byref(fp), C.byref(fb)))
+        return (up.value, ub.value), (fp.value, fb.value)
+
+    def tensors(self, column=0):
+        """The reference's tensors for one column: GC, K, B, G_inv_mu_inv, G."""
+        M, L, Q = self.M, self.L, self.Q
+        GC, G = np.empty((M, L, Q, Q)), np.empty((M, L, Q, Q))
+        K, B, Z = np.empty((M, L, Q)), np.empty((M, L, Q)), np.zeros((L, Q))
+        _lib.check(self._lib.rtd_plan_get_tensors(self._h, column, _lib.dptr(GC), _lib.dptr(K), _lib.dptr(B),
+                                                  _lib.dptr(Z), _lib.dptr(G)))
+        return dict(GC=GC, K=K, B=B, G_inv_mu_inv=Z, G=G)
+
+    def enable_timing(self, on=True):
+        _lib.check(self._lib.rtd_plan_enable_timing(self._h, int(on)))
+
+    def timing(self, reset=True):
+        ms = (C.c_double * 4)()
+        n = (C.c_int64 * 4)()
+        _lib.check(self._lib.rtd_plan_get_timing(self._h, ms, n, int(reset)))
+        names = ("tables", "eig", "bc", "eval")
+        return {k: (ms[i], n[i]) for i, k in enumerate(names)}
+
+    def max_sweeps(self):
+        s = C.c_int32()
+        _lib.check(self._lib.rtd_plan_max_sweeps(self._h, C.byref(s)))
+        return s.value
+
+
+def device_count():
+    n = C.c_int32()
+    lib = _lib.load()
+    rc = lib.rtd_device_count(C.byref(n))
+    return n.value if rc == 0 else 0

@@ -1,0 +1,76 @@
+"""ctypes binding of librtd.so (include/rtd.h).  There is no CPU fallback: if the HIP library is
+missing or fails to load, importing the solver entry points raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtd.so")
+
+
+class rtd_dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("ncols", "nlayers", "nquad", "nleg", "nfourier", "nscoeffs", "nbdrf", "beam")]
+
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+# every symbol include/rtd.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "rtd_version": (C.c_int, []),
+    "rtd_last_error": (C.c_char_p, []),
+    "rtd_device_count": (C.c_int, [C.POINTER(C.c_int32)]),
+    "rtd_plan_create": (C.c_int, [C.POINTER(rtd_dims), C.c_int32, C.POINTER(_vp)]),
+    "rtd_plan_destroy": (C.c_int, [_vp]),
+    "rtd_plan_synchronize": (C.c_int, [_vp]),
+    "rtd_plan_device_bytes": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "rtd_plan_set_quadrature": (C.c_int, [_vp, _dp, _dp]),
+    "rtd_plan_set_columns": (C.c_int, [_vp] + [_dp] * 14),
+    "rtd_plan_solve": (C.c_int, [_vp]),
+    "rtd_plan_evaluate": (C.c_int, [_vp, C.c_int32, _dp, C.c_int32, _dp, C.c_int32] + [_dp] * 6),
+    "rtd_plan_set_eval_points": (C.c_int, [_vp, C.c_int32, _dp, C.c_int32, _dp]),
+    "rtd_plan_run": (C.c_int, [_vp]),
+    "rtd_plan_fetch": (C.c_int, [_vp] + [_dp] * 5),
+    "rtd_plan_result_dev_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_int64), C.POINTER(_vp),
+                                           C.POINTER(C.c_int64)]),
+    "rtd_plan_get_tensors": (C.c_int, [_vp, C.c_int32] + [_dp] * 5),
+    "rtd_plan_enable_timing": (C.c_int, [_vp, C.c_int32]),
+    "rtd_plan_get_timing": (C.c_int, [_vp, _dp, C.POINTER(C.c_int64), C.c_int32]),
+    "rtd_plan_max_sweeps": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
+}
+RTD_ERR_TAU_RANGE = 3
+
+_lib = None
+
+
+def load():
+    """Load librtd.so and declare every prototype; raises if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python pythonic-disort_amd/build.py` "
+                "(pydisort_amd has no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def dptr(a):
+    """float64 C-contiguous array -> double* (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_dp)
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().rtd_last_error().decode()
+        if rc == RTD_ERR_TAU_RANGE:
+            raise ValueError("tau input outside the tau range specified for the atmosphere (check `tau_arr`).")
+        raise RuntimeError(f"librtd error {rc}: {msg}")

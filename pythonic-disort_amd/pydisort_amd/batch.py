@@ -1,0 +1,96 @@
+"""Column-batched entry point: many independent atmospheres per call (no reference equivalent -- the
+reference solves one column per ``pydisort`` call)."""
+import numpy as np
+
+from ._engine import Plan
+from ._prepare import double_gauss, prepare_columns
+
+
+class BatchSolution:
+    """Evaluators over all columns; arrays carry a leading column axis."""
+
+    def __init__(self, plan, prep):
+        self.plan, self.prep = plan, prep
+        self.mu_arr = np.concatenate((prep["mu"], -prep["mu"]))
+
+    def _tau(self, tau):
+        tau = np.asarray(tau, dtype=float)
+        if tau.ndim == 1:
+            tau = np.broadcast_to(tau, (self.prep["C"], len(tau)))
+        if np.any(tau < 0) or np.any(tau > self.prep["tau"][:, -1:]):
+            raise ValueError("tau input outside the tau range specified for the atmosphere (check `tau_arr`).")
+        return np.ascontiguousarray(tau)
+
+    def u(self, tau, phi, is_antiderivative_wrt_tau=False):
+        """-> [C, NQuad, ntau, nphi]"""
+        return self.plan.evaluate(self._tau(tau), phi, is_antiderivative_wrt_tau, want=("u",))["u"]
+
+    def u0(self, tau, is_antiderivative_wrt_tau=False):
+        """-> [C, NQuad, ntau]"""
+        return self.plan.evaluate(self._tau(tau), None, is_antiderivative_wrt_tau, want=("u0",))["u0"]
+
+    def flux_up(self, tau, is_antiderivative_wrt_tau=False):
+        """-> [C, ntau]"""
+        return self.plan.evaluate(self._tau(tau), None, is_antiderivative_wrt_tau, want=("flux",))["flux_up"]
+
+    def flux_down(self, tau, is_antiderivative_wrt_tau=False):
+        """-> (diffuse [C, ntau], direct [C, ntau])"""
+        r = self.plan.evaluate(self._tau(tau), None, is_antiderivative_wrt_tau, want=("flux",))
+        return r["flux_down_diffuse"], r["flux_down_direct"]
+
+
+def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLeg=None, NFourier=None,
+                   b_pos=0, b_neg=0, only_flux=False, f_arr=0, bdrf_q=None, bdrf_q0=None,
+                   s_poly_coeffs=None, device=0):
+    """Like ``pydisort`` with a leading column axis on every atmospheric input:
+    tau_arr, omega_arr, f_arr [C, L]; Leg_coeffs_all [C, L, NLeg_all]; mu0, I0, phi0 [C];
+    b_pos / b_neg: scalar, [C], [C, N] or [C, N, NFourier]; s_poly_coeffs [C, L, Ns];
+    bdrf_q [C, NBDRF, N, N] and bdrf_q0 [C, NBDRF, N]: BDRF Fourier modes tabulated on the quadrature grid.
+    All columns share NQuad, NLeg, NFourier and the layer count.  Returns (mu_arr, BatchSolution)."""
+    tau_arr = np.atleast_2d(np.asarray(tau_arr, float))
+    C, L = tau_arr.shape
+    omega_arr = np.broadcast_to(np.asarray(omega_arr, float), (C, L))
+    Leg = np.asarray(Leg_coeffs_all, float)
+    if Leg.ndim == 2:
+        Leg = np.broadcast_to(Leg[None], (C,) + Leg.shape)
+    N = NQuad // 2
+    NLeg = NQuad if NLeg is None else NLeg
+    NFourier = 1 if only_flux else (NQuad if NFourier is None else NFourier)
+    if NQuad % 2 or NQuad < 2 or NQuad > 64:
+        raise ValueError("NQuad must be even and between 2 and 64.")
+    if not (0 < NFourier <= NLeg <= NQuad and NLeg <= Leg.shape[2]):
+        raise ValueError("Need 0 < NFourier <= NLeg <= NQuad and NLeg <= number of Legendre coefficients provided.")
+    if not (np.all(tau_arr > 0) and np.all(np.diff(tau_arr, axis=1) > 0)):
+        raise ValueError("tau values must be positive and increasing.")
+    if not (np.all(omega_arr >= 0) and np.all(omega_arr < 1)):
+        raise ValueError("Single-scattering albedo must be between 0 and 1, excluding 1.")
+    mu0 = np.broadcast_to(np.asarray(mu0, float), (C,))
+    I0 = np.broadcast_to(np.asarray(I0, float), (C,))
+    phi0 = np.broadcast_to(np.asarray(phi0, float), (C,))
+    if np.any(I0 < 0) or (np.any(I0 > 0) and not np.all((mu0 > 0) & (mu0 <= 1))):
+        raise ValueError("Need I0 >= 0 and 0 < mu0 <= 1 for every column when there is a beam source.")
+
+    def bc(b):
+        b = np.asarray(b, float)
+        out = np.zeros((C, N, NFourier))
+        if b.ndim == 0 or b.shape == (C,):
+            out[:, :, 0] = np.broadcast_to(b, (C,))[:, None]
+        elif b.shape == (C, N):
+            out[:, :, 0] = b
+        elif b.shape == (C, N, NFourier):
+            out[:] = b
+        else:
+            raise ValueError("The shape of a boundary condition is incorrect.")
+        return out
+
+    f_arr = np.broadcast_to(np.asarray(f_arr, float), (C, L))
+    sp = np.zeros((C, L, 0)) if s_poly_coeffs is None or np.all(np.asarray(s_poly_coeffs) == 0) \
+        else np.asarray(s_poly_coeffs, float).reshape(C, L, -1)
+    bq = np.zeros((C, 0, N, N)) if bdrf_q is None else np.asarray(bdrf_q, float)
+    bq0 = np.zeros((C, 0, N)) if bdrf_q0 is None else np.asarray(bdrf_q0, float)
+    prep = prepare_columns(tau_arr, omega_arr, NQuad, Leg, mu0, I0, phi0, NLeg, NFourier, bc(b_pos), bc(b_neg),
+                           f_arr, sp, bq, bq0)
+    plan = Plan(prep, device=device)
+    plan.solve()
+    sol = BatchSolution(plan, prep)
+    return sol.mu_arr, sol

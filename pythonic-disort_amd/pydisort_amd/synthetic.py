@@ -1,0 +1,78 @@
+"""Synthetic batched atmospheres of BASELINE.json's configs: inputs for bench.py
+and for the parity tests.  Deterministic: column c of a config is always the same atmosphere."""
+import numpy as np
+
+
+def cfg4_columns(C, first=0, L=20, NQuad=32, seed=4):
+    """Henyey-Greenstein atmospheres: dtau ~ U(0.05,0.5), omega ~ U(0.5,0.99), g ~ U(0.6,0.85),
+    Leg[l,k] = g_l^k (NQuad+1 moments), f = g^NQuad (delta-M on), mu0 ~ U(0.2,1), I0 = pi, phi0 = 0,
+    black surface, no thermal source.  Column index c uses its own generator default_rng([seed, c])."""
+    tau = np.empty((C, L))
+    omega = np.empty((C, L))
+    g = np.empty((C, L))
+    mu0 = np.empty(C)
+    for i in range(C):
+        rng = np.random.default_rng([seed, first + i])
+        tau[i] = np.cumsum(rng.uniform(0.05, 0.5, L))
+        omega[i] = rng.uniform(0.5, 0.99, L)
+        g[i] = rng.uniform(0.6, 0.85, L)
+        mu0[i] = rng.uniform(0.2, 1.0)
+    k = np.arange(NQuad + 1)
+    Leg = g[:, :, None] ** k[None, None, :]
+    return dict(tau_arr=tau, omega_arr=omega, NQuad=NQuad, Leg_coeffs_all=Leg, mu0=mu0, I0=np.full(C, np.pi),
+                phi0=np.zeros(C), f_arr=g**NQuad)
+
+
+def cfg3_columns(C, first=0, big=True, seed=9):
+    """Test-Problem-9-like multi-layer atmospheres with every layer different, replicated with a
+    per-column perturbation of omega.  big=True: L=8, NQuad=16 (BASELINE wording); False: L=6, NQuad=8."""
+    L, NQuad = (8, 16) if big else (6, 8)
+    tau = np.cumsum(np.arange(1, L + 1)).astype(float)
+    omega0 = 0.6 + np.arange(1, L + 1) * 0.05 * (6 / L)
+    Leg = np.array([[(l + 1) / (L + 1)] for l in range(L)]) ** np.arange(NQuad + 1)[None, :]
+    om = np.empty((C, L))
+    for i in range(C):
+        rng = np.random.default_rng([seed, first + i])
+        om[i] = omega0 * (1 - 0.05 * rng.uniform())
+    s_poly = np.tile(np.array([[0.3, 0.02]]), (C, L, 1))
+    return dict(tau_arr=np.tile(tau, (C, 1)), omega_arr=om, NQuad=NQuad, Leg_coeffs_all=np.tile(Leg, (C, 1, 1)),
+                mu0=np.full(C, 0.5), I0=np.full(C, np.pi), phi0=np.zeros(C), f_arr=0.0,
+                s_poly_coeffs=s_poly, b_pos=0.1, b_neg=0.05,
+                bdrf_q=np.full((C, 1, NQuad // 2, NQuad // 2), 0.5), bdrf_q0=np.full((C, 1, NQuad // 2), 0.5))
+
+
+def cfg5_columns(C, first=0, L=50, NQuad=64, seed=5):
+    """Stress config: 64 streams, 50 layers, 64 Fourier modes, 2-mode BDRF surface, linear thermal source."""
+    base = cfg4_columns(C, first, L, NQuad, seed)
+    N = NQuad // 2
+    x, _ = np.polynomial.legendre.leggauss(N)
+    mu = 0.5 * (x + 1)
+    rho = np.empty(C)
+    for i in range(C):
+        rho[i] = np.random.default_rng([seed + 100, first + i]).uniform(0.05, 0.4)
+    q0 = rho[:, None, None] * (1 + 0.5 * mu[None, :, None] * mu[None, None, :])
+    q1 = rho[:, None, None] * 0.3 * (np.sqrt(1 - mu**2)[None, :, None] * np.sqrt(1 - mu**2)[None, None, :])
+    mu0 = base["mu0"]
+    q00 = rho[:, None] * (1 + 0.5 * mu[None, :] * mu0[:, None])
+    q10 = rho[:, None] * 0.3 * np.sqrt(1 - mu**2)[None, :] * np.sqrt(1 - mu0**2)[:, None]
+    base.update(bdrf_q=np.stack((q0, q1), axis=1), bdrf_q0=np.stack((q00, q10), axis=1),
+                b_pos=0.1 * (1 - rho), s_poly_coeffs=np.tile(np.array([[0.3, 0.02]]), (C, L, 1)))
+    return base
+
+
+def column_kwargs(cfg, i):
+    """The i-th column of a batched config as keyword arguments of the single-column ``pydisort``."""
+    from .pydisort import pydisort  # noqa: F401  (documented pairing)
+
+    kw = dict(tau_arr=cfg["tau_arr"][i], omega_arr=cfg["omega_arr"][i], NQuad=cfg["NQuad"],
+              Leg_coeffs_all=cfg["Leg_coeffs_all"][i], mu0=float(cfg["mu0"][i]), I0=float(cfg["I0"][i]),
+              phi0=float(cfg["phi0"][i]))
+    f = cfg.get("f_arr", 0.0)
+    kw["f_arr"] = f[i] if np.ndim(f) == 2 else f
+    if "s_poly_coeffs" in cfg:
+        kw["s_poly_coeffs"] = cfg["s_poly_coeffs"][i]
+    for b in ("b_pos", "b_neg"):
+        if b in cfg:
+            v = cfg[b]
+            kw[b] = v[i] if np.ndim(v) >= 1 else v
+    return kw
