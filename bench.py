@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: column-solves/sec for 20-layer, 32-stream Henyey-Greenstein atmospheres
+(BASELINE.json configs[3], "cfg4" of SURVEY section 8(d)) on N GPUs of one node.
+
+A step = one pass of the whole hot path (Legendre tables, eigen stage, boundary-condition solve,
+evaluation of u at the 21 layer interfaces x 3 azimuths plus fluxes) over one batch of
+`--columns` synthetic columns per GPU, inputs already resident in HBM.  Columns are independent, so
+ranks shard them with no data-path exchange during the solve (weak scaling: per-GPU work fixed); one
+RCCL all-gather of the flux results per step stitches the outputs.
+
+Prints ONE JSON line on rank 0 (contract in the build prompt) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "pythonic-disort_amd")]
+
+FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector = matrix peak (vendor figure)
+L, NQUAD, NTAU, NPHI = 20, 32, 21, 3
+
+
+def algorithmic_flops():
+    """Per-column algorithmic FLOPs of each stage (F_col = 195 MFLOP for cfg4)."""
+    N, P, M = NQUAD // 2, NQUAD, NQUAD
+    eig = L * (2 * N * N * P * (P + 1) + (2 + 25 + 2 + 5.33) * N**3 * M)
+    bc = L * 36.0 * N**3 * M
+    ev = NTAU * M * (2 * N) * (2 * N) * 2.0
+    return dict(eig=eig, bc=bc, eval=ev, total=eig + bc)
+
+
+def _cpu_worker(args):
+    first, n = args
+    from threadpoolctl import threadpool_limits
+    from oracle import disort_oracle as O
+    from pydisort_amd import synthetic
+    with threadpool_limits(1):
+        cfg = synthetic.cfg4_columns(n, first=first)
+        phi = np.array([0.0, np.pi / 2, np.pi])
+        for i in range(n):
+            res = O.pydisort(**synthetic.column_kwargs(cfg, i))
+            tau = np.concatenate(([0.0], cfg["tau_arr"][i]))
+            res[4](tau, phi), res[1](tau), res[2](tau)
+    return n
+
+
+def cpu_baseline(cols_per_core=6):
+    """Oracle (NumPy/SciPy port of the reference, same LAPACK calls) on every host core, 1 BLAS thread
+    per process, same synthetic inputs; bounded sample.  Runs BEFORE the GPU is initialised (fork)."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    ctx = mp.get_context("fork")
+    jobs = [(10_000 + k * cols_per_core, cols_per_core) for k in range(cores)]
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_worker, [(0, 1)] * cores)  # warm imports
+        t0 = time.perf_counter()
+        done = sum(pool.map(_cpu_worker, jobs))
+        dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="column-solves/sec", cores=cores, kind="port",
+                sample=f"{done} cfg4 columns (L=20, NQuad=32, 32 Fourier modes, u at 21 tau x 3 phi + fluxes), "
+                       f"{cores} processes x 1 BLAS thread, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--columns", type=int, default=2048, help="columns per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    from pydisort_amd import synthetic
+    from pydisort_amd._engine import Plan
+    from pydisort_amd._prepare import prepare_columns
+
+    C = a.columns
+    cfg = synthetic.cfg4_columns(C, first=rank * C)
+    N = NQUAD // 2
+    prep = prepare_columns(cfg["tau_arr"], cfg["omega_arr"], NQUAD, cfg["Leg_coeffs_all"], cfg["mu0"], cfg["I0"],
+                           cfg["phi0"], NQUAD, NQUAD, np.zeros((C, N, NQUAD)), np.zeros((C, N, NQUAD)),
+                           cfg["f_arr"], np.zeros((C, L, 0)), np.zeros((C, 0, N, N)), np.zeros((C, 0, N)))
+    plan = Plan(prep, device=local)  # uploads: inputs now resident in HBM
+    tau = np.concatenate((np.zeros((C, 1)), cfg["tau_arr"]), axis=1)
+    plan.set_eval_points(tau, np.array([0.0, np.pi / 2, np.pi]))
+
+    dist = None
+    gather = None
+    collective = "none (single rank)"
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")  # control plane: barriers and the max-over-ranks of the time
+        collective = "none (nccl unavailable)"
+        try:  # data plane: one RCCL all-gather of the flux results per step
+            torch.cuda.set_device(local)
+            pg = dist.new_group(backend="nccl")
+            (_, _), (fptr, fbytes) = plan.result_dev_ptrs()
+            n = fbytes // 8
+            mine = torch.empty(n, dtype=torch.float64, device=f"cuda:{local}")
+            allf = torch.empty(n * world, dtype=torch.float64, device=f"cuda:{local}")
+            cudart = torch.cuda.cudart()
+
+            def gather():
+                plan.synchronize()
+                cudart.cudaMemcpy(mine.data_ptr(), fptr, fbytes, 3)  # device-to-device
+                dist.all_gather_into_tensor(allf, mine, group=pg)
+                torch.cuda.synchronize()
+            gather()
+            collective = "rccl all_gather (fluxes)"
+        except Exception as e:  # keep the benchmark alive on a misconfigured node
+            gather = None
+            collective = f"none ({type(e).__name__})"
+
+    def barrier():
+        plan.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        plan.run()
+        if gather:
+            gather()
+    plan.enable_timing(True)
+    plan.timing(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        plan.run()
+        if gather:
+            gather()
+    plan.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    stage = plan.timing(reset=True)
+    sweeps = plan.max_sweeps()
+
+    if rank == 0:
+        fl = algorithmic_flops()
+        ms = {k: (v[0] / max(v[1], 1)) for k, v in stage.items()}
+        dom = max(("eig", "bc"), key=lambda k: ms[k])
+        achieved = fl[dom] * C / (ms[dom] * 1e-3) / 1e12
+        value = world * C * a.steps / elapsed
+        out = {
+            "metric": "column-solves/sec (32 streams, 20 layers)", "value": value, "unit": "column-solves/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cfg4: synthetic Henyey-Greenstein, 20 layers, 32 streams, 32 Fourier modes, "
+                                   "delta-M on, beam source, u at 21 interfaces x 3 azimuths + fluxes",
+                       "columns_per_gpu_per_step": C, "global_columns_per_step": world * C,
+                       "parallelism": f"column-sharded x{world}", "collective": collective,
+                       "max_jacobi_sweeps": sweeps},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "kernel": {"eig": "rtd_asm/jacobi/post_kernel<16> (eigen stage)",
+                                    "bc": "rtd_bc_kernel<16>"}[dom],
+                         "note": "FP64 path: peak is the MI355X FP64 vector=matrix peak; achieved = algorithmic "
+                                 "FLOPs of the stage (SURVEY 8(d)) x columns / HIP-event time of the stage",
+                         "stage_ms_per_step": ms,
+                         "whole_path_tflops": fl["total"] * C * a.steps / elapsed / 1e12},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

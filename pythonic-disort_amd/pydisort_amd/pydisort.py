@@ -242,7 +242,9 @@ class _Closures:
     def flux_down(self, tau, is_antiderivative_wrt_tau=False, return_tau_arr=False):
         tau = self._tau(tau)
         r = self.plan.evaluate(tau[None], None, is_antiderivative_wrt_tau, want=("flux",))
-        outs = (np.squeeze(r["flux_down_diffuse"][0])[()], np.squeeze(r["flux_down_direct"][0])[()])
+        # without a beam source the reference's direct flux is the scalar 0 (_assemble.py:568-570, :610)
+        direct = np.squeeze(r["flux_down_direct"][0])[()] if self.beam else np.float64(0.0)
+        outs = (np.squeeze(r["flux_down_diffuse"][0])[()], direct)
         return outs + (self.tau_arr,) if return_tau_arr else outs
 
     def make_corrected_u(self, corr):

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Golden vectors for BASELINE.json's synthetic configs, computed by the REFERENCE (this container only).
+
+For the first few columns of each synthetic config (pydisort_amd.synthetic) the reference
+PythonicDISORT is called one column at a time and u, u0, flux_up, flux_down are stored at every layer
+interface, mid-layer points and phi in {0, pi/2, pi, 2.5}.  Inputs are regenerated deterministically by
+pydisort_amd.synthetic, so only outputs (and the evaluation points) are stored.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_synthetic_goldens.py
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = ["/root/reference/src", os.path.join(ROOT, "pythonic-disort_amd")]
+import PythonicDISORT  # noqa: E402
+from pydisort_amd import synthetic  # noqa: E402
+
+PHI = np.array([0.0, np.pi / 2, np.pi, 2.5])
+
+
+def lambertian_like(q, q0):
+    """BDRF callables reproducing tabulated modes on the quadrature grid (tables come from synthetic.py)."""
+    def mk(m):
+        def f(mu, neg_mup):
+            return q0[m][:, None] if len(np.atleast_1d(neg_mup)) == 1 else q[m]
+        return f
+    return [mk(m) for m in range(q.shape[0])]
+
+
+def run(name, cfg, ncol):
+    out = {}
+    for i in range(ncol):
+        kw = synthetic.column_kwargs(cfg, i)
+        if "bdrf_q" in cfg:
+            kw["BDRF_Fourier_modes"] = lambertian_like(cfg["bdrf_q"][i], cfg["bdrf_q0"][i])
+        tau_arr = kw["tau_arr"]
+        mids = 0.5 * (np.concatenate(([0.0], tau_arr[:-1])) + tau_arr)
+        tau_pts = np.sort(np.concatenate(([0.0], tau_arr, mids)))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mu_arr, Fp, Fm, u0, u = PythonicDISORT.pydisort(**kw)
+        out[f"c{i}.tau_pts"] = tau_pts
+        out[f"c{i}.u"] = u(tau_pts, PHI)
+        out[f"c{i}.u0"] = u0(tau_pts)
+        out[f"c{i}.flux_up"] = Fp(tau_pts)
+        fd = Fm(tau_pts)
+        out[f"c{i}.flux_down_diffuse"], out[f"c{i}.flux_down_direct"] = fd
+        print(name, i, "done", flush=True)
+    out["phi"] = PHI
+    out["ncol"] = np.array(ncol)
+    os.makedirs(os.path.join(HERE, "synth"), exist_ok=True)
+    np.savez_compressed(os.path.join(HERE, "synth", name + ".npz"), **out)
+
+
+if __name__ == "__main__":
+    run("cfg4", synthetic.cfg4_columns(16), 16)
+    run("cfg3_big", synthetic.cfg3_columns(4, big=True), 4)
+    run("cfg3_small", synthetic.cfg3_columns(4, big=False), 4)
+    run("cfg5", synthetic.cfg5_columns(2), 2)

@@ -1,0 +1,128 @@
+"""CPU-only tests: host glue of the drop-in (validation, preparation), the C-ABI library's exported
+symbols, synthetic generators, and that nothing in the product imports the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import goldens
+from oracle import disort_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "pythonic-disort_amd", "pydisort_amd")
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rtd.h")).read()
+    declared = set(re.findall(r"\b(rtd_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    from pydisort_amd import _lib
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().rtd_version() >= 100
+
+
+def test_product_never_imports_oracle_or_reference():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pythonic-disort_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+                assert "PythonicDISORT" not in src or "import PythonicDISORT" not in src, f
+                assert "/root/reference" not in src, f
+
+
+def _kw(tid="9c"):
+    return goldens.load(tid)[0]["kwargs"]
+
+
+@pytest.mark.parametrize("tid", ["1a", "3a", "5b", "7c", "8ARTS_B", "9c", "11a", "Ic"])
+def test_prepare_matches_oracle_prepare(tid):
+    """Host preparation (delta-M scaling, source rescale) against the oracle's restatement."""
+    from pydisort_amd._prepare import prepare_columns
+    for call in goldens.load(tid):
+        kw = call["kwargs"]
+        p = O.prepare(**kw)
+        L, N, M = p["L"], p["N"], p["M"]
+        Leg = np.atleast_2d(kw["Leg_coeffs_all"]).astype(float)
+        Leg[:, 0] = 1.0
+        s = np.atleast_2d(kw["s_poly_coeffs"])
+        s = s[:, :p["Ns"]] if p["Ns"] else np.zeros((L, 0))
+        f = np.broadcast_to(np.atleast_1d(kw["f_arr"]), (L,))
+        bq = np.stack([t[0] for t in p["bdrf"]]) if p["bdrf"] else np.zeros((0, N, N))
+        bq0 = np.stack([t[1] for t in p["bdrf"]]) if p["bdrf"] else np.zeros((0, N))
+
+        def bc(b):
+            out = np.zeros((N, M))
+            b = np.asarray(b, float)
+            if b.size == 1:
+                out[:, 0] = b.reshape(-1)[0]
+            elif b.ndim == 1:
+                out[:, 0] = b
+            else:
+                out[:] = b
+            return out
+        q = prepare_columns(np.atleast_1d(kw["tau_arr"])[None], np.atleast_1d(kw["omega_arr"])[None], kw["NQuad"],
+                            Leg[None], [kw["mu0"]], [kw["I0"]], [kw["phi0"]], p["P"], M, bc(kw["b_pos"])[None],
+                            bc(kw["b_neg"])[None], f[None], s[None], bq[None], bq0[None])
+        for a, b in [("omega_s", "omega_s"), ("tau_s0", "tau_s0"), ("scale_tau", "scale_tau"), ("wleg", "wleg")]:
+            assert np.allclose(q[a][0], p[b], rtol=1e-14, atol=1e-15), a
+        assert np.isclose(q["rescale"][0], p["rescale"], rtol=1e-14)
+        assert np.isclose(q["I0"][0], p["I0"], rtol=1e-14)
+        assert np.allclose(q["b_pos"][0].T, p["b_pos"], rtol=1e-14) and np.allclose(q["b_neg"][0].T, p["b_neg"], rtol=1e-14)
+        if p["Ns"]:
+            assert np.allclose(q["s_s"][0], p["s_s"], rtol=1e-13, atol=1e-15)
+
+
+BAD = [
+    (dict(tau_arr=-1.0), "tau values cannot be non-positive"),
+    (dict(tau_arr=np.array([1.0, 0.5]), omega_arr=np.array([0.5, 0.5]), Leg_coeffs_all=np.ones((2, 9)) * 0.5), "thicknesses"),
+    (dict(omega_arr=1.0), "Single-scattering albedo"),
+    (dict(NLeg=100), "`NLeg` cannot be larger"),
+    (dict(NQuad=7), "even"),
+    (dict(NFourier=0), "Fourier modes to use in the solution must be positive"),
+    (dict(NFourier=9), "less than or equal to the number of phase function"),
+    (dict(I0=-1.0), "cannot be negative"),
+    (dict(mu0=1.5), "cosine of the polar angle"),
+    (dict(phi0=7.0), "principal azimuthal angle"),
+    (dict(b_pos=np.ones(3)), "bottom boundary condition"),
+    (dict(b_neg=np.ones((2, 2))), "top boundary condition"),
+    (dict(f_arr=1.5), "fractional scattering"),
+    (dict(use_banded_solver_NLayers=2), "minimum threshold"),
+]
+
+
+@pytest.mark.parametrize("override,msg", BAD)
+def test_input_checks_raise_like_the_reference(override, msg):
+    """Same hard-error conditions as pydisort.py:222-291 (checked before any device work)."""
+    import pydisort_amd
+    kw = dict(tau_arr=1.0, omega_arr=0.5, NQuad=8, Leg_coeffs_all=np.array([1.0, 0.5, 0.2, 0.1, 0.05, 0.02, 0.01, 0.005, 0.001]),
+              mu0=0.5, I0=1.0, phi0=0.0)
+    kw.update(override)
+    with pytest.raises(ValueError, match=re.escape(msg)):
+        pydisort_amd.pydisort(**kw)
+
+
+def test_synthetic_columns_are_deterministic_and_independent_of_batch():
+    from pydisort_amd import synthetic
+    a = synthetic.cfg4_columns(8)
+    b = synthetic.cfg4_columns(3, first=5)
+    for k in ("tau_arr", "omega_arr", "Leg_coeffs_all", "mu0", "f_arr"):
+        assert np.array_equal(a[k][5:8], b[k])
+    c5 = synthetic.cfg5_columns(2)
+    assert c5["bdrf_q"].shape == (2, 2, 32, 32) and c5["Leg_coeffs_all"].shape == (2, 50, 65)
+
+
+def test_oracle_on_synthetic_config_is_self_consistent():
+    """cfg4 column through the oracle: banded (L >= 10) and dense BC solvers agree."""
+    from pydisort_amd import synthetic
+    cfg = synthetic.cfg4_columns(1, L=12, NQuad=8)
+    kw = synthetic.column_kwargs(cfg, 0)
+    a = O.pydisort(**kw)
+    b = O.pydisort(use_banded_solver_NLayers=100, **kw)
+    tau = np.linspace(0, kw["tau_arr"][-1], 7)
+    assert np.allclose(a[4](tau, 0.3), b[4](tau, 0.3), rtol=1e-10)
