@@ -34,6 +34,19 @@ def algorithmic_flops():
     return dict(eig=eig, bc=bc, eval=ev, total=eig + bc)
 
 
+def shard_columns(rank, world, columns_per_gpu):
+    """Weak-scaling column shard of a rank: global column indices [first, first + count)."""
+    return rank * columns_per_gpu, columns_per_gpu
+
+
+def reduce_max_seconds(dist, seconds):
+    """Max over ranks of a host-side duration through the (gloo) control plane."""
+    import torch
+    t = torch.tensor([seconds], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
 def _cpu_worker(args):
     first, n = args
     from threadpoolctl import threadpool_limits
@@ -73,6 +86,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--columns", type=int, default=2048, help="columns per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="exercise the multi-rank code path even with one rank")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,12 +101,14 @@ def main():
     from pydisort_amd._engine import Plan
     from pydisort_amd._prepare import prepare_columns
 
-    C = a.columns
-    cfg = synthetic.cfg4_columns(C, first=rank * C)
+    first, C = shard_columns(rank, world, a.columns)
+    cfg = synthetic.cfg4_columns(C, first=first)
     N = NQUAD // 2
     prep = prepare_columns(cfg["tau_arr"], cfg["omega_arr"], NQUAD, cfg["Leg_coeffs_all"], cfg["mu0"], cfg["I0"],
                            cfg["phi0"], NQUAD, NQUAD, np.zeros((C, N, NQUAD)), np.zeros((C, N, NQUAD)),
                            cfg["f_arr"], np.zeros((C, L, 0)), np.zeros((C, 0, N, N)), np.zeros((C, 0, N)))
+    if world > 1 or a.force_dist:
+        Plan.comm_preload()  # bind RCCL to librtd's HIP runtime before torch (gloo control plane) is imported
     plan = Plan(prep, device=local)  # uploads: inputs now resident in HBM
     tau = np.concatenate((np.zeros((C, 1)), cfg["tau_arr"]), axis=1)
     plan.set_eval_points(tau, np.array([0.0, np.pi / 2, np.pi]))
@@ -100,30 +116,34 @@ def main():
     dist = None
     gather = None
     collective = "none (single rank)"
-    if world > 1:
-        import torch
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         dist.init_process_group("gloo")  # control plane: barriers and the max-over-ranks of the time
         collective = "none (nccl unavailable)"
-        try:  # data plane: one RCCL all-gather of the flux results per step
-            torch.cuda.set_device(local)
-            pg = dist.new_group(backend="nccl")
-            (_, _), (fptr, fbytes) = plan.result_dev_ptrs()
-            n = fbytes // 8
-            mine = torch.empty(n, dtype=torch.float64, device=f"cuda:{local}")
-            allf = torch.empty(n * world, dtype=torch.float64, device=f"cuda:{local}")
-            cudart = torch.cuda.cudart()
-
-            def gather():
+        # data plane: one RCCL all-gather of the flux results per step (ncclAllGather inside librtd)
+        uid = [None]
+        if rank == 0:
+            try:
+                uid = [Plan.comm_unique_id()]
+            except Exception as e:
+                print(f"[bench] RCCL unavailable: {e!r}", file=sys.stderr)
+        dist.broadcast_object_list(uid, src=0)
+        ok = 0
+        if uid[0] is not None:
+            try:
+                plan.comm_init(uid[0], rank, world)
+                plan.run()
+                plan.allgather_fluxes()
                 plan.synchronize()
-                cudart.cudaMemcpy(mine.data_ptr(), fptr, fbytes, 3)  # device-to-device
-                dist.all_gather_into_tensor(allf, mine, group=pg)
-                torch.cuda.synchronize()
-            gather()
+                ok = 1
+            except Exception as e:  # keep the benchmark alive on a misconfigured node
+                print(f"[bench] rank {rank}: RCCL data plane unavailable: {e!r}", file=sys.stderr)
+        import torch
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:
+            gather = plan.allgather_fluxes
             collective = "rccl all_gather (fluxes)"
-        except Exception as e:  # keep the benchmark alive on a misconfigured node
-            gather = None
-            collective = f"none ({type(e).__name__})"
 
     def barrier():
         plan.synchronize()
@@ -146,10 +166,7 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+        elapsed = reduce_max_seconds(dist, elapsed)
     stage = plan.timing(reset=True)
     sweeps = plan.max_sweeps()
 

@@ -119,6 +119,19 @@ int rtd_plan_get_timing(rtd_plan* plan, double ms[4], int64_t nlaunch[4], int32_
 /* maximum Jacobi sweeps used by any eigenproblem of the last solve (diagnostic) */
 int rtd_plan_max_sweeps(rtd_plan* plan, int32_t* sweeps);
 
+/* --- multi-GPU: RCCL over xGMI, one communicator rank per plan (one process per GPU) -------- */
+/* The path shards by atmospheric column with no exchange during the solve; the one
+ * collective stitches the evaluated flux results [3][C][ntau] of every rank: ncclAllGather on the plan's
+ * stream.  rank 0 creates the id (ncclGetUniqueId) and hands the 128 bytes to the other ranks by any
+ * host channel. */
+/* Load RCCL now (call before anything else in the process loads another RCCL/HIP runtime, e.g. PyTorch). */
+int rtd_comm_preload(void);
+int rtd_comm_unique_id(char id[128]);
+int rtd_comm_init(rtd_plan* plan, const char id[128], int32_t rank, int32_t nranks);
+int rtd_comm_allgather_fluxes(rtd_plan* plan);               /* asynchronous on the plan's stream */
+int rtd_comm_fetch_gathered(rtd_plan* plan, double* out);    /* host [nranks][3][C][ntau] */
+int rtd_comm_destroy(rtd_plan* plan);
+
 enum {
   RTD_OK = 0,
   RTD_ERR_ARG = 1,        /* bad argument / unsupported size */

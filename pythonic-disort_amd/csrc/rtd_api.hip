@@ -1,5 +1,7 @@
 // rtd_api.hip -- host side of the C ABI declared in include/rtd.h (plan life cycle, uploads, launches).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdio>
@@ -50,6 +52,11 @@ struct rtd_plan {
   int64_t cap_tau = 0, cap_phi = 0, cap_u = 0, cap_u0 = 0, cap_fl = 0;
   // export buffers
   double* ex_buf = nullptr;
+  // RCCL communicator (one rank per GPU), gathered flux results [nranks][3][C][ntau]
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_size = 0;
+  double* gathered = nullptr;
+  int64_t cap_gathered = 0;
   // timing
   bool timing = false;
   hipEvent_t evt[6] = {};
@@ -134,6 +141,8 @@ int launch_solve(rtd_plan* p, bool with_eval, const RtdEval* ev) {
 
 extern "C" {
 
+int rtd_comm_destroy(rtd_plan* p);
+
 int rtd_version(void) { return 100; }
 
 const char* rtd_last_error(void) { return g_err.c_str(); }
@@ -200,6 +209,7 @@ int rtd_plan_destroy(rtd_plan* p) {
   if (!p) return 0;
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
+  rtd_comm_destroy(p);
   for (void* a : p->allocs)
     if (a) (void)hipFree(a);
   for (auto& e : p->evt)
@@ -459,6 +469,102 @@ int rtd_plan_max_sweeps(rtd_plan* p, int32_t* sweeps) {
   int v = 0;
   HIP_TRY(hipMemcpy(&v, p->d.sweeps, sizeof(int), hipMemcpyDeviceToHost));
   *sweeps = v;
+  return 0;
+}
+
+/* ---- RCCL over xGMI: one communicator rank per plan/GPU ------------------ */
+namespace {
+struct RcclApi {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi* rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    // The ROCm install's RCCL first, by absolute path: a process that also imports PyTorch carries a second,
+    // bundled RCCL/HIP pair under the same SONAMEs, and RCCL must bind to the HIP runtime librtd itself uses.
+    for (const char* name : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) {
+      api.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (api.h) break;
+    }
+    if (api.h) {
+      api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
+      api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");
+      api.AllGather = (decltype(api.AllGather))dlsym(api.h, "ncclAllGather");
+      api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
+      if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) api.h = nullptr;
+    }
+  }
+  return api.h ? &api : nullptr;
+}
+}  // namespace
+
+int rtd_comm_preload(void) {
+  return rccl() ? 0 : fail(RTD_ERR_HIP, "librccl.so could not be loaded");
+}
+
+int rtd_comm_unique_id(char id[128]) {
+  RcclApi* r = rccl();
+  if (!r) return fail(RTD_ERR_HIP, "librccl.so could not be loaded");
+  ncclUniqueId u;
+  ncclResult_t rc = r->GetUniqueId(&u);
+  if (rc != ncclSuccess) return fail(RTD_ERR_HIP, std::string("ncclGetUniqueId: ") + r->GetErrorString(rc));
+  std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+  return 0;
+}
+
+int rtd_comm_init(rtd_plan* p, const char id[128], int32_t rank, int32_t nranks) {
+  if (!p || !id || rank < 0 || rank >= nranks) return fail(RTD_ERR_ARG, "bad communicator arguments");
+  RcclApi* r = rccl();
+  if (!r) return fail(RTD_ERR_HIP, "librccl.so could not be loaded");
+  HIP_TRY(hipSetDevice(p->device));
+  ncclUniqueId u;
+  std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+  ncclResult_t rc = r->CommInitRank(&p->comm, nranks, u, rank);
+  if (rc != ncclSuccess) {
+    p->comm = nullptr;
+    return fail(RTD_ERR_HIP, std::string("ncclCommInitRank: ") + r->GetErrorString(rc));
+  }
+  p->comm_rank = rank;
+  p->comm_size = nranks;
+  return 0;
+}
+
+int rtd_comm_allgather_fluxes(rtd_plan* p) {
+  if (!p || !p->comm) return fail(RTD_ERR_STATE, "communicator not initialised");
+  if (p->ev_ntau < 1) return fail(RTD_ERR_STATE, "no evaluation results to gather");
+  HIP_TRY(hipSetDevice(p->device));
+  const int64_t n = 3 * (int64_t)p->d.C * p->ev_ntau;
+  int rc = grow(p, &p->gathered, &p->cap_gathered, n * p->comm_size);
+  if (rc) return rc;
+  ncclResult_t nr = rccl()->AllGather(p->ev_fl, p->gathered, (size_t)n, ncclDouble, p->comm, p->stream);
+  if (nr != ncclSuccess) return fail(RTD_ERR_HIP, std::string("ncclAllGather: ") + rccl()->GetErrorString(nr));
+  return 0;
+}
+
+int rtd_comm_fetch_gathered(rtd_plan* p, double* out) {
+  if (!p || !out || !p->gathered) return fail(RTD_ERR_STATE, "nothing gathered");
+  HIP_TRY(hipSetDevice(p->device));
+  const int64_t n = 3 * (int64_t)p->d.C * p->ev_ntau * p->comm_size;
+  HIP_TRY(hipMemcpyAsync(out, p->gathered, (size_t)n * 8, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+int rtd_comm_destroy(rtd_plan* p) {
+  if (!p) return 0;
+  if (p->comm && rccl()) {
+    (void)hipStreamSynchronize(p->stream);
+    rccl()->CommDestroy(p->comm);
+  }
+  p->comm = nullptr;
   return 0;
 }
 

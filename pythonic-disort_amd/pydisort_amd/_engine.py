@@ -110,6 +110,29 @@ class Plan:
                                                   _lib.dptr(Z), _lib.dptr(G)))
         return dict(GC=GC, K=K, B=B, G_inv_mu_inv=Z, G=G)
 
+    # ---- RCCL over xGMI (one rank per plan) ----
+    @staticmethod
+    def comm_preload():
+        _lib.check(_lib.load().rtd_comm_preload())
+
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().rtd_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, uid, rank, nranks):
+        _lib.check(self._lib.rtd_comm_init(self._h, uid, rank, nranks))
+        self._nranks = nranks
+
+    def allgather_fluxes(self):
+        _lib.check(self._lib.rtd_comm_allgather_fluxes(self._h))
+
+    def fetch_gathered(self):
+        out = np.empty((self._nranks, 3, self.C, self._ev_shape[0]))
+        _lib.check(self._lib.rtd_comm_fetch_gathered(self._h, _lib.dptr(out)))
+        return out
+
     def enable_timing(self, on=True):
         _lib.check(self._lib.rtd_plan_enable_timing(self._h, int(on)))
 

@@ -195,3 +195,23 @@ def test_tau_out_of_range_raises(amd):
         res[1](np.array([0.0, 99.0]))
     with pytest.raises(ValueError):
         res[4](-0.1, 0.0)
+
+
+def test_rccl_allgather_single_rank(amd):
+    """The one collective of the path (ncclAllGather of the flux results) with a 1-rank communicator."""
+    from pydisort_amd import synthetic
+    from pydisort_amd._engine import Plan
+    Plan.comm_preload()
+    cfg = synthetic.cfg4_columns(8, L=5, NQuad=8)
+    _, sol = amd.pydisort_batch(**cfg)
+    plan = sol.plan
+    tau = np.concatenate((np.zeros((8, 1)), cfg["tau_arr"]), axis=1)
+    plan.set_eval_points(tau, np.array([0.0, 1.0]))
+    plan.run()
+    plan.comm_init(Plan.comm_unique_id(), 0, 1)
+    plan.allgather_fluxes()
+    got = plan.fetch_gathered()
+    res = plan.fetch()
+    assert got.shape == (1, 3, 8, 6)
+    assert np.array_equal(got[0, 0], res["flux_up"]) and np.array_equal(got[0, 1], res["flux_down_diffuse"])
+    assert np.array_equal(got[0, 2], res["flux_down_direct"])
