@@ -189,7 +189,7 @@ int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** out) {
   A(d.Gp, C * M * L * NP * NP) A(d.Gm, C * M * L * NP * NP) A(d.kk, C * M * L * NP) A(d.Bv, C * M * L * Q2)
   A(d.dq, C * L * Ns * Q2) A(d.zneg, C * L * NP) A(d.coef, C * M * L * Q2)
   A(d.Lw, C * M * L * NP * NP) A(d.Qw, C * M * L * NP * NP)
-  A(d.Fws, C * M * (L - 1) * Q2 * Q2) A(d.yws, C * M * (L - 1) * Q2)
+  A(d.Fws, C * M * (L - 1) * Q2 * Q2) A(d.Ek, C * M * L * NP)
   A(d.sweeps, 1) A(d.status, 1)
 #undef A
   d.mu = mu; d.w = w; d.invmu = invmu; d.S = S; d.T = T;

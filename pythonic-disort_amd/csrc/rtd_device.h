@@ -30,8 +30,10 @@ struct RtdDev {
   const double *bdrfq, *bdrfq0;  // [C][NBDRF][NP][NP], [C][NBDRF][NP]
   // intermediates
   double *Gp, *Gm, *kk, *Bv, *dq, *zneg, *coef;
-  double *Lw, *Qw;    // eigen-stage workspace [C][M][L][NP][NP]: Cholesky factor L, symmetrised Qm
-  double *Fws, *yws;  // BC workspace: [C][M][L-1][Q2][Q2] (column-major per block), [C][M][L-1][Q2]
+  double *Lw, *Qw;    // eigen-stage workspace [C][M][L][NP][NP]: Cholesky factor L, symmetrised Qm;
+                      // after the post kernel: V^-1 and U^-1 (transposed) of G = [[V+U, V-U],[V-U, V+U]]
+  double* Ek;         // [C][M][L][NP]  exp(-k dtau*_l): the Stamnes-Conklin scaling factors
+  double* Fws;  // BC workspace: [C][M][L-1][4 NP^2]: Wp, Wq, S, rho_t, rho_b, s per interface (rtd_bc.hip)
   int* sweeps;        // [1] max Jacobi sweeps (diagnostic)
   int* status;        // [1] device-side status flags (bit 0: tau out of range)
 };

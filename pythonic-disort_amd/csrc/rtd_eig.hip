@@ -277,6 +277,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
   constexpr int LD = NP + 1;
   __shared__ double sL[GPW][NP * LD];
   __shared__ double sQ[GPW][NP * LD];
+  __shared__ double sR[GPW][NP * LD];  // scratch for cross-lane reductions (Qm must survive until the beam stage)
   __shared__ double sV[GPW][3][NP];
   const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
   const ProbId id = locate<NP>(d);
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
   const bool valid = id.valid;
   double* L_ = sL[grp];
   double* Q_ = sQ[grp];
+  double* R_ = sR[grp];
   double* v0 = sV[grp][0];
   double* v1 = sV[grp][1];
   double* v2 = sV[grp][2];
@@ -323,10 +325,17 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
       double a = 0.0;
 #pragma unroll
       for (int r = 0; r <= i; ++r) a += L_[i * LD + r] * zc[r];
-      const double rT = 1.0 / d.T[i];
+      const double Ti = d.T[i];
+      const double rT = 1.0 / Ti;
       const double vt = y[i] * rT, ut = -a * rk * rT;
       gp[i] = vt + ut;
       gm[i] = vt - ut;
+      // closed-form inverses for the boundary-condition stage (rtd_bc.hip): with V = T^-1 L^-T Z and
+      // U = -T^-1 L Z / k:  V^-1[j][i] = T_i (L z_j)_i,  U^-1[j][i] = -k_j T_i (L^-T z_j)_i; stored transposed
+      if (valid) {
+        d.Lw[base * NP * NP + i * NP + j] = Ti * a;
+        d.Qw[base * NP * NP + i * NP + j] = -kj * Ti * y[i];
+      }
       RTD_FENCE();
     }
   }
@@ -339,6 +348,8 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
       Gm[i * NP + j] = gm[i];
     }
     d.kk[base * NP + j] = kj;
+    const double* ts0 = d.taus0 + (long)c * (d.L + 1);
+    d.Ek[base * NP + j] = exp(-kj * (ts0[l + 1] - ts0[l]));
   }
 
   // isotropic (thermal) source, Fourier mode 0 only (subroutines.py:746-862, _assemble.py:124).
@@ -376,18 +387,18 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
       // up-streams: Gp a + Gm b ; down-streams: Gm a + Gp b  (sum over eigen-index = lanes)
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < NP; ++i) Q_[i * LD + j] = gp[i] * a + gm[i] * b;
+      for (int i = 0; i < NP; ++i) R_[i * LD + j] = gp[i] * a + gm[i] * b;
       __syncthreads();
       double up = 0.0;
 #pragma unroll
-      for (int r = 0; r < NP; ++r) up += Q_[j * LD + r];
+      for (int r = 0; r < NP; ++r) up += R_[j * LD + r];
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < NP; ++i) Q_[i * LD + j] = gm[i] * a + gp[i] * b;
+      for (int i = 0; i < NP; ++i) R_[i * LD + j] = gm[i] * a + gp[i] * b;
       __syncthreads();
       double dn = 0.0;
 #pragma unroll
-      for (int r = 0; r < NP; ++r) dn += Q_[j * LD + r];
+      for (int r = 0; r < NP; ++r) dn += R_[j * LD + r];
       if (valid && act) {
         double* dq = d.dq + (((long)c * d.L + l) * d.Ns + q) * 2 * NP;
         dq[j] = up;
@@ -395,13 +406,6 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
       }
     }
     __syncthreads();
-    // Qm is needed again by the beam stage
-    if (d.beam) {
-      const double* Qw = d.Qw + base * NP * NP;
-#pragma unroll
-      for (int i = 0; i < NP; ++i) Q_[i * LD + j] = Qw[i * NP + j];
-      __syncthreads();
-    }
   }
 
   // beam particular solution (:143-152, :226-231) through the spectral decomposition:
@@ -442,13 +446,13 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
 #pragma unroll
     for (int i = 0; i < NP; ++i) h += zc[i] * v2[i];
     h /= (1.0 / (mu0 * mu0) - k2);
-    // e = Z h (cross-lane sum through LDS; Qm is no longer needed)
+    // e = Z h (cross-lane sum through LDS)
 #pragma unroll
-    for (int i = 0; i < NP; ++i) Q_[i * LD + j] = zc[i] * h;
+    for (int i = 0; i < NP; ++i) R_[i * LD + j] = zc[i] * h;
     __syncthreads();
     double e = 0.0;
 #pragma unroll
-    for (int r = 0; r < NP; ++r) e += Q_[j * LD + r];
+    for (int r = 0; r < NP; ++r) e += R_[j * LD + r];
     // shat = L^-T e by back substitution distributed over the lanes
     double sh = 0.0;
 #pragma unroll

@@ -245,3 +245,88 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ------------------------------------------------------------------------------------------------
+# Structured block elimination of the BC system (candidate replacement of bc_stage):
+# multiply the continuity rows of interface l by G_l^-1 (known in closed form from the eigen stage)
+# so that the x_l block becomes diag(E_l, 1); eliminate C+_l with those rows and C-_l with the carry.
+# ------------------------------------------------------------------------------------------------
+def bc_stage_structured(p, Gp, Gm, kk, Bp, Bm, dq):
+    L, N, M = p["L"], p["N"], p["M"]
+    Q = 2 * N
+    mu, W, mu0, ts0 = p["mu"], p["W"], p["mu0"], p["tau_s0"]
+    Cc = np.zeros((M, L, Q))
+    vpoly = lambda l, t: sum(dq[l, q] * t**q for q in range(p["Ns"])) if p["iso"] else np.zeros(Q)
+    for m in range(M):
+        E = np.exp(-kk[m] * np.diff(ts0)[:, None])
+        Bfull = np.concatenate((Bp[m], Bm[m]), axis=1)
+        Vi = [np.linalg.inv(0.5 * (Gp[m, l] + Gm[m, l])) for l in range(L)]  # device: Z^T L^T T (closed form)
+        Ui = [np.linalg.inv(0.5 * (Gp[m, l] - Gm[m, l])) for l in range(L)]
+        Ta, Tb = Gm[m, 0].copy(), Gp[m, 0] * E[0]
+        t = p["b_neg"][:, m] - Bfull[0, N:] - (vpoly(0, 0.0)[N:] if m == 0 else 0)
+        keep = []
+        for l in range(L - 1):
+            tb = ts0[l + 1]
+            r = (Bfull[l + 1] - Bfull[l]) * (np.exp(-tb / mu0) if p["beam"] else 0.0)
+            if m == 0:
+                r = r + vpoly(l + 1, tb) - vpoly(l, tb)
+            # G_l^-1 = 1/4 [[Vi+Ui, Vi-Ui],[Vi-Ui, Vi+Ui]] with V = (Gp+Gm)/2, U = (Gp-Gm)/2
+            rs, rd = r[:N] + r[N:], r[:N] - r[N:]
+            rho_t = 0.25 * (Vi[l] @ rs + Ui[l] @ rd)
+            rho_b = 0.25 * (Vi[l] @ rs - Ui[l] @ rd)
+            VV = Vi[l] @ (0.5 * (Gp[m, l + 1] + Gm[m, l + 1]))
+            UU = Ui[l] @ (0.5 * (Gp[m, l + 1] - Gm[m, l + 1]))
+            Wp, Wq = 0.5 * (VV + UU), 0.5 * (VV - UU)
+            sol = np.linalg.solve(Ta, np.concatenate((Tb, t[:, None]), axis=1))
+            S, s = sol[:, :N], sol[:, N]
+            keep.append((S, s, Wp, Wq, rho_b))
+            ES = E[l][:, None] * S
+            Ta_n = -(ES @ Wq + Wp)
+            Tb_n = -(ES @ Wp + Wq) * E[l + 1][None, :]
+            t = rho_t - E[l] * (s - S @ rho_b)
+            Ta, Tb = Ta_n, Tb_n
+        l = L - 1
+        att = np.exp(-ts0[-1] / mu0) if p["beam"] else 0.0
+        vb = vpoly(l, ts0[-1]) if m == 0 else np.zeros(Q)
+        if len(p["bdrf"]) > m:
+            R = (1 + (m == 0)) * p["bdrf"][m][0] * (mu * W)[None, :]
+            Ba, Bb = (Gp[m, l] - R @ Gm[m, l]) * E[l], Gm[m, l] - R @ Gp[m, l]
+            br = p["b_pos"][:, m] + (mu0 * p["I0_4pi"] * 4 * p["bdrf"][m][1] + R @ Bfull[l, N:] - Bfull[l, :N]) * att \
+                + R @ vb[N:] - vb[:N]
+        else:
+            Ba, Bb = Gp[m, l] * E[l], Gm[m, l]
+            br = p["b_pos"][:, m] - Bfull[l, :N] * att - vb[:N]
+        sol = np.linalg.solve(Ta, np.concatenate((Tb, t[:, None]), axis=1))
+        S, s = sol[:, :N], sol[:, N]
+        cp = np.linalg.solve(Bb - Ba @ S, br - Ba @ s)
+        cm_ = s - S @ cp
+        Cc[m, l] = np.concatenate((cm_, cp))
+        for l in range(L - 2, -1, -1):
+            S, s, Wp, Wq, rho_b = keep[l]
+            nxt_m, nxt_p = Cc[m, l + 1, :N], Cc[m, l + 1, N:] * E[l + 1]
+            cp = Wq @ nxt_m + Wp @ nxt_p + rho_b
+            Cc[m, l] = np.concatenate((s - S @ cp, cp))
+    return Cc
+
+
+def check_structured(ids=None):
+    import goldens
+    import warnings
+    warnings.simplefilter("ignore")
+    ids = ids or goldens.list_ids()
+    for tid in ids:
+        worst = 0.0
+        for call in goldens.load(tid)[:3]:
+            p = O.prepare(**call["kwargs"])
+            st = eig_stage(p, use_jacobi=False)
+            C1 = bc_stage(p, *st[:5], st[6])
+            C2 = bc_stage_structured(p, *st[:5], st[6])
+            tau = np.concatenate(([0.0], p["tau"], 0.37 * p["tau"][:1]))
+            phi = np.array([0.0, 1.0])
+            u1 = evaluate(p, *st[:5], st[6], C1, tau, phi)
+            u2 = evaluate(p, *st[:5], st[6], C2, tau, phi)
+            sc = np.max(np.abs(u1))
+            if sc > 0:
+                worst = max(worst, np.max(np.abs(u1 - u2)) / sc)
+        print(f"{tid:12s} structured vs pivoted-GJ: {worst:.2e}", flush=True)
