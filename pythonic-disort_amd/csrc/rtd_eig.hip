@@ -37,64 +37,59 @@ constexpr __host__ __device__ int high_bit(int t) {
   return b;
 }
 
-// One parallel Jacobi step: all pairs (j, j^T) are rotated at once.
-// hx[s] = H[j^s][j] (XOR-relative rows), zc[i] = Z[i][j].
+// 1/sqrt(x) and 1/x to full double precision from the hardware seeds (x > 0, normal range)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * (1.5 - hx * y * y);
+  y = y * (1.5 - hx * y * y);
+  return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  y = y * (2.0 - x * y);
+  return y;
+}
+
+// One parallel step of the one-sided (Hestenes) Jacobi iteration on the columns of W (H = W W^T at the
+// start): lane j holds column j, all pairs (j, j^T) are orthogonalised at once.  On convergence the columns
+// are k_j z_j (singular values x left singular vectors = sqrt(eigenvalues) x eigenvectors of H).
 template <int NP, int T>
 struct JacobiStep {
-  static __device__ __forceinline__ void run(double (&hx)[NP], double (&zc)[NP], const int j, double* cs,
-                                             double& offacc) {
-    const double app = hx[0];
-    const double aqq = xor_lane<T>(app);
+  static __device__ __forceinline__ void run(double (&w)[NP], const int j, int& notconv) {
+    double pw[NP];
+    double alpha = 0.0, gamma = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      pw[i] = xor_lane<T>(w[i]);
+      alpha += w[i] * w[i];
+      gamma += w[i] * pw[i];
+    }
+    const double beta = xor_lane<T>(alpha);
     const bool lo = (j & high_bit(T)) == 0;  // j < j^T
-    // both lanes of a pair use the lower lane's copy of H[p][q] so that (c, s) are bitwise identical
-    const double apq_own = hx[T];
-    const double apq_oth = xor_lane<T>(apq_own);
-    const double apq = lo ? apq_own : apq_oth;
     double c = 1.0, sg = 0.0;
-    if (apq != 0.0) {
-      const double alo = lo ? app : aqq, ahi = lo ? aqq : app;
-      const double zeta = (ahi - alo) / (2.0 * apq);
-      const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-      c = 1.0 / sqrt(1.0 + tt * tt);
+    if (gamma != 0.0) {
+      // tan(2 theta) = 2 gamma / (a_hi - a_lo);  t = tan(theta) without cancellation
+      const double delta = lo ? (beta - alpha) : (alpha - beta);
+      const double g2 = 2.0 * gamma;
+      const double r2 = delta * delta + g2 * g2;
+      const double rho = r2 * fast_rsqrt(r2);
+      const double den = delta + copysign(rho, delta);
+      const double tt = g2 * fast_rcp(den);
+      c = fast_rsqrt(1.0 + tt * tt);
       const double s = tt * c;
       sg = lo ? -s : s;
     }
-    offacc += apq * apq;
-    // opaque copy of the lane index: stops the compiler from hoisting the 8 x 15 LDS addresses of the
-    // (c, sg) look-ups out of the sweep loop (they would occupy > 100 VGPRs)
-    int jv = j;
-    asm volatile("" : "+v"(jv));
-    // publish (c, sg) of this lane's pair for the row rotations
-    cs[2 * j] = c;
-    cs[2 * j + 1] = sg;
-    __syncthreads();
-    // H <- J^T (H J), two registers at a time: column rotation W[:, j] = c H[:, j] + sg H[:, j^T],
-    // then the row rotation of rows (i, i^T), i = j^s, with that pair's parameters
+    notconv |= (gamma * gamma > 1e-26 * alpha * beta) ? 1 : 0;
 #pragma unroll
-    for (int s = 0; s < NP; ++s) {
-      if (s < (s ^ T)) {
-        const double wa = c * hx[s] + sg * xor_lane<T>(hx[s ^ T]);
-        const double wb = c * hx[s ^ T] + sg * xor_lane<T>(hx[s]);
-        const int i = jv ^ s;
-        const double ci = cs[2 * i], sgi = cs[2 * i + 1];
-        hx[s] = ci * wa + sgi * wb;
-        hx[s ^ T] = ci * wb - sgi * wa;
-        __builtin_amdgcn_sched_barrier(0);  // bound the live swizzle results (register pressure)
-      }
-    }
-    // eigenvector accumulation Z <- Z J
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      zc[i] = c * zc[i] + sg * xor_lane<T>(zc[i]);
-      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-    JacobiStep<NP, T + 1>::run(hx, zc, j, cs, offacc);
+    for (int i = 0; i < NP; ++i) w[i] = c * w[i] + sg * pw[i];
+    JacobiStep<NP, T + 1>::run(w, j, notconv);
   }
 };
 template <int NP>
 struct JacobiStep<NP, NP> {
-  static __device__ __forceinline__ void run(double (&)[NP], double (&)[NP], const int, double*, double&) {}
+  static __device__ __forceinline__ void run(double (&)[NP], const int, int&) {}
 };
 
 // sum over the NP lanes of a group (result in every lane)
@@ -106,6 +101,28 @@ __device__ __forceinline__ double group_sum(double v) {
   if (NP > 8) v += xor_lane<8>(v);
   if (NP > 16) v += xor_lane<16>(v);
   return v;
+}
+
+// In-register Cholesky of a symmetric positive definite matrix held one column per lane (col[i] = A[i][j]);
+// on exit col[i] = L[i][j] for i >= j and 0 above the diagonal.  The trailing matrix is kept symmetric so
+// that L[j][k] is available in the lane's own registers.
+template <int NP>
+__device__ __forceinline__ void cholesky_columns(double (&col)[NP], const int j) {
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const double akk = __shfl(col[k], k, NP);
+    const double rinv = 1.0 / sqrt(akk);
+    const double ljk = col[k] * rinv;  // L[j][k] by symmetry (meaningful for j > k)
+#pragma unroll
+    for (int i = k + 1; i < NP; ++i) {
+      const double lik = __shfl(col[i], k, NP) * rinv;
+      if (j > k) col[i] -= lik * ljk;
+      if (j == k) col[i] = lik;
+    }
+    if (j == k) col[k] = akk * rinv;
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) col[i] = (i >= j) ? col[i] : 0.0;
 }
 
 // problem index of this lane's group; invalid groups redo the last problem and skip their stores
@@ -129,21 +146,19 @@ __device__ __forceinline__ ProbId locate(const RtdDev& d) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stage 1: assemble Pm, Qm (symmetrised alpha+-beta), Cholesky Pm = L L^T, H = L^T Qm L.
+// Stage 1: assemble Pm, Qm (symmetrised alpha+-beta), Cholesky Pm = L L^T, Qm = R R^T, F = L^T R (H = F F^T).
 // Workspace written: Lw [prob][NP][NP] (row-major L), Qw [prob][NP][NP] (Qm),
-//                    Hx (aliases Gp) [prob][s][j] = H[j^s][j].
+//                    F (aliases Gp) [prob][i][j].
 // ------------------------------------------------------------------------------------------------
 template <int NP>
 __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_asm_kernel(RtdDev d) {
   constexpr int GPW = 64 / NP;
   constexpr int LD = NP + 1;
   __shared__ double sL[GPW][NP * LD];
-  __shared__ double sQ[GPW][NP * LD];
   const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
   const ProbId id = locate<NP>(d);
   const int P = d.P, m = id.m;
   double* L_ = sL[grp];
-  double* Q_ = sQ[grp];
   const double* wl = d.wleg + ((long)id.c * d.L + id.l) * P;
   const double om = d.omega[(long)id.c * d.L + id.l];
   const double* Ym = d.Y + (long)m * P * NP;
@@ -178,93 +193,67 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_asm_kernel(RtdDev 
     for (int i = 0; i < NP; ++i) acc_e[i] = acc_o[i] = 0.0;
   }
   const double invmu_j = d.invmu[j], S_j = d.S[j];
-  double pcol[NP];
+  double pcol[NP], qcol[NP];
   double* Qw = d.Qw + id.pid * NP * NP;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const double Si = d.S[i];
     pcol[i] = (i == j ? invmu_j : 0.0) - Si * acc_e[i] * S_j;  // Pm = M^-1 - S Ae S
-    const double qv = (i == j ? invmu_j : 0.0) - Si * acc_o[i] * S_j;  // Qm = M^-1 - S Ao S
-    Q_[i * LD + j] = qv;
-    if (id.valid) Qw[i * NP + j] = qv;
+    qcol[i] = (i == j ? invmu_j : 0.0) - Si * acc_o[i] * S_j;  // Qm = M^-1 - S Ao S
+    if (id.valid) Qw[i * NP + j] = qcol[i];
   }
-  // Cholesky Pm = L L^T, column j in lane j (trailing matrix kept symmetric)
-#pragma unroll
-  for (int k = 0; k < NP; ++k) {
-    const double akk = __shfl(pcol[k], k, NP);
-    const double rinv = 1.0 / sqrt(akk);
-    const double ljk = pcol[k] * rinv;  // L[j][k] by symmetry (meaningful for j > k)
-#pragma unroll
-    for (int i = k + 1; i < NP; ++i) {
-      const double lik = __shfl(pcol[i], k, NP) * rinv;
-      if (j > k) pcol[i] -= lik * ljk;
-      if (j == k) pcol[i] = lik;
-    }
-    if (j == k) pcol[k] = akk * rinv;
-  }
+  cholesky_columns<NP>(pcol, j);  // Pm = L L^T
+  cholesky_columns<NP>(qcol, j);  // Qm = R R^T
   double* Lw = d.Lw + id.pid * NP * NP;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    const double v = (i >= j) ? pcol[i] : 0.0;
-    pcol[i] = v;
-    L_[i * LD + j] = v;
-    if (id.valid) Lw[i * NP + j] = v;
+    L_[i * LD + j] = pcol[i];
+    if (id.valid) Lw[i * NP + j] = pcol[i];
   }
   __syncthreads();
-  // H = L^T Qm L; lane j: w = Qm L[:, j], then hx[s] = H[j^s][j] = sum_r L[r][j^s] w[r]
-  double wv[NP];
+  // H = L^T Qm L = F F^T with F = L^T R;  lane j: F[i][j] = sum_r L[r][i] R[r][j]
+  double* Fw = d.Gp + id.pid * NP * NP;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     double a = 0.0;
 #pragma unroll
-    for (int r = 0; r < NP; ++r) a += Q_[i * LD + r] * pcol[r];
-    wv[i] = a;
-  }
-  double* Hx = d.Gp + id.pid * NP * NP;
-#pragma unroll
-  for (int s = 0; s < NP; ++s) {
-    const int col = j ^ s;
-    double a = 0.0;
-#pragma unroll
-    for (int r = 0; r < NP; ++r) a += L_[r * LD + col] * wv[r];
-    if (id.valid) Hx[s * NP + j] = a;
+    for (int r = i; r < NP; ++r) a += L_[r * LD + i] * qcol[r];
+    if (id.valid) Fw[i * NP + j] = a;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stage 2: cyclic Jacobi (XOR round-robin ordering) on H; k^2 -> kk (squared, fixed up in stage 3),
-// Z -> Zw (aliases Gm) [prob][i][j].
+// Stage 2: one-sided cyclic Jacobi (XOR round-robin ordering) on the columns of F; k^2 -> kk (fixed up in
+// stage 3), k_j z_j -> Zw (aliases Gm) [prob][i][j].  Registers and cross-lane swizzles only.
 // ------------------------------------------------------------------------------------------------
+#ifndef RTD_JAC_WAVES
+#define RTD_JAC_WAVES 2
+#endif
 template <int NP>
-__global__ __launch_bounds__(64, (NP <= 8 ? 4 : (NP == 16 ? 2 : 1))) void rtd_jacobi_kernel(RtdDev d) {
-  constexpr int GPW = 64 / NP;
-  __shared__ double sCS[GPW][2 * NP];
-  const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
+__global__ __launch_bounds__(64, (NP <= 8 ? 4 : (NP == 16 ? RTD_JAC_WAVES : 1))) void rtd_jacobi_kernel(RtdDev d) {
+  const int j = threadIdx.x % NP;
   const ProbId id = locate<NP>(d);
-  double* cs = sCS[grp];
-  const double* Hx = d.Gp + id.pid * NP * NP;
-  double hx[NP], zc[NP];
+  const double* Fw = d.Gp + id.pid * NP * NP;
+  double w[NP];
 #pragma unroll
-  for (int s = 0; s < NP; ++s) {
-    hx[s] = Hx[s * NP + j];
-    zc[s] = (s == j) ? 1.0 : 0.0;
-  }
+  for (int i = 0; i < NP; ++i) w[i] = Fw[i * NP + j];
   int nsweep = 0;
-  for (int sweep = 0; sweep < 30; ++sweep) {
-    double offacc = 0.0;
-    JacobiStep<NP, 1>::run(hx, zc, j, cs, offacc);
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    int notconv = 0;
+    JacobiStep<NP, 1>::run(w, j, notconv);
     ++nsweep;
-    const double off = group_sum<NP>(offacc);
-    const double dg = group_sum<NP>(hx[0] * hx[0]);
-    // the off-diagonal mass seen during this sweep was already negligible -> converged
-    if (__all(off <= 1e-26 * dg)) break;
+    // every pair met during this sweep was already orthogonal to ~1e-13: the sweep just done finished the job
+    if (!__any(notconv)) break;
   }
   if (threadIdx.x == 0 && nsweep > *(volatile int*)d.sweeps) atomicMax(d.sweeps, nsweep);
   if (id.valid) {
-    d.kk[id.pid * NP + j] = hx[0];
+    double n2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) n2 += w[i] * w[i];
+    d.kk[id.pid * NP + j] = n2;  // k^2 (the post kernel takes the root and normalises the column)
     double* Zw = d.Gm + id.pid * NP * NP;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) Zw[i * NP + j] = zc[i];
+    for (int i = 0; i < NP; ++i) Zw[i * NP + j] = w[i];
   }
 }
 
@@ -304,6 +293,11 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
   }
   const double k2 = d.kk[base * NP + j];
   const double kj = sqrt(k2);
+  {
+    const double rk0 = 1.0 / kj;  // columns arrive as k_j z_j
+#pragma unroll
+    for (int i = 0; i < NP; ++i) zc[i] *= rk0;
+  }
   const double invmu_j = d.invmu[j], T_j = d.T[j];
   __syncthreads();
 

@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtd.so")
+LIB_PATH = os.environ.get("RTD_LIB", os.path.join(_HERE, "librtd.so"))  # RTD_LIB: A/B builds of the same ABI
 
 
 class rtd_dims(C.Structure):
