@@ -25,6 +25,14 @@
 
 namespace {
 
+#define RTD_FENCE() asm volatile("" ::: "memory")
+#ifndef RTD_GJ_BATCH
+#define RTD_GJ_BATCH 3  /* cross-lane fetches in flight per batch - 1 (power of two minus one) */
+#endif
+#ifndef RTD_SWEEP_WAVES
+#define RTD_SWEEP_WAVES 3
+#endif
+
 template <int MASK>
 __device__ __forceinline__ double xor_lane(double v) {
   constexpr int pat = (MASK << 10) | 0x1F;
@@ -42,6 +50,41 @@ __device__ __forceinline__ double group_max(double v) {
   if (NP > 8) v = fmax(v, xor_lane<8>(v));
   if (NP > 16) v = fmax(v, xor_lane<16>(v));
   return v;
+}
+
+
+// max over the NP lanes of a group for non-negative f32 keys, with DPP row operations (no LDS crossbar):
+// xor-1 and xor-2 quad permutes, row_half_mirror, row_mirror; one v_max_f32 each.
+template <int CTRL>
+__device__ __forceinline__ float dpp_max_f32(float v) {
+  const int o = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false);
+  return fmaxf(v, __int_as_float(o));
+}
+template <int NP>
+__device__ __forceinline__ float group_max_key(float v) {
+  v = dpp_max_f32<0xB1>(v);                // quad_perm [1,0,3,2]
+  v = dpp_max_f32<0x4E>(v);                // quad_perm [2,3,0,1]
+  if (NP > 4) v = dpp_max_f32<0x141>(v);   // row_half_mirror
+  if (NP > 8) v = dpp_max_f32<0x140>(v);   // row_mirror
+  if (NP > 16) {
+    const int o = __builtin_amdgcn_ds_swizzle(__float_as_int(v), (16 << 10) | 0x1F);
+    v = fmaxf(v, __int_as_float(o));
+  }
+  return v;
+}
+
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  y = y * (2.0 - x * y);
+  return y;
+}
+
+// value of `v` in lane `addr/4` (addr precomputed once per pivot step)
+__device__ __forceinline__ double bperm(int addr, double v) {
+  const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+  return __hiloint2double(hi, lo);
 }
 
 // Workspace layout per (c, m, l), l < L-1, inside d.Fws (4 NP^2 doubles per slot):
@@ -146,20 +189,29 @@ __global__ __launch_bounds__(64) void rtd_iface_kernel(RtdDev d) {
 template <int NP, int NB, int K>
 struct GjStep {
   static __device__ __forceinline__ void run(double (&am)[NP], double (&bm)[NB], double& bv, int& pc, const int grp) {
-    const double val = (pc < 0) ? fabs(am[K]) : -1.0;
-    const double vmax = group_max<NP>(val);
-    const unsigned long long bal = __ballot(val == vmax);
+    // pivot search on f32 keys (a pivot within 2^-24 of the largest candidate is as good as the largest)
+    const float key = (pc < 0) ? fabsf((float)am[K]) : -1.0f;
+    const float kmax = group_max_key<NP>(key);
+    const unsigned long long bal = __ballot(key == kmax);
     const unsigned int bits = (unsigned int)((bal >> (grp * NP)) & ((NP == 32) ? 0xffffffffull : ((1ull << NP) - 1)));
     const int src = __ffs((int)bits) - 1;  // pivot lane of this group
     const bool isp = ((int)(threadIdx.x % NP) == src);
-    const double piv = __shfl(am[K], src, NP);
-    const double rp = 1.0 / piv;
+    const int addr = (grp * NP + src) << 2;
+    const double piv = bperm(addr, am[K]);
+    const double rp = fast_rcp(piv);
     const double f = isp ? 0.0 : am[K] * rp;
+    // (scheduling barriers bound the number of cross-lane results in flight: register pressure)
 #pragma unroll
-    for (int c = K + 1; c < NP; ++c) am[c] -= f * __shfl(am[c], src, NP);
+    for (int c = K + 1; c < NP; ++c) {
+      am[c] -= f * bperm(addr, am[c]);
+      if ((c & RTD_GJ_BATCH) == RTD_GJ_BATCH) __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
-    for (int c = 0; c < NB; ++c) bm[c] -= f * __shfl(bm[c], src, NP);
-    bv -= f * __shfl(bv, src, NP);
+    for (int c = 0; c < NB; ++c) {
+      bm[c] -= f * bperm(addr, bm[c]);
+      if ((c & RTD_GJ_BATCH) == RTD_GJ_BATCH) __builtin_amdgcn_sched_barrier(0);
+    }
+    bv -= f * bperm(addr, bv);
     if (isp) {  // normalise the pivot row now: later steps leave it untouched in column K
       pc = K;
 #pragma unroll
@@ -180,7 +232,7 @@ struct GjStep<NP, NB, NP> {
 // Sweep kernel: per (c, m): forward carry recursion over the layers, bottom BC, backward sweep.
 // ------------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(64) void rtd_sweep_kernel(RtdDev d) {
+__global__ __launch_bounds__(64, (NP <= 16 ? RTD_SWEEP_WAVES : 1)) void rtd_sweep_kernel(RtdDev d) {
   constexpr int GPW = 64 / NP, LD = NP + 1, Q = 2 * NP;
   __shared__ double sA[GPW][NP * LD];  // Wq (forward) / S (bottom)
   __shared__ double sB[GPW][NP * LD];  // Wp
@@ -267,6 +319,7 @@ __global__ __launch_bounds__(64) void rtd_sweep_kernel(RtdDev d) {
       }
       ta[cc] = -(Er * swq + B_[pc * LD + cc]);           // Ta' = -(E S Wq + Wp)
       nbuf[cc] = -(Er * swp + A_[pc * LD + cc]) * v1[cc];  // Tb' = -(E S Wp + Wq) E'  (tb is still an input)
+      RTD_FENCE();
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) tb[k] = nbuf[k];
@@ -325,6 +378,7 @@ __global__ __launch_bounds__(64) void rtd_sweep_kernel(RtdDev d) {
 #pragma unroll
       for (int k = 0; k < NP; ++k) a -= ba[k] * A_[k * LD + cc];
       am[cc] = a;
+      RTD_FENCE();
     }
     double bvec = br;
 #pragma unroll

@@ -52,18 +52,25 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return y;
 }
 
+// a sweep is the last one when every pair it met had cos^2(angle) <= RTD_JAC_TOL (quadratic convergence
+// squares the residual angle during that sweep)
+#ifndef RTD_JAC_TOL
+#define RTD_JAC_TOL 1e-20
+#endif
+
 // One parallel step of the one-sided (Hestenes) Jacobi iteration on the columns of W (H = W W^T at the
 // start): lane j holds column j, all pairs (j, j^T) are orthogonalised at once.  On convergence the columns
 // are k_j z_j (singular values x left singular vectors = sqrt(eigenvalues) x eigenvectors of H).
 template <int NP, int T>
 struct JacobiStep {
-  static __device__ __forceinline__ void run(double (&w)[NP], const int j, int& notconv) {
+  // alpha = |w|^2 of this lane's column, maintained across steps (it only steers the rotation angles, so the
+  // slow drift of the recurrence is harmless; it is recomputed from the column at every sweep start)
+  static __device__ __forceinline__ void run(double (&w)[NP], double& alpha, const int j, int& notconv) {
     double pw[NP];
-    double alpha = 0.0, gamma = 0.0;
+    double gamma = 0.0;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       pw[i] = xor_lane<T>(w[i]);
-      alpha += w[i] * w[i];
       gamma += w[i] * pw[i];
     }
     const double beta = xor_lane<T>(alpha);
@@ -81,15 +88,16 @@ struct JacobiStep {
       const double s = tt * c;
       sg = lo ? -s : s;
     }
-    notconv |= (gamma * gamma > 1e-26 * alpha * beta) ? 1 : 0;
+    notconv |= (gamma * gamma > RTD_JAC_TOL * alpha * beta) ? 1 : 0;
+    alpha = c * c * alpha + sg * (sg * beta + 2.0 * c * gamma);
 #pragma unroll
     for (int i = 0; i < NP; ++i) w[i] = c * w[i] + sg * pw[i];
-    JacobiStep<NP, T + 1>::run(w, j, notconv);
+    JacobiStep<NP, T + 1>::run(w, alpha, j, notconv);
   }
 };
 template <int NP>
 struct JacobiStep<NP, NP> {
-  static __device__ __forceinline__ void run(double (&)[NP], const int, int&) {}
+  static __device__ __forceinline__ void run(double (&)[NP], double&, const int, int&) {}
 };
 
 // sum over the NP lanes of a group (result in every lane)
@@ -240,9 +248,12 @@ __global__ __launch_bounds__(64, (NP <= 8 ? 4 : (NP == 16 ? RTD_JAC_WAVES : 1)))
   int nsweep = 0;
   for (int sweep = 0; sweep < 40; ++sweep) {
     int notconv = 0;
-    JacobiStep<NP, 1>::run(w, j, notconv);
+    double alpha = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) alpha += w[i] * w[i];
+    JacobiStep<NP, 1>::run(w, alpha, j, notconv);
     ++nsweep;
-    // every pair met during this sweep was already orthogonal to ~1e-13: the sweep just done finished the job
+    // every pair met during this sweep was already orthogonal to ~1e-10: the sweep just done finished the job
     if (!__any(notconv)) break;
   }
   if (threadIdx.x == 0 && nsweep > *(volatile int*)d.sweeps) atomicMax(d.sweeps, nsweep);
