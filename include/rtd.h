@@ -87,12 +87,23 @@ int rtd_plan_solve(rtd_plan* plan);
  * u0     [C][NQuad][ntau]
  * fluxes [C][ntau]: flux_up, flux_down diffuse, flux_down direct
  * ulast  [C][NQuad][ntau]: last Fourier mode u^{M-1} (for return_Fourier_error), may be NULL
- * antiderivative != 0 switches every output to the tau-antiderivative (is_antiderivative_wrt_tau).
+ * antiderivative bit 0 switches every output to the tau-antiderivative (is_antiderivative_wrt_tau);
+ * bit 1 evaluates u without the Nakajima-Tanaka corrections even when rtd_plan_set_nt is active.
  * Any output pointer may be NULL.  Synchronous (returns when the host arrays are filled).
  * Returns RTD_ERR_TAU_RANGE if some tau lies outside its column (the reference raises ValueError). */
 int rtd_plan_evaluate(rtd_plan* plan, int32_t ntau, const double* tau, int32_t nphi, const double* phi,
                       int32_t antiderivative, double* u, double* u0, double* flux_up,
                       double* flux_down_diffuse, double* flux_down_direct, double* ulast);
+
+/* Nakajima-Tanaka intensity corrections (TMS + IMS; reference pydisort.py:375-698), applied on the device to the
+ * `u` output of rtd_plan_evaluate once set (the reference returns u_corrected in place of u).
+ *   weighted_leg_all [C][L][nleg_all]  (2l+1) g_l of the FULL phase function (weighted_Leg_coeffs_all)
+ *   f_arr            [C][L]            delta-M truncation fractions
+ *   ims_coef         [C][nleg_all]     (2l+1)(2 g~_l - g~_l^2), g~ the tau-omega weighted residual moments (:601-611)
+ *   ims_par          [C][2]            scaled_mu0 = mu0/(1 - omega_avg f_avg), amplitude I0/(4pi) (omega_avg f_avg)^2/(1 - omega_avg f_avg)
+ * nleg_all <= 0 switches the corrections off. */
+int rtd_plan_set_nt(rtd_plan* plan, int32_t nleg_all, const double* weighted_leg_all, const double* f_arr,
+                    const double* ims_coef, const double* ims_par);
 
 /* Throughput form: evaluation points are uploaded once, results stay in HBM. */
 int rtd_plan_set_eval_points(rtd_plan* plan, int32_t ntau, const double* tau, int32_t nphi, const double* phi);

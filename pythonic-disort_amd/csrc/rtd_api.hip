@@ -52,6 +52,9 @@ struct rtd_plan {
   int64_t cap_tau = 0, cap_phi = 0, cap_u = 0, cap_u0 = 0, cap_fl = 0;
   // export buffers
   double* ex_buf = nullptr;
+  // Nakajima-Tanaka corrections (optional)
+  RtdNt nt{};
+  bool have_nt = false, nt_tables_ready = false;
   // RCCL communicator (one rank per GPU), gathered flux results [nranks][3][C][ntau]
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_size = 0;
@@ -397,13 +400,21 @@ int rtd_plan_evaluate(rtd_plan* p, int32_t ntau, const double* tau, int32_t nphi
   if (!p->solved) return fail(RTD_ERR_STATE, "evaluate before solve");
   int rc = rtd_plan_set_eval_points(p, ntau, tau, nphi, phi);
   if (rc) return rc;
-  RtdEval e = make_eval(p, antiderivative, u != nullptr);
+  const bool skip_nt = (antiderivative & 2) != 0;
+  RtdEval e = make_eval(p, antiderivative & 1, u != nullptr);
   if (p->timing) {
     (void)hipStreamSynchronize(p->stream);
     harvest(p);
     (void)hipEventRecord(p->evt[3], p->stream);
   }
   rtd_launch_eval(p->d, e, p->stream);
+  if (p->have_nt && !skip_nt && e.u != nullptr) {
+    if (!p->nt_tables_ready) {
+      rtd_launch_nt_tables(p->d, p->nt, p->stream);
+      p->nt_tables_ready = true;
+    }
+    rtd_launch_nt_apply(p->d, p->nt, e, p->stream);
+  }
   if (p->timing) {
     (void)hipEventRecord(p->evt[4], p->stream);
     p->pending[3] = true;
@@ -416,6 +427,35 @@ int rtd_plan_evaluate(rtd_plan* p, int32_t ntau, const double* tau, int32_t nphi
     const int64_t C = p->d.C, Qr = 2 * p->d.N;
     HIP_TRY(hipMemcpy(ulast, p->ev_u0 + C * Qr * ntau, (size_t)(C * Qr * ntau) * 8, hipMemcpyDeviceToHost));
   }
+  return 0;
+}
+
+int rtd_plan_set_nt(rtd_plan* p, int32_t nleg_all, const double* weighted_leg_all, const double* f_arr,
+                    const double* ims_coef, const double* ims_par) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  if (nleg_all <= 0) {  // switch the corrections off
+    p->have_nt = false;
+    return 0;
+  }
+  if (!weighted_leg_all || !f_arr || !ims_coef || !ims_par) return fail(RTD_ERR_ARG, "null argument");
+  if (!p->d.beam) return fail(RTD_ERR_ARG, "NT corrections need a beam source");
+  HIP_TRY(hipSetDevice(p->device));
+  const int64_t C = p->d.C, L = p->d.L;
+  double *w, *f, *ic, *ip, *R;
+  int rc;
+  if ((rc = p->alloc(&w, C * L * nleg_all)) || (rc = p->alloc(&f, C * L)) || (rc = p->alloc(&ic, C * nleg_all)) ||
+      (rc = p->alloc(&ip, C * 2)) || (rc = p->alloc(&R, C * 4 * p->d.NP * L)))
+    return rc;
+  hipStream_t s = p->stream;
+  HIP_TRY(hipMemcpyAsync(w, weighted_leg_all, (size_t)(C * L * nleg_all) * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(f, f_arr, (size_t)(C * L) * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ic, ims_coef, (size_t)(C * nleg_all) * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ip, ims_par, (size_t)(C * 2) * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  p->nt.nleg_all = nleg_all;
+  p->nt.wfull = w; p->nt.f = f; p->nt.ims_coef = ic; p->nt.ims_par = ip; p->nt.R = R;
+  p->have_nt = true;
+  p->nt_tables_ready = false;
   return 0;
 }
 

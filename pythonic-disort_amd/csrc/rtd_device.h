@@ -45,10 +45,22 @@ struct RtdEval {
   double *u, *u0, *fup, *fdn, *fdir, *ulast;  // device outputs (may be null)
 };
 
+// Nakajima-Tanaka corrections (rtd_nt.hip)
+struct RtdNt {
+  int nleg_all;
+  const double* wfull;     // [C][L][nleg_all]  (2l+1) g_l of the full phase function
+  const double* f;         // [C][L]            delta-M truncation fractions
+  const double* ims_coef;  // [C][nleg_all]     Legendre series of the IMS correction
+  const double* ims_par;   // [C][2]            scaled mu0, amplitude
+  double* R;               // [C][2][2][NP][L]  other-layer sums: [antiderivative][up|down]
+};
+
 // launchers (one per translation unit)
 void rtd_launch_tables(const RtdDev& d, hipStream_t s);
 void rtd_launch_eig(const RtdDev& d, hipStream_t s);
 void rtd_launch_bc(const RtdDev& d, hipStream_t s);
 void rtd_launch_eval(const RtdDev& d, const RtdEval& e, hipStream_t s);
+void rtd_launch_nt_tables(const RtdDev& d, const RtdNt& nt, hipStream_t s);
+void rtd_launch_nt_apply(const RtdDev& d, const RtdNt& nt, const RtdEval& e, hipStream_t s);
 void rtd_launch_export(const RtdDev& d, int col, double* GC, double* K, double* B, double* Gim, double* G,
                        hipStream_t s);

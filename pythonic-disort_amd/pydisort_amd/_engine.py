@@ -43,6 +43,14 @@ class Plan:
         except Exception:
             pass
 
+    def set_nt(self, weighted_leg_all, f_arr, ims_coef, ims_par):
+        """Enable device-side Nakajima-Tanaka corrections of `u` (arrays with a leading column axis)."""
+        a = [_f64(v) for v in (weighted_leg_all, f_arr, ims_coef, ims_par)]
+        _lib.check(self._lib.rtd_plan_set_nt(self._h, a[0].shape[-1], *[_lib.dptr(v) for v in a]))
+
+    def clear_nt(self):
+        _lib.check(self._lib.rtd_plan_set_nt(self._h, 0, None, None, None, None))
+
     def solve(self):
         _lib.check(self._lib.rtd_plan_solve(self._h))
         self.solved = True
@@ -55,7 +63,7 @@ class Plan:
         _lib.check(self._lib.rtd_plan_device_bytes(self._h, C.byref(b)))
         return b.value
 
-    def evaluate(self, tau, phi=None, antiderivative=False, want=("u", "u0", "flux")):
+    def evaluate(self, tau, phi=None, antiderivative=False, want=("u", "u0", "flux"), skip_nt=False):
         """tau [C, ntau]; phi [nphi] or None -> dict of arrays (u [C,Q,ntau,nphi], u0 [C,Q,ntau],
         flux_up / flux_down_diffuse / flux_down_direct [C,ntau], ulast [C,Q,ntau])."""
         tau = _f64(np.atleast_2d(tau))
@@ -69,7 +77,8 @@ class Plan:
         ul = np.empty((self.C, self.Q, ntau)) if "ulast" in want else None
         fl = [np.empty((self.C, ntau)) for _ in range(3)] if "flux" in want else [None] * 3
         _lib.check(self._lib.rtd_plan_evaluate(self._h, ntau, _lib.dptr(tau), nphi, _lib.dptr(phi),
-                                               int(bool(antiderivative)), _lib.dptr(u), _lib.dptr(u0),
+                                               int(bool(antiderivative)) | (2 if skip_nt else 0), _lib.dptr(u),
+                                               _lib.dptr(u0),
                                                _lib.dptr(fl[0]), _lib.dptr(fl[1]), _lib.dptr(fl[2]),
                                                _lib.dptr(ul)))
         out.update(u=u, u0=u0, ulast=ul, flux_up=fl[0], flux_down_diffuse=fl[1], flux_down_direct=fl[2])

@@ -29,6 +29,7 @@ SIGNATURES = {
     "rtd_plan_set_columns": (C.c_int, [_vp] + [_dp] * 14),
     "rtd_plan_solve": (C.c_int, [_vp]),
     "rtd_plan_evaluate": (C.c_int, [_vp, C.c_int32, _dp, C.c_int32, _dp, C.c_int32] + [_dp] * 6),
+    "rtd_plan_set_nt": (C.c_int, [_vp, C.c_int32, _dp, _dp, _dp, _dp]),
     "rtd_plan_set_eval_points": (C.c_int, [_vp, C.c_int32, _dp, C.c_int32, _dp]),
     "rtd_plan_run": (C.c_int, [_vp]),
     "rtd_plan_fetch": (C.c_int, [_vp] + [_dp] * 5),

@@ -3,6 +3,7 @@ reference solves one column per ``pydisort`` call).""
 import numpy as np
 
 from ._engine import Plan
+from . import _nt
 from ._prepare import double_gauss, prepare_columns
 
 
@@ -40,12 +41,14 @@ class BatchSolution:
 
 
 def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLeg=None, NFourier=None,
-                   b_pos=0, b_neg=0, only_flux=False, f_arr=0, bdrf_q=None, bdrf_q0=None,
+                   b_pos=0, b_neg=0, only_flux=False, f_arr=0, NT_cor=False, bdrf_q=None, bdrf_q0=None,
                    s_poly_coeffs=None, device=0):
     """Like ``pydisort`` with a leading column axis on every atmospheric input:
     tau_arr, omega_arr, f_arr [C, L]; Leg_coeffs_all [C, L, NLeg_all]; mu0, I0, phi0 [C];
     b_pos / b_neg: scalar, [C], [C, N] or [C, N, NFourier]; s_poly_coeffs [C, L, Ns];
     bdrf_q [C, NBDRF, N, N] and bdrf_q0 [C, NBDRF, N]: BDRF Fourier modes tabulated on the quadrature grid.
+    NT_cor=True adds the Nakajima-Tanaka corrections to ``u`` on the device (needs a beam in every column,
+    f_arr > 0 and more Legendre coefficients than NLeg).
     All columns share NQuad, NLeg, NFourier and the layer count.  Returns (mu_arr, BatchSolution)."""
     tau_arr = np.atleast_2d(np.asarray(tau_arr, float))
     C, L = tau_arr.shape
@@ -92,5 +95,11 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
                            f_arr, sp, bq, bq0)
     plan = Plan(prep, device=device)
     plan.solve()
+    if NT_cor and not only_flux:
+        if not (np.all(I0 > 0) and np.any(f_arr > 0) and NLeg < Leg.shape[2]):
+            raise ValueError("NT_cor needs a beam source in every column, f_arr > 0 and NLeg < number of Legendre coefficients.")
+        if np.any(np.abs(prep["mu"][None, :] - mu0[:, None]) < 1e-8):
+            raise ValueError("Some quadrature angles come too close to `mu0`. Perturb `NQuad` or `mu0` to rectify this error.")
+        plan.set_nt(*_nt.nt_inputs(prep, omega_arr, f_arr, Leg, NLeg, mu0))
     sol = BatchSolution(plan, prep)
     return sol.mu_arr, sol

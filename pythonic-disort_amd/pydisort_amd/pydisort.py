@@ -175,9 +175,8 @@ def pydisort(
     if only_flux:
         return mu_arr, sol.flux_up, sol.flux_down, sol.u0
     nt_on = (NT_cor and beam and np.any(f_arr > 0) and NLeg < NLeg_all and np.any(omega_arr > 0))
-    if nt_on:
-        corr = _nt.Corrections(prep, mu_pos, omega_arr, f_full, Leg_coeffs_all, NLeg, mu0, phi0)
-        return mu_arr, sol.flux_up, sol.flux_down, sol.u0, sol.make_corrected_u(corr)
+    if nt_on:  # the device adds TMS + IMS to u from now on (the reference returns u_corrected as `u`, :696-698)
+        plan.set_nt(*_nt.nt_inputs(prep, omega_arr[None], f_full[None], Leg_coeffs_all[None], NLeg, [mu0]))
     return mu_arr, sol.flux_up, sol.flux_down, sol.u0, sol.u
 
 
@@ -198,12 +197,11 @@ class _Closures:
           *, _return_l=False):
         tau = self._tau(tau)
         phi = np.atleast_1d(np.asarray(phi, dtype=float))
-        want = ("u", "ulast") if return_Fourier_error else ("u",)
-        r = self.plan.evaluate(tau[None], phi, is_antiderivative_wrt_tau, want=want)
-        full = r["u"][0]
-        outs = (np.squeeze(full),)
-        if return_Fourier_error:  # _assemble.py:264-318
-            ua = np.abs(full)
+        r = self.plan.evaluate(tau[None], phi, is_antiderivative_wrt_tau, want=("u",))
+        outs = (np.squeeze(r["u"][0]),)
+        if return_Fourier_error:  # _assemble.py:264-318; measured on the uncorrected delta-M solution (pydisort.py:652-660)
+            r = self.plan.evaluate(tau[None], phi, is_antiderivative_wrt_tau, want=("u", "ulast"), skip_nt=True)
+            ua = np.abs(r["u"][0])
             last = np.abs(r["ulast"][0][:, :, None] * np.cos((self.M - 1) * (self.prep["phi0"][0] - phi))[None, None, :])
             outs += (np.max(np.divide(last, ua, out=np.zeros_like(ua), where=ua > 1e-8 * self.prep["rescale"][0])),)
         if return_tau_arr:
@@ -246,15 +244,3 @@ class _Closures:
         direct = np.squeeze(r["flux_down_direct"][0])[()] if self.beam else np.float64(0.0)
         outs = (np.squeeze(r["flux_down_diffuse"][0])[()], direct)
         return outs + (self.tau_arr,) if return_tau_arr else outs
-
-    def make_corrected_u(self, corr):
-        def u_corrected(tau, phi, is_antiderivative_wrt_tau=False, return_Fourier_error=False, return_tau_arr=False):
-            tau_a = self._tau(tau)
-            phi_a = np.atleast_1d(np.asarray(phi, dtype=float))
-            base = self.u(tau_a, phi_a, is_antiderivative_wrt_tau, return_Fourier_error, return_tau_arr)
-            add = np.squeeze(corr(tau_a, phi_a, is_antiderivative_wrt_tau))
-            if isinstance(base, tuple):
-                return (base[0] + add,) + base[1:]
-            return base + add
-
-        return u_corrected

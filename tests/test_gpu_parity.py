@@ -215,3 +215,26 @@ def test_rccl_allgather_single_rank(amd):
     assert got.shape == (1, 3, 8, 6)
     assert np.array_equal(got[0, 0], res["flux_up"]) and np.array_equal(got[0, 1], res["flux_down_diffuse"])
     assert np.array_equal(got[0, 2], res["flux_down_direct"])
+
+
+def test_batch_nt_corrections_match_single_column_reference_path(amd):
+    """pydisort_batch(NT_cor=True) == per-column drop-in pydisort(NT_cor=True) == oracle with NT."""
+    from oracle import disort_oracle as O
+    from pydisort_amd import synthetic
+    C = 3
+    cfg = synthetic.cfg4_columns(C, L=5, NQuad=16)
+    k = np.arange(40)
+    g = cfg["Leg_coeffs_all"][:, :, 1]
+    cfg["Leg_coeffs_all"] = g[:, :, None] ** k[None, None, :]   # more moments than NLeg -> corrections active
+    _, sol = amd.pydisort_batch(NT_cor=True, **cfg)
+    tau = np.concatenate((np.zeros((C, 1)), cfg["tau_arr"] * 0.999), axis=1)
+    phi = np.array([0.1, 2.0, 4.0])
+    u = sol.u(tau, phi)
+    for i in range(C):
+        kw = synthetic.column_kwargs(cfg, i)
+        want = O.pydisort(NT_cor=True, **kw)[4](tau[i], phi)
+        assert np.max(np.abs(u[i] - want)) / np.max(np.abs(want)) < 1e-9
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got1 = amd.pydisort(NT_cor=True, **kw)[4](tau[i], phi)
+        assert np.max(np.abs(got1 - u[i])) / np.max(np.abs(want)) < 1e-12
