@@ -101,8 +101,8 @@ struct Ws {
 template <int NP>
 __global__ __launch_bounds__(64) void rtd_iface_kernel(RtdDev d) {
   constexpr int GPW = 64 / NP, LD = NP + 1, Q = 2 * NP;
-  __shared__ double sVi[GPW][NP * LD];
-  __shared__ double sUi[GPW][NP * LD];
+  __shared__ double sA[GPW][NP * LD];  // A_l  (natural [i][j])
+  __shared__ double sY[GPW][NP * LD];  // Y_l
   const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
   const int Lm1 = d.L - 1;
   const long nprob = (long)d.C * d.M * Lm1;
@@ -113,49 +113,53 @@ __global__ __launch_bounds__(64) void rtd_iface_kernel(RtdDev d) {
   const long cm = pid / Lm1;
   const int m = (int)(cm % d.M), c = (int)(cm / d.M);
   const long p0 = cm * d.L + l, p1 = p0 + 1;
-  double* Vi = sVi[grp];
-  double* Ui = sUi[grp];
-  {  // V^-1, U^-1 of layer l were stored transposed ([i][j] = inv[j][i]) by the post kernel
-    const double* ViT = d.Lw + p0 * NP * NP;
-    const double* UiT = d.Qw + p0 * NP * NP;
+  double* A0 = sA[grp];
+  double* Y0 = sY[grp];
+  {
+    const double* Am = d.Am + p0 * NP * NP;
+    const double* Ym = d.Ym + p0 * NP * NP;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      Vi[j * LD + i] = ViT[i * NP + j];
-      Ui[j * LD + i] = UiT[i * NP + j];
+      A0[i * LD + j] = Am[i * NP + j];
+      Y0[i * LD + j] = Ym[i * NP + j];
     }
   }
-  // column j of V' = (Gp'+Gm')/2 and U' = (Gp'-Gm')/2 of layer l+1
-  double vcol[NP], ucol[NP];
+  // column j of Y' and A' of layer l+1
+  double ycol[NP], acol[NP];
   {
-    const double* gp = d.Gp + p1 * NP * NP;
-    const double* gm = d.Gm + p1 * NP * NP;
+    const double* Ym = d.Ym + p1 * NP * NP;
+    const double* Am = d.Am + p1 * NP * NP;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const double a = gp[i * NP + j], b = gm[i * NP + j];
-      vcol[i] = 0.5 * (a + b);
-      ucol[i] = 0.5 * (a - b);
+      ycol[i] = Ym[i * NP + j];
+      acol[i] = Am[i * NP + j];
     }
   }
   __syncthreads();
+  // V^-1 V' = A^T Y'   and   U^-1 U' = diag(k) Y^T A' diag(1/k')   (T cancels)
+  const double rk1 = 1.0 / d.kk[p1 * NP + j];
   double* ws = d.Fws + (cm * Lm1 + l) * Ws<NP>::SLOT;
 #pragma unroll 4
   for (int r = 0; r < NP; ++r) {
     double vv = 0.0, uu = 0.0;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      vv += Vi[r * LD + i] * vcol[i];
-      uu += Ui[r * LD + i] * ucol[i];
+      vv += A0[i * LD + r] * ycol[i];
+      uu += Y0[i * LD + r] * acol[i];
     }
+    uu *= d.kk[p0 * NP + r] * rk1;
     if (valid) {
       ws[Ws<NP>::WP + r * NP + j] = 0.5 * (vv + uu);
       ws[Ws<NP>::WQ + r * NP + j] = 0.5 * (vv - uu);
     }
   }
-  // particular-solution jump r_l at the interface (:184-205, :242-245) and rho = G_l^-1 r_l
+  // particular-solution jump r_l at the interface (:184-205, :242-245) and rho = G_l^-1 r_l:
+  //   rho_t/b = 1/4 [ V^-1 (r_up + r_dn) +- U^-1 (r_up - r_dn) ],  V^-1[j][i] = T_i A[i][j],  U^-1[j][i] = -k_j T_i Y[i][j]
   const double* ts0 = d.taus0 + (long)c * (d.L + 1);
   const double tb = ts0[l + 1];
   const double att = d.beam ? exp(-tb / d.mu0[c]) : 0.0;
   const bool iso = d.Ns > 0 && m == 0;
+  const double kj = d.kk[p0 * NP + j];
   double rt = 0.0, rb = 0.0;
 #pragma unroll 4
   for (int i = 0; i < NP; ++i) {
@@ -174,7 +178,8 @@ __global__ __launch_bounds__(64) void rtd_iface_kernel(RtdDev d) {
         tp *= tb;
       }
     }
-    const double a = Vi[j * LD + i] * (ru + rd), b = Ui[j * LD + i] * (ru - rd);
+    const double Ti = d.T[i];
+    const double a = Ti * A0[i * LD + j] * (ru + rd), b = -kj * Ti * Y0[i * LD + j] * (ru - rd);
     rt += a + b;
     rb += a - b;
   }
@@ -250,8 +255,10 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_SWEEP_WAVES : 1)) void rtd_swee
   double* v1 = sV[grp][1];
   double* v2 = sV[grp][2];
   double* v3 = sV[grp][3];
-  const double* Gp = d.Gp + cm * L * NP * NP;
-  const double* Gm = d.Gm + cm * L * NP * NP;
+  const double* Ym = d.Ym + cm * L * NP * NP;
+  const double* Am = d.Am + cm * L * NP * NP;
+  const double* kk = d.kk + cm * L * NP;
+  const double rTj = 1.0 / d.T[j];  // row scaling of G: Gp = (Y - A/k)/T, Gm = (Y + A/k)/T
   const double* Ek = d.Ek + cm * L * NP;
   const double* Bv = d.Bv + cm * L * Q;
   const double* ts0 = d.taus0 + (long)c * (L + 1);
@@ -274,8 +281,9 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_SWEEP_WAVES : 1)) void rtd_swee
   double ta[NP], tb[NP], tt;
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
-    ta[k] = Gm[j * NP + k];
-    tb[k] = Gp[j * NP + k] * Ek[k];
+    const double yv = Ym[j * NP + k], av = Am[j * NP + k] / kk[k];
+    ta[k] = (yv + av) * rTj;          // Gm_0
+    tb[k] = (yv - av) * rTj * Ek[k];  // Gp_0 E_0
   }
   tt = d.bneg[cm * NP + j];
   if (beam) tt -= Bv[NP + j];
@@ -335,14 +343,17 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_SWEEP_WAVES : 1)) void rtd_swee
   __syncthreads();
   {
     const int l = Lm1;
-    const double* gp = Gp + (long)l * NP * NP;
-    const double* gm = Gm + (long)l * NP * NP;
+    const double* ymL = Ym + (long)l * NP * NP;
+    const double* amL = Am + (long)l * NP * NP;
+    const double* kl = kk + (long)l * NP;
     const double att = beam ? exp(-ts0[L] / mu0) : 0.0;
-    double ba[NP], bb[NP];
+    // Ba = Gp - R Gm, Bb = Gm - R Gp  built from  P = (I - R) Y / T-rows and  Qd = (I + R) A / (k T-rows):
+    //   Gp = P0 - Q0, Gm = P0 + Q0 with P0 = Y/T, Q0 = A/(kT)  =>  Ba = (P0 - R P0) - (Q0 + R Q0), Bb = (P0 - R P0) + (Q0 + R Q0)
+    double pa[NP], qa[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      ba[k] = gp[j * NP + k];
-      bb[k] = gm[j * NP + k];
+      pa[k] = ymL[j * NP + k] * rTj;
+      qa[k] = amL[j * NP + k] * rTj;
     }
     double br = d.bpos[cm * NP + j];
     if (m < d.NBDRF) {
@@ -350,14 +361,15 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_SWEEP_WAVES : 1)) void rtd_swee
       const double* qt = d.bdrfq + (((long)c * d.NBDRF + m) * NP + j) * NP;
       double rbm = 0.0, rvm = 0.0;
       for (int j2 = 0; j2 < NP; ++j2) {
-        const double Rij = delta * qt[j2] * d.mu[j2] * d.w[j2];  // R = (1 + delta_m0) q (mu w)
+        const double Rij = delta * qt[j2] * d.mu[j2] * d.w[j2] / d.T[j2];  // R = (1 + delta_m0) q (mu w), times 1/T_j2
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-          ba[k] -= Rij * gm[j2 * NP + k];
-          bb[k] -= Rij * gp[j2 * NP + k];
+          pa[k] -= Rij * ymL[j2 * NP + k];
+          qa[k] += Rij * amL[j2 * NP + k];
         }
-        if (beam) rbm += Rij * Bv[l * Q + NP + j2];
-        if (iso) rvm += Rij * vpoly(l, ts0[L], NP + j2);
+        const double Rraw = Rij * d.T[j2];
+        if (beam) rbm += Rraw * Bv[l * Q + NP + j2];
+        if (iso) rvm += Rraw * vpoly(l, ts0[L], NP + j2);
       }
       if (beam) {
         const double Xs = mu0 * d.I0[c] / M_PI * d.bdrfq0[((long)c * d.NBDRF + m) * NP + j];
@@ -367,6 +379,13 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_SWEEP_WAVES : 1)) void rtd_swee
     } else {
       if (beam) br -= Bv[l * Q + j] * att;
       if (iso) br -= vpoly(l, ts0[L], j);
+    }
+    double ba[NP], bb[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const double qk = qa[k] / kl[k];
+      ba[k] = pa[k] - qk;
+      bb[k] = pa[k] + qk;
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) ba[k] *= Ek[l * NP + k];

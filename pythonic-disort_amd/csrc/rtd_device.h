@@ -2,9 +2,11 @@
 //
 // Device-side layout (all float64, NP = per-hemisphere stream count padded to a power of two,
 // Q2 = 2*NP; padded streams have mu = 2, w = 0 and decouple exactly):
-//   Gp, Gm   [C][M][L][NP][NP]  the two distinct blocks of the reference's eigenvector matrix
-//                               G = [[Gp, Gm],[Gm, Gp]]  (_solve_for_gen_and_part_sols.py:192-198),
-//                               row = stream, column = eigen-index
+//   Ym, Am   [C][M][L][NP][NP]  Y = L^-T Z and A = L Z (row = stream, column = eigen-index): everything the
+//                               later stages need of the reference's eigenvector matrix
+//                               G = [[Gp, Gm],[Gm, Gp]]  (_solve_for_gen_and_part_sols.py:192-198):
+//                               Gp = (Y - A/k)/T, Gm = (Y + A/k)/T,  V = (Gp+Gm)/2 = Y/T, U = (Gp-Gm)/2 = -A/(kT),
+//                               V^-1 = A^T T, U^-1 = -k Y^T T   (T = diag(sqrt(mu w)))
 //   kk       [C][M][L][NP]      positive eigenvalues k;   K = [-k, +k]      (:186-187)
 //   Bv       [C][M][L][Q2]      beam particular solution  [B+ ; B-]         (:209-231)
 //   dq       [C][L][Ns][Q2]     isotropic-source particular solution as polynomial coefficient
@@ -29,9 +31,8 @@ struct RtdDev {
   const double* spoly;        // [C][L][Ns]
   const double *bdrfq, *bdrfq0;  // [C][NBDRF][NP][NP], [C][NBDRF][NP]
   // intermediates
-  double *Gp, *Gm, *kk, *Bv, *dq, *zneg, *coef;
-  double *Lw, *Qw;    // eigen-stage workspace [C][M][L][NP][NP]: Cholesky factor L, symmetrised Qm;
-                      // after the post kernel: V^-1 and U^-1 (transposed) of G = [[V+U, V-U],[V-U, V+U]]
+  double *Ym, *Am, *kk, *Bv, *dq, *zneg, *coef;
+  double *Lw, *Qw;    // eigen-stage workspace [C][M][L][NP][NP]: Cholesky factor L, symmetrised Qm
   double* Ek;         // [C][M][L][NP]  exp(-k dtau*_l): the Stamnes-Conklin scaling factors
   double* Fws;  // BC workspace: [C][M][L-1][4 NP^2]: Wp, Wq, S, rho_t, rho_b, s per interface (rtd_bc.hip)
   int* sweeps;        // [1] max Jacobi sweeps (diagnostic)

@@ -156,7 +156,7 @@ __device__ __forceinline__ ProbId locate(const RtdDev& d) {
 // ------------------------------------------------------------------------------------------------
 // Stage 1: assemble Pm, Qm (symmetrised alpha+-beta), Cholesky Pm = L L^T, Qm = R R^T, F = L^T R (H = F F^T).
 // Workspace written: Lw [prob][NP][NP] (row-major L), Qw [prob][NP][NP] (Qm),
-//                    F (aliases Gp) [prob][i][j].
+//                    F (aliases Ym) [prob][i][j].
 // ------------------------------------------------------------------------------------------------
 template <int NP>
 __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_asm_kernel(RtdDev d) {
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_asm_kernel(RtdDev 
   }
   __syncthreads();
   // H = L^T Qm L = F F^T with F = L^T R;  lane j: F[i][j] = sum_r L[r][i] R[r][j]
-  double* Fw = d.Gp + id.pid * NP * NP;
+  double* Fw = d.Ym + id.pid * NP * NP;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     double a = 0.0;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_asm_kernel(RtdDev 
 
 // ------------------------------------------------------------------------------------------------
 // Stage 2: one-sided cyclic Jacobi (XOR round-robin ordering) on the columns of F; k^2 -> kk (fixed up in
-// stage 3), k_j z_j -> Zw (aliases Gm) [prob][i][j].  Registers and cross-lane swizzles only.
+// stage 3), k_j z_j -> Zw (aliases Am) [prob][i][j].  Registers and cross-lane swizzles only.
 // ------------------------------------------------------------------------------------------------
 #ifndef RTD_JAC_WAVES
 #define RTD_JAC_WAVES 2
@@ -241,7 +241,7 @@ template <int NP>
 __global__ __launch_bounds__(64, (NP <= 8 ? 4 : (NP == 16 ? RTD_JAC_WAVES : 1))) void rtd_jacobi_kernel(RtdDev d) {
   const int j = threadIdx.x % NP;
   const ProbId id = locate<NP>(d);
-  const double* Fw = d.Gp + id.pid * NP * NP;
+  const double* Fw = d.Ym + id.pid * NP * NP;
   double w[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) w[i] = Fw[i * NP + j];
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64, (NP <= 8 ? 4 : (NP == 16 ? RTD_JAC_WAVES : 1)))
 #pragma unroll
     for (int i = 0; i < NP; ++i) n2 += w[i] * w[i];
     d.kk[id.pid * NP + j] = n2;  // k^2 (the post kernel takes the root and normalises the column)
-    double* Zw = d.Gm + id.pid * NP * NP;
+    double* Zw = d.Am + id.pid * NP * NP;
 #pragma unroll
     for (int i = 0; i < NP; ++i) Zw[i * NP + j] = w[i];
   }
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
   {
     const double* Lw = d.Lw + base * NP * NP;
     const double* Qw = d.Qw + base * NP * NP;
-    const double* Zw = d.Gm + base * NP * NP;
+    const double* Zw = d.Am + base * NP * NP;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       L_[i * LD + j] = Lw[i * NP + j];
@@ -312,45 +312,32 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
   const double invmu_j = d.invmu[j], T_j = d.T[j];
   __syncthreads();
 
-  // eigenvector blocks: Vt = T^-1 L^-T Z, Ut = -T^-1 L Z / k ; Gp = Vt + Ut, Gm = Vt - Ut (:190-198)
-  double gp[NP], gm[NP];
-  {
-    double y[NP];
+  // eigenvector blocks (:190-198): V = T^-1 L^-T Z, U = (alpha+beta) V / k = -T^-1 L Z / k; stored as
+  // Y = L^-T Z and A = L Z, from which Gp = (Y - A/k)/T, Gm = (Y + A/k)/T, V^-1 = A^T T, U^-1 = -k Y^T T
+  double ya[NP], aa[NP];
 #pragma unroll
-    for (int i = NP - 1; i >= 0; --i) {
-      double a = zc[i];
+  for (int i = NP - 1; i >= 0; --i) {
+    double a = zc[i];
 #pragma unroll
-      for (int r = i + 1; r < NP; ++r) a -= L_[r * LD + i] * y[r];
-      y[i] = a / L_[i * LD + i];
-      RTD_FENCE();
-    }
-    const double rk = 1.0 / kj;
+    for (int r = i + 1; r < NP; ++r) a -= L_[r * LD + i] * ya[r];
+    ya[i] = a / L_[i * LD + i];
+    RTD_FENCE();
+  }
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      double a = 0.0;
+  for (int i = 0; i < NP; ++i) {
+    double a = 0.0;
 #pragma unroll
-      for (int r = 0; r <= i; ++r) a += L_[i * LD + r] * zc[r];
-      const double Ti = d.T[i];
-      const double rT = 1.0 / Ti;
-      const double vt = y[i] * rT, ut = -a * rk * rT;
-      gp[i] = vt + ut;
-      gm[i] = vt - ut;
-      // closed-form inverses for the boundary-condition stage (rtd_bc.hip): with V = T^-1 L^-T Z and
-      // U = -T^-1 L Z / k:  V^-1[j][i] = T_i (L z_j)_i,  U^-1[j][i] = -k_j T_i (L^-T z_j)_i; stored transposed
-      if (valid) {
-        d.Lw[base * NP * NP + i * NP + j] = Ti * a;
-        d.Qw[base * NP * NP + i * NP + j] = -kj * Ti * y[i];
-      }
-      RTD_FENCE();
-    }
+    for (int r = 0; r <= i; ++r) a += L_[i * LD + r] * zc[r];
+    aa[i] = a;
+    RTD_FENCE();
   }
   if (valid) {
-    double* Gp = d.Gp + base * NP * NP;
-    double* Gm = d.Gm + base * NP * NP;
+    double* Ym = d.Ym + base * NP * NP;
+    double* Am = d.Am + base * NP * NP;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      Gp[i * NP + j] = gp[i];
-      Gm[i * NP + j] = gm[i];
+      Ym[i * NP + j] = ya[i];
+      Am[i * NP + j] = aa[i];
     }
     d.kk[base * NP + j] = kj;
     const double* ts0 = d.taus0 + (long)c * (d.L + 1);
@@ -389,17 +376,19 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
         pw_neg *= -rk;
       }
       const double a = zn * bneg, b = -zn * bpos;
-      // up-streams: Gp a + Gm b ; down-streams: Gm a + Gp b  (sum over eigen-index = lanes)
+      // up-streams: Gp a + Gm b ; down-streams: Gm a + Gp b  (sum over eigen-index = lanes), with
+      // Gp = (Y - A/k)/T, Gm = (Y + A/k)/T:  up = [Y (a+b) - A (a-b)/k]/T, down = [Y (a+b) + A (a-b)/k]/T
+      const double sab = a + b, dab = (a - b) * rk;
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < NP; ++i) R_[i * LD + j] = gp[i] * a + gm[i] * b;
+      for (int i = 0; i < NP; ++i) R_[i * LD + j] = (ya[i] * sab - aa[i] * dab) / d.T[i];
       __syncthreads();
       double up = 0.0;
 #pragma unroll
       for (int r = 0; r < NP; ++r) up += R_[j * LD + r];
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < NP; ++i) R_[i * LD + j] = gm[i] * a + gp[i] * b;
+      for (int i = 0; i < NP; ++i) R_[i * LD + j] = (ya[i] * sab + aa[i] * dab) / d.T[i];
       __syncthreads();
       double dn = 0.0;
 #pragma unroll

@@ -56,29 +56,28 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
       en /= (-k * sc);
       ep /= (k * sc);
     }
-    e_s[m * Q + jj] = en;
-    e_s[m * Q + NP + jj] = ep;
+    // Gp en + Gm ep = [Y (en+ep) - A (en-ep)/k]/T and Gm en + Gp ep = [Y (en+ep) + A (en-ep)/k]/T
+    e_s[m * Q + jj] = en + ep;
+    e_s[m * Q + NP + jj] = (en - ep) / k;
   }
   __syncthreads();
   const bool beam = d.beam != 0;
   const double mu0 = beam ? d.mu0[c] : 1.0;
   double bfac = beam ? exp(-ts / mu0) : 0.0;
   if (antider) bfac /= (-sc / mu0);
-  // u^m_i = sum_j G_ij e_j + B_i exp(-tau*/mu0) (+ v_i for m = 0): NP lanes per (m, i)
+  // u^m_i = sum_j G_ij e_j + B_i exp(-tau*/mu0) (+ v_i for m = 0): NP lanes per (m, stream i); the up- and the
+  // down-stream of a quadrature node share the two row sums  P = Y_i . (en+ep),  Qs = A_i . (en-ep)/k
   const int grp = tid / NP, jj = tid % NP;
   constexpr int NGRP = EVAL_THREADS / NP;
-  for (int item = grp; item < M * Q; item += NGRP) {
-    const int m = item / Q, i2 = item % Q;
-    const bool up = i2 < NP;
-    const int i = up ? i2 : i2 - NP;
+  for (int item = grp; item < M * NP; item += NGRP) {
+    const int m = item / NP, i = item % NP;
     const long ml = ((long)c * M + m) * L + l;
-    const double* gp = d.Gp + (ml * NP + i) * NP;
-    const double* gm = d.Gm + (ml * NP + i) * NP;
-    const double en = e_s[m * Q + jj], ep = e_s[m * Q + NP + jj];
-    double part = up ? (gp[jj] * en + gm[jj] * ep) : (gm[jj] * en + gp[jj] * ep);
-    part = group_reduce<NP>(part);
-    if (jj == 0) {
-      double v = part;
+    const double ps = d.Ym[(ml * NP + i) * NP + jj] * e_s[m * Q + jj];
+    const double qs = d.Am[(ml * NP + i) * NP + jj] * e_s[m * Q + NP + jj];
+    const double P = group_reduce<NP>(ps), Qs = group_reduce<NP>(qs);
+    if (jj < 2) {  // lane 0: up-stream i, lane 1: down-stream i
+      const int i2 = jj == 0 ? i : NP + i;
+      double v = (jj == 0 ? P - Qs : P + Qs) / d.T[i];
       if (beam) v += d.Bv[ml * Q + i2] * bfac;
       if (m == 0 && d.Ns > 0) {  // isotropic-source particular solution (subroutines.py:786-862)
         const double* dq = d.dq + ((long)c * L + l) * d.Ns * Q;
@@ -153,9 +152,9 @@ __global__ void rtd_export_kernel(RtdDev d, int col, double* GC, double* K, doub
     const long mlg = (long)col * M * L + ml;
     const bool rup = ri < N, cneg = cj < N;
     const int i = rup ? ri : ri - N, j = cneg ? cj : cj - N;
-    // G = [[Gp, Gm],[Gm, Gp]]
-    const double* blk = (rup == cneg) ? d.Gp : d.Gm;
-    const double g = blk[(mlg * NP + i) * NP + j];
+    // G = [[Gp, Gm],[Gm, Gp]],  Gp = (Y - A/k)/T,  Gm = (Y + A/k)/T
+    const double yv = d.Ym[(mlg * NP + i) * NP + j], av = d.Am[(mlg * NP + i) * NP + j] / d.kk[mlg * NP + j];
+    const double g = ((rup == cneg) ? yv - av : yv + av) / d.T[i];
     const double cf = d.coef[mlg * Q + (cneg ? j : NP + j)];
     if (G) G[idx] = g;
     if (GC) GC[idx] = g * cf;
