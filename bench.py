@@ -26,12 +26,26 @@ L, NQUAD, NTAU, NPHI = 20, 32, 21, 3
 
 
 def algorithmic_flops():
-    """Per-column algorithmic FLOPs of each stage (F_col = 195 MFLOP for cfg4)."""
+    """Per-column algorithmic FLOPs per kernel (F_col = L[2N^2 P(P+1) + 70.3 N^3 M] = 195 MFLOP
+    for cfg4; per (m, l): assembly 4N^2(P-m), product 2N^3, eigen-decomposition 25N^3, U = (alpha+beta)V/k 2N^3,
+    particular solve 5.33N^3, BC solve 36N^3 per layer)."""
     N, P, M = NQUAD // 2, NQUAD, NQUAD
-    eig = L * (2 * N * N * P * (P + 1) + (2 + 25 + 2 + 5.33) * N**3 * M)
-    bc = L * 36.0 * N**3 * M
-    ev = NTAU * M * (2 * N) * (2 * N) * 2.0
-    return dict(eig=eig, bc=bc, eval=ev, total=eig + bc)
+    ml = L * M
+    fl = dict(asm=L * 2 * N * N * P * (P + 1) + 2 * N**3 * ml, jacobi=25.0 * N**3 * ml, post=(2 + 5.33) * N**3 * ml,
+              bc=36.0 * N**3 * ml, eval=NTAU * M * (2 * N) * (2 * N) * 2.0)
+    fl["total"] = fl["asm"] + fl["jacobi"] + fl["post"] + fl["bc"]
+    return fl
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json;
+    FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as read), or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def shard_columns(rank, world, columns_per_gpu):
@@ -173,9 +187,15 @@ def main():
     if rank == 0:
         fl = algorithmic_flops()
         ms = {k: (v[0] / max(v[1], 1)) for k, v in stage.items()}
-        dom = max(("eig", "bc"), key=lambda k: ms[k])
-        achieved = fl[dom] * C / (ms[dom] * 1e-3) / 1e12
+        ms["bc"] = ms["iface"] + ms["sweep"]
+        dom = max(("asm", "jacobi", "post", "iface", "sweep"), key=lambda k: ms[k])
+        dom_flops = fl["bc"] if dom in ("iface", "sweep") else fl[dom]
+        dom_ms = ms["bc"] if dom in ("iface", "sweep") else ms[dom]
+        kname = {"asm": "rtd_asm_kernel<16>", "jacobi": "rtd_jacobi_kernel<16>", "post": "rtd_post_kernel<16>",
+                 "iface": "rtd_iface_kernel<16>+rtd_sweep_kernel<16>", "sweep": "rtd_iface_kernel<16>+rtd_sweep_kernel<16>"}[dom]
+        achieved = dom_flops * C / (dom_ms * 1e-3) / 1e12
         value = world * C * a.steps / elapsed
+        traffic = measured_traffic(kname.split("+")[-1].split("<")[0]) if C == 2048 else None
         out = {
             "metric": "column-solves/sec (32 streams, 20 layers)", "value": value, "unit": "column-solves/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
@@ -186,13 +206,13 @@ def main():
                        "parallelism": f"column-sharded x{world}", "collective": collective,
                        "max_jacobi_sweeps": sweeps},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
-                         "kernel": {"eig": "rtd_asm/jacobi/post_kernel<16> (eigen stage)",
-                                    "bc": "rtd_bc_kernel<16>"}[dom],
-                         "note": "FP64 path: peak is the MI355X FP64 vector=matrix peak; achieved = algorithmic "
-                                 "FLOPs of the stage (SURVEY 8(d)) x columns / HIP-event time of the stage",
-                         "stage_ms_per_step": ms,
-                         "whole_path_tflops": fl["total"] * C * a.steps / elapsed / 1e12},
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "kernel": kname,
+                         "note": "FP64 path (SURVEY 8(d): compute-bound, not HBM-bound): peak = MI355X FP64 vector = matrix "
+                                 "peak; achieved = algorithmic FLOPs of the kernel x columns / its HIP-event duration; "
+                                 "traffic = measured HBM bytes per launch of that kernel (profiles/r01_pmc_traffic.json)",
+                         "kernel_ms_per_step": ms,
+                         "whole_path_tflops": fl["total"] * C * a.steps / elapsed / 1e12,
+                         "whole_path_frac": fl["total"] * C * a.steps / elapsed / 1e12 / FP64_PEAK_TFLOPS},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -62,10 +62,11 @@ struct rtd_plan {
   int64_t cap_gathered = 0;
   // timing
   bool timing = false;
-  hipEvent_t evt[6] = {};
-  double ms[4] = {0, 0, 0, 0};
-  int64_t nlaunch[4] = {0, 0, 0, 0};
-  bool pending[4] = {false, false, false, false};
+  static constexpr int NT = 7;  // timed kernels: tables, asm, jacobi, post, iface, sweep, eval
+  hipEvent_t evt[NT + 1] = {};
+  double ms[NT] = {};
+  int64_t nlaunch[NT] = {};
+  bool pending[NT] = {};
 
   template <typename T>
   int alloc(T** p, int64_t n) {
@@ -100,7 +101,7 @@ int grow(rtd_plan* p, double** buf, int64_t* cap, int64_t need) {
 
 // collect timing of stage `k` if an event pair is pending
 void harvest(rtd_plan* p) {
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < rtd_plan::NT; ++k) {
     if (!p->pending[k]) continue;
     float t = 0.f;
     if (hipEventElapsedTime(&t, p->evt[k], p->evt[k + 1]) == hipSuccess) {
@@ -118,21 +119,30 @@ int launch_solve(rtd_plan* p, bool with_eval, const RtdEval* ev) {
     harvest(p);
   }
   const bool tm = p->timing;
-  if (tm) (void)hipEventRecord(p->evt[0], s);
+  auto mark = [&](int k) {
+    if (tm) (void)hipEventRecord(p->evt[k], s);
+  };
+  mark(0);
   (void)hipMemsetAsync(p->d.sweeps, 0, sizeof(int), s);
   rtd_launch_tables(p->d, s);
-  if (tm) (void)hipEventRecord(p->evt[1], s);
-  rtd_launch_eig(p->d, s);
-  if (tm) (void)hipEventRecord(p->evt[2], s);
-  rtd_launch_bc(p->d, s);
-  if (tm) (void)hipEventRecord(p->evt[3], s);
+  mark(1);
+  rtd_launch_eig(p->d, s, 0);
+  mark(2);
+  rtd_launch_eig(p->d, s, 1);
+  mark(3);
+  rtd_launch_eig(p->d, s, 2);
+  mark(4);
+  rtd_launch_bc(p->d, s, 0);
+  mark(5);
+  rtd_launch_bc(p->d, s, 1);
+  mark(6);
   if (with_eval) {
     rtd_launch_eval(p->d, *ev, s);
-    if (tm) (void)hipEventRecord(p->evt[4], s);
+    mark(7);
   }
   if (tm) {
-    p->pending[0] = p->pending[1] = p->pending[2] = true;
-    p->pending[3] = with_eval;
+    for (int k = 0; k < 6; ++k) p->pending[k] = true;
+    p->pending[6] = with_eval;
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -405,7 +415,7 @@ int rtd_plan_evaluate(rtd_plan* p, int32_t ntau, const double* tau, int32_t nphi
   if (p->timing) {
     (void)hipStreamSynchronize(p->stream);
     harvest(p);
-    (void)hipEventRecord(p->evt[3], p->stream);
+    (void)hipEventRecord(p->evt[6], p->stream);
   }
   rtd_launch_eval(p->d, e, p->stream);
   if (p->have_nt && !skip_nt && e.u != nullptr) {
@@ -416,8 +426,8 @@ int rtd_plan_evaluate(rtd_plan* p, int32_t ntau, const double* tau, int32_t nphi
     rtd_launch_nt_apply(p->d, p->nt, e, p->stream);
   }
   if (p->timing) {
-    (void)hipEventRecord(p->evt[4], p->stream);
-    p->pending[3] = true;
+    (void)hipEventRecord(p->evt[7], p->stream);
+    p->pending[6] = true;
   }
   hipError_t er = hipGetLastError();
   if (er != hipSuccess) return fail(RTD_ERR_HIP, std::string("eval launch: ") + hipGetErrorString(er));
@@ -488,11 +498,11 @@ int rtd_plan_enable_timing(rtd_plan* p, int32_t enable) {
   return 0;
 }
 
-int rtd_plan_get_timing(rtd_plan* p, double ms[4], int64_t nlaunch[4], int32_t reset) {
+int rtd_plan_get_timing(rtd_plan* p, double ms[7], int64_t nlaunch[7], int32_t reset) {
   if (!p) return fail(RTD_ERR_ARG, "null plan");
   HIP_TRY(hipStreamSynchronize(p->stream));
   harvest(p);
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < rtd_plan::NT; ++k) {
     if (ms) ms[k] = p->ms[k];
     if (nlaunch) nlaunch[k] = p->nlaunch[k];
     if (reset) {

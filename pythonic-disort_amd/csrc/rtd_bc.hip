@@ -441,15 +441,16 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_SWEEP_WAVES : 1)) void rtd_swee
 
 }  // namespace
 
-void rtd_launch_bc(const RtdDev& d, hipStream_t s) {
+void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
+  // part 0: interface operators (all interfaces in parallel), 1: carry recursion / bottom BC / backward sweep
   const int gpw = 64 / d.NP;
   const long nif = (long)d.C * d.M * (d.L - 1);
   const dim3 gi((unsigned)((nif + gpw - 1) / gpw));
   const dim3 gs((unsigned)(((long)d.C * d.M + gpw - 1) / gpw));
-#define RTD_BC_CASE(NPV)                                                               \
-  case NPV:                                                                            \
-    if (nif > 0) hipLaunchKernelGGL(rtd_iface_kernel<NPV>, gi, dim3(64), 0, s, d);     \
-    hipLaunchKernelGGL(rtd_sweep_kernel<NPV>, gs, dim3(64), 0, s, d);                  \
+#define RTD_BC_CASE(NPV)                                                                             \
+  case NPV:                                                                                          \
+    if (part == 0 && nif > 0) hipLaunchKernelGGL(rtd_iface_kernel<NPV>, gi, dim3(64), 0, s, d);      \
+    if (part == 1) hipLaunchKernelGGL(rtd_sweep_kernel<NPV>, gs, dim3(64), 0, s, d);                 \
     break;
   switch (d.NP) {
     RTD_BC_CASE(4)

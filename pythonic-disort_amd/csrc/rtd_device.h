@@ -58,8 +58,8 @@ struct RtdNt {
 
 // launchers (one per translation unit)
 void rtd_launch_tables(const RtdDev& d, hipStream_t s);
-void rtd_launch_eig(const RtdDev& d, hipStream_t s);
-void rtd_launch_bc(const RtdDev& d, hipStream_t s);
+void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part);  // 0 asm, 1 jacobi, 2 post
+void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part);   // 0 iface, 1 sweep
 void rtd_launch_eval(const RtdDev& d, const RtdEval& e, hipStream_t s);
 void rtd_launch_nt_tables(const RtdDev& d, const RtdNt& nt, hipStream_t s);
 void rtd_launch_nt_apply(const RtdDev& d, const RtdNt& nt, const RtdEval& e, hipStream_t s);

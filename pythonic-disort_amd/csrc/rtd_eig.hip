@@ -526,15 +526,16 @@ void rtd_launch_tables(const RtdDev& d, hipStream_t s) {
   }
 }
 
-void rtd_launch_eig(const RtdDev& d, hipStream_t s) {
+void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part) {
+  // part 0: assembly + Cholesky + F, 1: Jacobi, 2: eigenvector blocks / particular solutions
   const long nprob = (long)d.C * d.M * d.L;
   const int gpw = 64 / d.NP;
   const dim3 grid((unsigned)((nprob + gpw - 1) / gpw));
-#define RTD_EIG_CASE(NPV)                                                        \
-  case NPV:                                                                      \
-    hipLaunchKernelGGL(rtd_asm_kernel<NPV>, grid, dim3(64), 0, s, d);            \
-    hipLaunchKernelGGL(rtd_jacobi_kernel<NPV>, grid, dim3(64), 0, s, d);         \
-    hipLaunchKernelGGL(rtd_post_kernel<NPV>, grid, dim3(64), 0, s, d);           \
+#define RTD_EIG_CASE(NPV)                                                                       \
+  case NPV:                                                                                     \
+    if (part == 0) hipLaunchKernelGGL(rtd_asm_kernel<NPV>, grid, dim3(64), 0, s, d);            \
+    if (part == 1) hipLaunchKernelGGL(rtd_jacobi_kernel<NPV>, grid, dim3(64), 0, s, d);         \
+    if (part == 2) hipLaunchKernelGGL(rtd_post_kernel<NPV>, grid, dim3(64), 0, s, d);           \
     break;
   switch (d.NP) {
     RTD_EIG_CASE(4)

@@ -146,10 +146,10 @@ class Plan:
         _lib.check(self._lib.rtd_plan_enable_timing(self._h, int(on)))
 
     def timing(self, reset=True):
-        ms = (C.c_double * 4)()
-        n = (C.c_int64 * 4)()
+        ms = (C.c_double * 7)()
+        n = (C.c_int64 * 7)()
         _lib.check(self._lib.rtd_plan_get_timing(self._h, ms, n, int(reset)))
-        names = ("tables", "eig", "bc", "eval")
+        names = ("tables", "asm", "jacobi", "post", "iface", "sweep", "eval")
         return {k: (ms[i], n[i]) for i, k in enumerate(names)}
 
     def max_sweeps(self):
