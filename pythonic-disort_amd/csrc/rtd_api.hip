@@ -6,7 +6,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <utility>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/rtd.h"
@@ -34,6 +37,72 @@ int pad_pow2(int n) {
   return p;
 }
 
+// Device-buffer and stream pool (SURVEY section 8(b) "threading": the library owns only device scratch, pooled and
+// guarded by a mutex).  One-column pydisort() calls create and destroy a plan per call; recycling small arenas and
+// streams removes the hipMalloc/hipFree/hipStreamCreate cost (milliseconds) from that path.
+struct DevPool {
+  struct Block { void* p; size_t bytes; int dev; };
+  std::mutex m;
+  std::vector<Block> free_blocks;
+  std::vector<std::pair<hipStream_t, int>> free_streams;
+  size_t cached = 0;
+  static constexpr size_t MAX_BLOCK = 64u << 20, MAX_CACHED = 512u << 20;
+
+  void* get(size_t bytes, int dev, size_t* got) {
+    std::lock_guard<std::mutex> g(m);
+    int best = -1;
+    for (int i = 0; i < (int)free_blocks.size(); ++i) {
+      const Block& b = free_blocks[i];
+      if (b.dev == dev && b.bytes >= bytes && b.bytes <= 4 * bytes + 4096 &&
+          (best < 0 || b.bytes < free_blocks[best].bytes))
+        best = i;
+    }
+    if (best < 0) return nullptr;
+    Block b = free_blocks[best];
+    free_blocks.erase(free_blocks.begin() + best);
+    cached -= b.bytes;
+    *got = b.bytes;
+    return b.p;
+  }
+  bool put(void* p, size_t bytes, int dev) {
+    std::lock_guard<std::mutex> g(m);
+    if (bytes > MAX_BLOCK || cached + bytes > MAX_CACHED) return false;
+    free_blocks.push_back({p, bytes, dev});
+    cached += bytes;
+    return true;
+  }
+  hipStream_t get_stream(int dev) {
+    std::lock_guard<std::mutex> g(m);
+    for (int i = 0; i < (int)free_streams.size(); ++i)
+      if (free_streams[i].second == dev) {
+        hipStream_t s = free_streams[i].first;
+        free_streams.erase(free_streams.begin() + i);
+        return s;
+      }
+    return nullptr;
+  }
+  void put_stream(hipStream_t s, int dev) {
+    std::lock_guard<std::mutex> g(m);
+    if (free_streams.size() < 16) free_streams.emplace_back(s, dev);
+    else (void)hipStreamDestroy(s);
+  }
+};
+DevPool& pool() {
+  static DevPool* p = new DevPool();  // never destroyed: outlives the HIP runtime teardown order
+  return *p;
+}
+
+// pooled device allocation: returns the block and its true size
+hipError_t pooled_malloc(void** q, size_t bytes, int dev, size_t* got) {
+  *q = pool().get(bytes, dev, got);
+  if (*q) return hipSuccess;
+  *got = bytes;
+  return hipMalloc(q, bytes);
+}
+void pooled_free(void* q, size_t bytes, int dev) {
+  if (!pool().put(q, bytes, dev)) (void)hipFree(q);
+}
+
 }  // namespace
 
 struct rtd_plan {
@@ -43,6 +112,7 @@ struct rtd_plan {
   hipStream_t stream = nullptr;
   RtdDev d{};
   std::vector<void*> allocs;
+  std::vector<size_t> alloc_bytes;
   int64_t bytes = 0;
   bool have_quad = false, have_cols = false, solved = false, tables_ready = false;
   // evaluation buffers (grown on demand)
@@ -72,10 +142,12 @@ struct rtd_plan {
   int alloc(T** p, int64_t n) {
     void* q = nullptr;
     if (n <= 0) n = 1;
-    hipError_t e = hipMalloc(&q, (size_t)n * sizeof(T));
+    size_t got = 0;
+    hipError_t e = pooled_malloc(&q, (size_t)n * sizeof(T), device, &got);
     if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
     allocs.push_back(q);
-    bytes += n * (int64_t)sizeof(T);
+    alloc_bytes.push_back(got);
+    bytes += (int64_t)got;
     *p = (T*)q;
     return 0;
   }
@@ -86,10 +158,12 @@ namespace {
 int grow(rtd_plan* p, double** buf, int64_t* cap, int64_t need) {
   if (need <= *cap) return 0;
   if (*buf) {
-    for (auto& a : p->allocs)
-      if (a == *buf) a = nullptr;
-    (void)hipFree(*buf);
-    p->bytes -= *cap * 8;
+    for (size_t i = 0; i < p->allocs.size(); ++i)
+      if (p->allocs[i] == *buf) {
+        pooled_free(*buf, p->alloc_bytes[i], p->device);
+        p->bytes -= (int64_t)p->alloc_bytes[i];
+        p->allocs[i] = nullptr;
+      }
   }
   *buf = nullptr;
   *cap = 0;
@@ -183,28 +257,57 @@ int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** out) {
   p->dims = *dims;
   p->device = device;
   p->NP = pad_pow2(N);
-  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-  for (auto& e : p->evt) HIP_TRY(hipEventCreate(&e));
+  p->stream = pool().get_stream(device);
+  if (!p->stream) HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   RtdDev& d = p->d;
   const int64_t C = dims->ncols, L = dims->nlayers, M = dims->nfourier, P = dims->nleg, NP = p->NP,
                 Ns = dims->nscoeffs, NB = dims->nbdrf, Q2 = 2 * NP;
   d.C = (int)C; d.L = (int)L; d.N = N; d.NP = (int)NP; d.P = (int)P; d.M = (int)M; d.Ns = (int)Ns;
   d.NBDRF = (int)NB; d.beam = dims->beam ? 1 : 0;
   int rc = 0;
-  double *mu, *w, *invmu, *S, *T, *omega, *tau, *taus0, *scale, *wleg, *mu0, *I0, *phi0, *rescale, *bpos, *bneg,
-      *spoly, *bq, *bq0;
-#define A(ptr, n) if ((rc = p->alloc(&ptr, (n)))) { rtd_plan_destroy(p); return rc; }
-  A(mu, NP) A(w, NP) A(invmu, NP) A(S, NP) A(T, NP)
-  A(d.Y, M * P * NP) A(d.Y0, C * M * P)
-  A(omega, C * L) A(tau, C * L) A(taus0, C * (L + 1)) A(scale, C * L) A(wleg, C * L * P)
-  A(mu0, C) A(I0, C) A(phi0, C) A(rescale, C)
-  A(bpos, C * M * NP) A(bneg, C * M * NP) A(spoly, C * L * Ns) A(bq, C * NB * NP * NP) A(bq0, C * NB * NP)
-  A(d.Ym, C * M * L * NP * NP) A(d.Am, C * M * L * NP * NP) A(d.kk, C * M * L * NP) A(d.Bv, C * M * L * Q2)
-  A(d.dq, C * L * Ns * Q2) A(d.zneg, C * L * NP) A(d.coef, C * M * L * Q2)
-  A(d.Lw, C * M * L * NP * NP) A(d.Qw, C * M * L * NP * NP)
-  A(d.Fws, C * M * (L - 1) * Q2 * Q2) A(d.Ek, C * M * L * NP)
-  A(d.sweeps, 1) A(d.status, 1)
+  double *mu = nullptr, *w = nullptr, *invmu = nullptr, *S = nullptr, *T = nullptr, *omega = nullptr, *tau = nullptr,
+         *taus0 = nullptr, *scale = nullptr, *wleg = nullptr, *mu0 = nullptr, *I0 = nullptr, *phi0 = nullptr,
+         *rescale = nullptr, *bpos = nullptr, *bneg = nullptr, *spoly = nullptr, *bq = nullptr, *bq0 = nullptr;
+  // one arena for every fixed-size buffer (a single hipMalloc keeps plan creation cheap for one-column calls):
+  // pass 0 sizes it, pass 1 carves it
+  char* arena = nullptr;
+  int64_t off = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    off = 0;
+    auto carve = [&](auto** ptr, int64_t n) {
+      using E = std::remove_pointer_t<std::remove_pointer_t<decltype(ptr)>>;
+      if (n <= 0) n = 1;
+      const int64_t bytes = (n * (int64_t)sizeof(E) + 255) / 256 * 256;
+      if (pass == 1) *ptr = reinterpret_cast<E*>(arena + off);
+      off += bytes;
+    };
+#define A(ptr, n) carve(&ptr, (n));
+    A(mu, NP) A(w, NP) A(invmu, NP) A(S, NP) A(T, NP)
+    A(d.Y, M * P * NP) A(d.Y0, C * M * P)
+    A(omega, C * L) A(tau, C * L) A(taus0, C * (L + 1)) A(scale, C * L) A(wleg, C * L * P)
+    A(mu0, C) A(I0, C) A(phi0, C) A(rescale, C)
+    A(bpos, C * M * NP) A(bneg, C * M * NP) A(spoly, C * L * Ns) A(bq, C * NB * NP * NP) A(bq0, C * NB * NP)
+    A(d.Ym, C * M * L * NP * NP) A(d.Am, C * M * L * NP * NP) A(d.kk, C * M * L * NP) A(d.Bv, C * M * L * Q2)
+    A(d.dq, C * L * Ns * Q2) A(d.zneg, C * L * NP) A(d.coef, C * M * L * Q2)
+    A(d.Lw, C * M * L * NP * NP) A(d.Qw, C * M * L * NP * NP)
+    A(d.Fws, C * M * (L - 1) * Q2 * Q2) A(d.Ek, C * M * L * NP)
+    A(d.sweeps, 1) A(d.status, 1)
 #undef A
+    if (pass == 0) {
+      void* q = nullptr;
+      size_t got = 0;
+      hipError_t e = pooled_malloc(&q, (size_t)off, device, &got);
+      if (e != hipSuccess) {
+        rtd_plan_destroy(p);
+        return fail(RTD_ERR_HIP, std::string("hipMalloc of ") + std::to_string(off) + " bytes: " + hipGetErrorString(e));
+      }
+      p->allocs.push_back(q);
+      p->alloc_bytes.push_back(got);
+      p->bytes += (int64_t)got;
+      arena = static_cast<char*>(q);
+    }
+  }
+  (void)rc;
   d.mu = mu; d.w = w; d.invmu = invmu; d.S = S; d.T = T;
   d.omega = omega; d.tau = tau; d.taus0 = taus0; d.scale = scale; d.wleg = wleg;
   d.mu0 = mu0; d.I0 = I0; d.phi0 = phi0; d.rescale = rescale; d.bpos = bpos; d.bneg = bneg;
@@ -223,11 +326,11 @@ int rtd_plan_destroy(rtd_plan* p) {
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   rtd_comm_destroy(p);
-  for (void* a : p->allocs)
-    if (a) (void)hipFree(a);
+  for (size_t i = 0; i < p->allocs.size(); ++i)
+    if (p->allocs[i]) pooled_free(p->allocs[i], p->alloc_bytes[i], p->device);
   for (auto& e : p->evt)
     if (e) (void)hipEventDestroy(e);
-  if (p->stream) (void)hipStreamDestroy(p->stream);
+  if (p->stream) pool().put_stream(p->stream, p->device);
   delete p;
   return 0;
 }
@@ -494,6 +597,10 @@ int rtd_plan_get_tensors(rtd_plan* p, int32_t column, double* GC, double* K, dou
 
 int rtd_plan_enable_timing(rtd_plan* p, int32_t enable) {
   if (!p) return fail(RTD_ERR_ARG, "null plan");
+  if (enable && !p->evt[0]) {
+    HIP_TRY(hipSetDevice(p->device));
+    for (auto& e : p->evt) HIP_TRY(hipEventCreate(&e));
+  }
   p->timing = enable != 0;
   return 0;
 }
