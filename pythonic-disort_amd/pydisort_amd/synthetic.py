@@ -76,3 +76,20 @@ def column_kwargs(cfg, i):
             v = cfg[b]
             kw[b] = v[i] if np.ndim(v) >= 1 else v
     return kw
+
+
+# Legendre moments of the Cloud C.1 phase function used by DISORT Test Problem 5 are 300 numbers of tabulated data
+# (pydisotest/5_test.py:10-45); the BASELINE-literal 32-stream variant below uses a Henyey-Greenstein stand-in with
+# the same asymmetry regime (g = 0.85, 300 moments) so that the case needs no table.
+def literal_cases():
+    """BASELINE.json configs[0] and configs[1] as literally worded (they have no Stamnes file):
+    cfg1_q4  : Test Problem 1a with 4 streams (isotropic scattering, 1 layer);
+    cfg2_q32 : a Test-Problem-5-like single thick layer, 32 streams, 300 moments, delta-M + NT corrections."""
+    k = np.arange(300)
+    cases = {
+        "cfg1_q4": (dict(tau_arr=0.03125, omega_arr=0.2, NQuad=4, Leg_coeffs_all=np.array([1.0, 0, 0, 0, 0]), mu0=0.1,
+                         I0=np.pi / 0.1, phi0=np.pi), np.array([0.0, 0.01, 0.03125])),
+        "cfg2_q32": (dict(tau_arr=64.0, omega_arr=0.9, NQuad=32, Leg_coeffs_all=0.85**k, mu0=1.0, I0=np.pi, phi0=np.pi,
+                          f_arr=0.85**32, NT_cor=True), np.array([0.0, 3.2, 32.0, 64.0])),
+    }
+    return cases

@@ -58,7 +58,21 @@ def run(name, cfg, ncol):
     np.savez_compressed(os.path.join(HERE, "synth", name + ".npz"), **out)
 
 
+def run_single(name, kw, tau_pts):
+    """One reference call -> inputs are re-created by the test from `literal_cases()` below."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mu_arr, Fp, Fm, u0, u = PythonicDISORT.pydisort(**kw)
+    out = {"tau_pts": tau_pts, "phi": PHI, "u": u(tau_pts, PHI), "u0": u0(tau_pts), "flux_up": Fp(tau_pts)}
+    out["flux_down_diffuse"], out["flux_down_direct"] = Fm(tau_pts)
+    os.makedirs(os.path.join(HERE, "synth"), exist_ok=True)
+    np.savez_compressed(os.path.join(HERE, "synth", name + ".npz"), **out)
+    print(name, "done", flush=True)
+
+
 if __name__ == "__main__":
+    for name, (kw, tau_pts) in synthetic.literal_cases().items():
+        run_single(name, kw, tau_pts)
     run("cfg4", synthetic.cfg4_columns(16), 16)
     run("cfg3_big", synthetic.cfg3_columns(4, big=True), 4)
     run("cfg3_small", synthetic.cfg3_columns(4, big=False), 4)

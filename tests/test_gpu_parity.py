@@ -238,3 +238,21 @@ def test_batch_nt_corrections_match_single_column_reference_path(amd):
             warnings.simplefilter("ignore")
             got1 = amd.pydisort(NT_cor=True, **kw)[4](tau[i], phi)
         assert np.max(np.abs(got1 - u[i])) / np.max(np.abs(want)) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["cfg1_q4", "cfg2_q32"])
+def test_baseline_literal_configs(amd, name):
+    """BASELINE.json configs[0]/[1] as literally worded (4-stream TP1, 32-stream TP5-like with NT): reference goldens."""
+    from pydisort_amd import synthetic
+    kw, tau_pts = synthetic.literal_cases()[name]
+    z = np.load(f"{goldens.HERE}/golden/synth/{name}.npz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mu_arr, Fp, Fm, u0, u = amd.pydisort(**kw)
+    scale = np.max(np.abs(z["u"]))
+    assert np.max(np.abs(u(tau_pts, z["phi"]) - z["u"])) / scale < TOL
+    assert np.max(np.abs(u0(tau_pts) - z["u0"])) / scale < TOL
+    assert np.allclose(Fp(tau_pts), z["flux_up"], rtol=1e-9, atol=1e-12 * scale)
+    fd = Fm(tau_pts)
+    assert np.allclose(fd[0], z["flux_down_diffuse"], rtol=1e-9, atol=1e-11 * scale)
+    assert np.allclose(fd[1], z["flux_down_direct"], rtol=1e-12, atol=1e-300)

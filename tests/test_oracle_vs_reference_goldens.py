@@ -36,3 +36,16 @@ def test_oracle_matches_reference(test_id):
     tol = 1e-7 if test_id in ILL_CONDITIONED else 1e-10
     for call in goldens.load(test_id):
         assert replay(call, O.pydisort) < tol
+
+
+@pytest.mark.parametrize("name", ["cfg1_q4", "cfg2_q32"])
+def test_oracle_on_baseline_literal_configs(name):
+    """BASELINE.json configs[0] (TP1 with 4 streams: the CPU plumbing case) and configs[1] (32-stream TP5-like)."""
+    import os
+    from pydisort_amd import synthetic
+    kw, tau_pts = synthetic.literal_cases()[name]
+    z = np.load(os.path.join(goldens.HERE, "golden", "synth", name + ".npz"))
+    mu_arr, Fp, Fm, u0, u = O.pydisort(**kw)
+    scale = np.max(np.abs(z["u"]))
+    assert np.max(np.abs(u(tau_pts, z["phi"]) - z["u"])) / scale < 1e-10
+    assert np.allclose(Fp(tau_pts), z["flux_up"], rtol=1e-10, atol=1e-13 * scale)
