@@ -14,6 +14,8 @@
 // Jacobi iteration.  One problem occupies NP lanes of a wavefront (64/NP problems per wave); lane j
 // owns column j of every matrix in registers; columns are exchanged with cross-lane swizzles,
 // rotation parameters and small vectors through LDS.
+#include <type_traits>
+
 #include "rtd_device.h"
 
 namespace {
@@ -111,29 +113,61 @@ __device__ __forceinline__ double group_sum(double v) {
   return v;
 }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+// value of lane K of this lane's NP-group, K a compile-time constant: a DPP row broadcast (VALU, no LDS crossbar)
+// when the group is one 16-lane DPP row, a ds_bpermute otherwise
+template <int NP, int K>
+__device__ __forceinline__ double bcast_lane(double v) {
+  if constexpr (NP == 16) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xF, 0xF, false);  // row_newbcast:K
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+  } else {
+    return __shfl(v, K, NP);
+  }
+}
+
 // In-register Cholesky of a symmetric positive definite matrix held one column per lane (col[i] = A[i][j]);
 // on exit col[i] = L[i][j] for i >= j and 0 above the diagonal.  The trailing matrix is kept symmetric so
-// that L[j][k] is available in the lane's own registers.
+// that L[j][k] is available in the lane's own registers; the updates are branch-free.
+template <int NP, int K>
+struct CholStep {
+  static __device__ __forceinline__ void run(double (&col)[NP], const int j) {
+    const double akk = bcast_lane<NP, K>(col[K]);
+    const double rinv = fast_rsqrt(akk);
+    const double ljk = (j > K) ? col[K] * rinv : 0.0;  // L[j][K] by symmetry; 0 freezes the finished columns
+    const bool own = (j == K);
+#pragma unroll
+    for (int i = K + 1; i < NP; ++i) {
+      const double lik = bcast_lane<NP, K>(col[i]) * rinv;
+      const double upd = col[i] - lik * ljk;
+      col[i] = own ? lik : upd;
+    }
+    col[K] = own ? akk * rinv : col[K];
+    CholStep<NP, K + 1>::run(col, j);
+  }
+};
+template <int NP>
+struct CholStep<NP, NP> {
+  static __device__ __forceinline__ void run(double (&)[NP], const int) {}
+};
 template <int NP>
 __device__ __forceinline__ void cholesky_columns(double (&col)[NP], const int j) {
-#pragma unroll
-  for (int k = 0; k < NP; ++k) {
-    const double akk = __shfl(col[k], k, NP);
-    const double rinv = 1.0 / sqrt(akk);
-    const double ljk = col[k] * rinv;  // L[j][k] by symmetry (meaningful for j > k)
-#pragma unroll
-    for (int i = k + 1; i < NP; ++i) {
-      const double lik = __shfl(col[i], k, NP) * rinv;
-      if (j > k) col[i] -= lik * ljk;
-      if (j == k) col[i] = lik;
-    }
-    if (j == k) col[k] = akk * rinv;
-  }
+  CholStep<NP, 0>::run(col, j);
 #pragma unroll
   for (int i = 0; i < NP; ++i) col[i] = (i >= j) ? col[i] : 0.0;
 }
 
-// problem index of this lane's group; invalid groups redo the last problem and skip their stores
+// problem index of this lane's group; invalid groups redo the last layer and skip their stores
 struct ProbId {
   long pid;
   int c, m, l;
@@ -141,15 +175,19 @@ struct ProbId {
 };
 template <int NP>
 __device__ __forceinline__ ProbId locate(const RtdDev& d) {
+  // One wavefront = the 64/NP consecutive layers of ONE (column, mode): c and m depend on blockIdx only, so
+  // they are wave-uniform and the Legendre-table reads (indexed by m and l only) become scalar loads.
   constexpr int GPW = 64 / NP;
-  const long nprob = (long)d.C * d.M * d.L;
+  const int nchunk = (d.L + GPW - 1) / GPW;
+  const long cmi = (long)blockIdx.x / nchunk;
+  const int chunk = (int)((long)blockIdx.x % nchunk);
   ProbId p;
-  p.pid = (long)blockIdx.x * GPW + threadIdx.x / NP;
-  p.valid = p.pid < nprob;
-  if (!p.valid) p.pid = nprob - 1;
-  p.l = (int)(p.pid % d.L);
-  p.m = (int)((p.pid / d.L) % d.M);
-  p.c = (int)(p.pid / ((long)d.L * d.M));
+  p.m = (int)(cmi % d.M);
+  p.c = (int)(cmi / d.M);
+  p.l = chunk * GPW + (int)(threadIdx.x / NP);
+  p.valid = p.l < d.L;
+  if (!p.valid) p.l = d.L - 1;  // redo the last layer, skip the stores
+  p.pid = cmi * d.L + p.l;
   return p;
 }
 
@@ -350,12 +388,12 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
     const bool act = (m == 0);
     // q = L^-1 (T / mu) by forward substitution distributed over the lanes
     double cur = T_j * invmu_j, q_j = 0.0;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const double qi = __shfl(cur, i, NP) / L_[i * LD + i];
-      if (j == i) q_j = qi;
-      if (j > i) cur -= L_[j * LD + i] * qi;
-    }
+    static_for<0, NP>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const double qi = bcast_lane<NP, i>(cur) / L_[i * LD + i];
+      q_j = (j == i) ? qi : q_j;
+      cur -= (j > i) ? L_[j * LD + i] * qi : 0.0;
+    });
     v0[j] = q_j;
     __syncthreads();
     double zn = 0.0;  // zneg_j = -k_j/2 sum_i Z[i][j] q[i]
@@ -449,12 +487,12 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
     for (int r = 0; r < NP; ++r) e += R_[j * LD + r];
     // shat = L^-T e by back substitution distributed over the lanes
     double sh = 0.0;
-#pragma unroll
-    for (int i = NP - 1; i >= 0; --i) {
-      const double si = __shfl(e, i, NP) / L_[i * LD + i];
-      if (j == i) sh = si;
-      if (j < i) e -= L_[i * LD + j] * si;
-    }
+    static_for<0, NP>([&](auto ic) {
+      constexpr int i = NP - 1 - decltype(ic)::value;
+      const double si = bcast_lane<NP, i>(e) / L_[i * LD + i];
+      sh = (j == i) ? si : sh;
+      e -= (j < i) ? L_[i * LD + j] * si : 0.0;
+    });
     v1[j] = sh;
     __syncthreads();
     double tv = 0.0;  // t = L^T shat
@@ -528,9 +566,8 @@ void rtd_launch_tables(const RtdDev& d, hipStream_t s) {
 
 void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part) {
   // part 0: assembly + Cholesky + F, 1: Jacobi, 2: eigenvector blocks / particular solutions
-  const long nprob = (long)d.C * d.M * d.L;
   const int gpw = 64 / d.NP;
-  const dim3 grid((unsigned)((nprob + gpw - 1) / gpw));
+  const dim3 grid((unsigned)((long)d.C * d.M * ((d.L + gpw - 1) / gpw)));
 #define RTD_EIG_CASE(NPV)                                                                       \
   case NPV:                                                                                     \
     if (part == 0) hipLaunchKernelGGL(rtd_asm_kernel<NPV>, grid, dim3(64), 0, s, d);            \
