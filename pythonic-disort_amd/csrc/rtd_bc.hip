@@ -21,6 +21,8 @@
 // Two kernels: rtd_iface_kernel (all (column, mode, interface) in parallel: Wp, Wq, rho) and
 // rtd_sweep_kernel (per (column, mode): forward carry recursion, bottom boundary, backward sweep).
 // NP lanes per problem, 64/NP problems per wavefront; lane i owns row i of the carry system.
+#include <type_traits>
+
 #include "rtd_device.h"
 
 namespace {
@@ -84,6 +86,24 @@ __device__ __forceinline__ double fast_rcp(double x) {
 __device__ __forceinline__ double bperm(int addr, double v) {
   const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
   const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+// value of lane K (compile-time) of this lane's 16-lane group: DPP row broadcast, VALU only
+template <int K>
+__device__ __forceinline__ double bcast16(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xF, 0xF, false);  // row_newbcast:K
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
 
@@ -417,25 +437,57 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_SWEEP_WAVES : 1)) void rtd_swee
     }
   }
   // ---- backward sweep: C+_l = Wq C-' + Wp E' C+' + rho_b ;  C-_l = s - S C+_l
-  for (int l = Lm1 - 1; l >= 0; --l) {
-    const double* ws = wsb + (long)l * Ws<NP>::SLOT;
-    double cp = ws[Ws<NP>::RB + j];
-#pragma unroll 4
-    for (int k = 0; k < NP; ++k)
-      cp += ws[Ws<NP>::WQ + j * NP + k] * v2[k] + ws[Ws<NP>::WP + j * NP + k] * (Ek[(l + 1) * NP + k] * v1[k]);
-    v3[j] = cp;
-    __syncthreads();
-    double cmin = ws[Ws<NP>::SV + j];
-#pragma unroll 4
-    for (int k = 0; k < NP; ++k) cmin -= ws[Ws<NP>::S + j * NP + k] * v3[k];
-    __syncthreads();
-    v1[j] = cp;
-    v2[j] = cmin;
-    if (valid) {
-      coef[(long)l * Q + j] = cmin;
-      coef[(long)l * Q + NP + j] = cp;
+  if constexpr (NP == 16) {
+    // lane j keeps C-_l[j], C+_l[j]; the other lanes' values arrive by DPP row broadcasts (no LDS, no barriers)
+    double cmj = v2[j], cpj = v1[j];
+    for (int l = Lm1 - 1; l >= 0; --l) {
+      const double* ws = wsb + (long)l * Ws<NP>::SLOT;
+      double wq[NP], wp[NP], sr[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        wq[k] = ws[Ws<NP>::WQ + j * NP + k];
+        wp[k] = ws[Ws<NP>::WP + j * NP + k];
+        sr[k] = ws[Ws<NP>::S + j * NP + k];
+      }
+      double cp = ws[Ws<NP>::RB + j];
+      double cmin = ws[Ws<NP>::SV + j];
+      const double ecp = Ek[(l + 1) * NP + j] * cpj;  // E'_j C+'_j
+      static_for<0, NP>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        cp += wq[k] * bcast16<k>(cmj) + wp[k] * bcast16<k>(ecp);
+      });
+      static_for<0, NP>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        cmin -= sr[k] * bcast16<k>(cp);
+      });
+      cmj = cmin;
+      cpj = cp;
+      if (valid) {
+        coef[(long)l * Q + j] = cmin;
+        coef[(long)l * Q + NP + j] = cp;
+      }
     }
-    __syncthreads();
+  } else {
+    for (int l = Lm1 - 1; l >= 0; --l) {
+      const double* ws = wsb + (long)l * Ws<NP>::SLOT;
+      double cp = ws[Ws<NP>::RB + j];
+#pragma unroll 4
+      for (int k = 0; k < NP; ++k)
+        cp += ws[Ws<NP>::WQ + j * NP + k] * v2[k] + ws[Ws<NP>::WP + j * NP + k] * (Ek[(l + 1) * NP + k] * v1[k]);
+      v3[j] = cp;
+      __syncthreads();
+      double cmin = ws[Ws<NP>::SV + j];
+#pragma unroll 4
+      for (int k = 0; k < NP; ++k) cmin -= ws[Ws<NP>::S + j * NP + k] * v3[k];
+      __syncthreads();
+      v1[j] = cp;
+      v2[j] = cmin;
+      if (valid) {
+        coef[(long)l * Q + j] = cmin;
+        coef[(long)l * Q + NP + j] = cp;
+      }
+      __syncthreads();
+    }
   }
 }
 
