@@ -289,7 +289,7 @@ int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** out) {
     A(bpos, C * M * NP) A(bneg, C * M * NP) A(spoly, C * L * Ns) A(bq, C * NB * NP * NP) A(bq0, C * NB * NP)
     A(d.Ym, C * M * L * NP * NP) A(d.Am, C * M * L * NP * NP) A(d.kk, C * M * L * NP) A(d.Bv, C * M * L * Q2)
     A(d.dq, C * L * Ns * Q2) A(d.zneg, C * L * NP) A(d.coef, C * M * L * Q2)
-    A(d.Lw, C * M * L * NP * NP) A(d.Qw, C * M * L * NP * NP)
+    A(d.Lw, NP == 32 ? C * M * L * NP * NP : 1) A(d.Qw, NP == 32 ? C * M * L * NP * NP : 1)  // 3-kernel eigen path only
     A(d.Fws, C * M * (L - 1) * Q2 * Q2) A(d.Ek, C * M * L * NP)
     A(d.sweeps, 1) A(d.status, 1)
 #undef A

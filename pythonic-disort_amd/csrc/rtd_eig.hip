@@ -513,6 +513,272 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused eigen stage (NP <= 16): assembly, Cholesky factors, one-sided Jacobi and the eigenvector /
+// particular-solution stage in ONE kernel per (c, m, l).  F, L, Qm and k Z never leave the CU (registers + LDS):
+// compared with the three-kernel pipeline this removes 10.6 KB of HBM traffic per problem (a third of the path's
+// total) and the Lw / Qw workspaces.
+// ------------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(64, 2) void rtd_eigen_kernel(RtdDev d) {
+  constexpr int GPW = 64 / NP;
+  constexpr int LD = NP + 1;
+  __shared__ double sL[GPW][NP * LD];  // Cholesky factor L of Pm
+  __shared__ double sQ[GPW][NP * LD];  // Qm, later scratch for cross-lane reductions
+  __shared__ double sV[GPW][3][NP];
+  const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
+  const ProbId id = locate<NP>(d);
+  const int P = d.P, m = id.m, c = id.c, l = id.l;
+  const bool valid = id.valid;
+  const long base = id.pid;
+  double* L_ = sL[grp];
+  double* Q_ = sQ[grp];
+  double* R_ = Q_;  // the beam stage is done with Qm before it needs scratch; the thermal stage runs after it
+  double* v0 = sV[grp][0];
+  double* v1 = sV[grp][1];
+  double* v2 = sV[grp][2];
+  const double* wl = d.wleg + ((long)c * d.L + l) * P;
+  const double om = d.omega[(long)c * d.L + l];
+  const double* Ym = d.Y + (long)m * P * NP;
+
+  // D+/D- split by parity of (l - m): Ae = 2 sum_even c_l Y_l Y_l^T, Ao likewise (:123-125)
+  double acc_e[NP], acc_o[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) acc_e[i] = acc_o[i] = 0.0;
+  double cmax = 0.0;
+  for (int ell = m; ell < P; ell += 2) {
+    {
+      const double cl = 0.5 * om * wl[ell];
+      cmax = fmax(cmax, fabs(cl));
+      const double* Yr = Ym + (long)ell * NP;
+      const double coef = 2.0 * cl * Yr[j];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) acc_e[i] += coef * Yr[i];
+    }
+    if (ell + 1 < P) {
+      const double cl = 0.5 * om * wl[ell + 1];
+      cmax = fmax(cmax, fabs(cl));
+      const double* Yr = Ym + (long)(ell + 1) * NP;
+      const double coef = 2.0 * cl * Yr[j];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) acc_o[i] += coef * Yr[i];
+    }
+  }
+  // "shortcut" of the reference when multiple scattering is insignificant (:119, :162-168): the layer
+  // is treated as non-scattering; the general path then gives G = [[0,D],[D,0]], k = 1/mu, B = 0.
+  if (!(cmax > 1e-8)) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) acc_e[i] = acc_o[i] = 0.0;
+  }
+  const double invmu_j = d.invmu[j], S_j = d.S[j], T_j = d.T[j];
+  double w[NP];  // column j of F = L^T R, then of k Z
+  {
+    double pcol[NP], qcol[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const double Si = d.S[i];
+      pcol[i] = (i == j ? invmu_j : 0.0) - Si * acc_e[i] * S_j;  // Pm = M^-1 - S Ae S
+      qcol[i] = (i == j ? invmu_j : 0.0) - Si * acc_o[i] * S_j;  // Qm = M^-1 - S Ao S
+      Q_[i * LD + j] = qcol[i];
+    }
+    cholesky_columns<NP>(pcol, j);  // Pm = L L^T
+    cholesky_columns<NP>(qcol, j);  // Qm = R R^T
+#pragma unroll
+    for (int i = 0; i < NP; ++i) L_[i * LD + j] = pcol[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      double a = 0.0;
+#pragma unroll
+      for (int r = i; r < NP; ++r) a += L_[r * LD + i] * qcol[r];
+      w[i] = a;
+    }
+  }
+  // one-sided Jacobi on the columns of F
+  int nsweep = 0;
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    int notconv = 0;
+    double alpha = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) alpha += w[i] * w[i];
+    JacobiStep<NP, 1>::run(w, alpha, j, notconv);
+    ++nsweep;
+    if (!__any(notconv)) break;
+  }
+  if (threadIdx.x == 0 && nsweep > *(volatile int*)d.sweeps) atomicMax(d.sweeps, nsweep);
+  double k2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) k2 += w[i] * w[i];
+  const double kj = sqrt(k2);
+  double zc[NP];
+  {
+    const double rk0 = 1.0 / kj;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) zc[i] = w[i] * rk0;
+  }
+
+  // eigenvector blocks (:190-198): V = T^-1 L^-T Z, U = (alpha+beta) V / k = -T^-1 L Z / k; stored as
+  // Y = L^-T Z and A = L Z, from which Gp = (Y - A/k)/T, Gm = (Y + A/k)/T, V^-1 = A^T T, U^-1 = -k Y^T T
+  double ya[NP], aa[NP];
+#pragma unroll
+  for (int i = NP - 1; i >= 0; --i) {
+    double a = zc[i];
+#pragma unroll
+    for (int r = i + 1; r < NP; ++r) a -= L_[r * LD + i] * ya[r];
+    ya[i] = a / L_[i * LD + i];
+    RTD_FENCE();
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    double a = 0.0;
+#pragma unroll
+    for (int r = 0; r <= i; ++r) a += L_[i * LD + r] * zc[r];
+    aa[i] = a;
+    RTD_FENCE();
+  }
+  if (valid) {
+    double* Ym = d.Ym + base * NP * NP;
+    double* Am = d.Am + base * NP * NP;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      Ym[i * NP + j] = ya[i];
+      Am[i * NP + j] = aa[i];
+    }
+    d.kk[base * NP + j] = kj;
+    const double* ts0 = d.taus0 + (long)c * (d.L + 1);
+    d.Ek[base * NP + j] = exp(-kj * (ts0[l + 1] - ts0[l]));
+  }
+
+  // beam particular solution (:143-152, :226-231) through the spectral decomposition:
+  //  s = B+ + B-, dd = B+ - B- ;  (I/mu0^2 - Qm Pm) T s = T(x+ + x-)/mu0 - Qm T (x+ - x-)
+  //  T dd = mu0 [ T (x+ - x-) - Pm T s ],  Qm Pm = L^-T Z k^2 Z^T L^T
+  if (d.beam) {
+    const double mu0 = d.mu0[c];
+    const double fac = d.I0[c] / (4.0 * M_PI) * (m == 0 ? 1.0 : 2.0) * om;
+    const double* Y0 = d.Y0 + ((long)c * d.M + m) * P;
+    double xe = 0.0, xo = 0.0, cmax = 0.0;  // X^e_j, X^o_j of this lane's stream
+    for (int ell = m; ell < P; ell += 2) {
+      cmax = fmax(cmax, fabs(0.5 * om * wl[ell]));
+      xe += fac * wl[ell] * Y0[ell] * Ym[(long)ell * NP + j];
+      if (ell + 1 < P) {
+        cmax = fmax(cmax, fabs(0.5 * om * wl[ell + 1]));
+        xo += fac * wl[ell + 1] * Y0[ell + 1] * Ym[(long)(ell + 1) * NP + j];
+      }
+    }
+    if (!(cmax > 1e-8)) xe = xo = 0.0;
+    const double txd = 2.0 * T_j * xe * invmu_j;  // T (x+ - x-)
+    v0[j] = txd;
+    __syncthreads();
+    double qv = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) qv += Q_[i * LD + j] * v0[i];
+    const double rhat = 2.0 * T_j * xo * invmu_j / mu0 - qv;
+    v1[j] = rhat;
+    __syncthreads();
+    double g = 0.0;  // g = L^T rhat
+#pragma unroll
+    for (int r = 0; r < NP; ++r) g += L_[r * LD + j] * v1[r];
+    v2[j] = g;
+    __syncthreads();
+    double h = 0.0;  // h = Z^T g / (1/mu0^2 - k^2)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) h += zc[i] * v2[i];
+    h /= (1.0 / (mu0 * mu0) - k2);
+    // e = Z h (cross-lane sum through LDS)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) R_[i * LD + j] = zc[i] * h;
+    __syncthreads();
+    double e = 0.0;
+#pragma unroll
+    for (int r = 0; r < NP; ++r) e += R_[j * LD + r];
+    // shat = L^-T e by back substitution distributed over the lanes
+    double sh = 0.0;
+    static_for<0, NP>([&](auto ic) {
+      constexpr int i = NP - 1 - decltype(ic)::value;
+      const double si = bcast_lane<NP, i>(e) / L_[i * LD + i];
+      sh = (j == i) ? si : sh;
+      e -= (j < i) ? L_[i * LD + j] * si : 0.0;
+    });
+    v1[j] = sh;
+    __syncthreads();
+    double tv = 0.0;  // t = L^T shat
+#pragma unroll
+    for (int r = 0; r < NP; ++r) tv += L_[r * LD + j] * v1[r];
+    v2[j] = tv;
+    __syncthreads();
+    double ps = 0.0;  // Pm shat = L t
+#pragma unroll
+    for (int r = 0; r < NP; ++r) ps += L_[j * LD + r] * v2[r];
+    const double rT = 1.0 / T_j;
+    const double s_j = sh * rT;
+    const double d_j = mu0 * (txd - ps) * rT;
+    if (valid) {
+      d.Bv[base * 2 * NP + j] = 0.5 * (s_j + d_j);
+      d.Bv[base * 2 * NP + NP + j] = 0.5 * (s_j - d_j);
+    }
+  }
+  __syncthreads();
+
+  // isotropic (thermal) source, Fourier mode 0 only (subroutines.py:746-862, _assemble.py:124).
+  // Every group runs the barriers below; only groups with m == 0 store.
+  if (d.Ns > 0) {
+    const bool act = (m == 0);
+    // q = L^-1 (T / mu) by forward substitution distributed over the lanes
+    double cur = T_j * invmu_j, q_j = 0.0;
+    static_for<0, NP>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const double qi = bcast_lane<NP, i>(cur) / L_[i * LD + i];
+      q_j = (j == i) ? qi : q_j;
+      cur -= (j > i) ? L_[j * LD + i] * qi : 0.0;
+    });
+    v0[j] = q_j;
+    __syncthreads();
+    double zn = 0.0;  // zneg_j = -k_j/2 sum_i Z[i][j] q[i]
+#pragma unroll
+    for (int i = 0; i < NP; ++i) zn += zc[i] * v0[i];
+    zn *= -0.5 * kj;
+    if (valid && act) d.zneg[((long)c * d.L + l) * NP + j] = zn;
+    const double* sp = d.spoly + ((long)c * d.L + l) * d.Ns;
+    const double rk = 1.0 / kj;
+    for (int q = 0; q < d.Ns; ++q) {
+      // b_q(K) = sum_{jj>=q} jj!/q! a_jj K^-(jj-q+1), K = -k (first N eigen-columns) and +k
+      double bneg = 0.0, bpos = 0.0, ratio = 1.0, pw_pos = rk, pw_neg = -rk;
+      for (int jj = q; jj < d.Ns; ++jj) {
+        bpos += ratio * sp[jj] * pw_pos;
+        bneg += ratio * sp[jj] * pw_neg;
+        ratio *= (double)(jj + 1);
+        pw_pos *= rk;
+        pw_neg *= -rk;
+      }
+      const double a = zn * bneg, b = -zn * bpos;
+      // up-streams: Gp a + Gm b ; down-streams: Gm a + Gp b  (sum over eigen-index = lanes), with
+      // Gp = (Y - A/k)/T, Gm = (Y + A/k)/T:  up = [Y (a+b) - A (a-b)/k]/T, down = [Y (a+b) + A (a-b)/k]/T
+      const double sab = a + b, dab = (a - b) * rk;
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NP; ++i) R_[i * LD + j] = (ya[i] * sab - aa[i] * dab) / d.T[i];
+      __syncthreads();
+      double up = 0.0;
+#pragma unroll
+      for (int r = 0; r < NP; ++r) up += R_[j * LD + r];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NP; ++i) R_[i * LD + j] = (ya[i] * sab + aa[i] * dab) / d.T[i];
+      __syncthreads();
+      double dn = 0.0;
+#pragma unroll
+      for (int r = 0; r < NP; ++r) dn += R_[j * LD + r];
+      if (valid && act) {
+        double* dq = d.dq + (((long)c * d.L + l) * d.Ns + q) * 2 * NP;
+        dq[j] = up;
+        dq[NP + j] = dn;
+      }
+    }
+    __syncthreads();
+  }
+
+}
+
 // ---- Legendre tables: Ybar_l^m(x) = sqrt((l-m)!/(l+m)!) P_l^m(x) without the Condon-Shortley sign
 //      (it cancels in every product the path forms); replaces scipy.special.lpmv/poch (:96-109).
 __device__ __forceinline__ void ybar_column(int m, int P, double x, double* out, long stride) {
@@ -568,18 +834,22 @@ void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part) {
   // part 0: assembly + Cholesky + F, 1: Jacobi, 2: eigenvector blocks / particular solutions
   const int gpw = 64 / d.NP;
   const dim3 grid((unsigned)((long)d.C * d.M * ((d.L + gpw - 1) / gpw)));
-#define RTD_EIG_CASE(NPV)                                                                       \
+  // NP <= 16: one fused kernel (launched as part 1); NP = 32: three kernels (the fused form would not fit the
+  // register file) exchanging F, L, Qm, k Z through the Ym / Am / Lw / Qw buffers
+#define RTD_EIG_FUSED(NPV)                                                                      \
   case NPV:                                                                                     \
-    if (part == 0) hipLaunchKernelGGL(rtd_asm_kernel<NPV>, grid, dim3(64), 0, s, d);            \
-    if (part == 1) hipLaunchKernelGGL(rtd_jacobi_kernel<NPV>, grid, dim3(64), 0, s, d);         \
-    if (part == 2) hipLaunchKernelGGL(rtd_post_kernel<NPV>, grid, dim3(64), 0, s, d);           \
+    if (part == 1) hipLaunchKernelGGL(rtd_eigen_kernel<NPV>, grid, dim3(64), 0, s, d);          \
     break;
   switch (d.NP) {
-    RTD_EIG_CASE(4)
-    RTD_EIG_CASE(8)
-    RTD_EIG_CASE(16)
-    RTD_EIG_CASE(32)
+    RTD_EIG_FUSED(4)
+    RTD_EIG_FUSED(8)
+    RTD_EIG_FUSED(16)
+    case 32:
+      if (part == 0) hipLaunchKernelGGL(rtd_asm_kernel<32>, grid, dim3(64), 0, s, d);
+      if (part == 1) hipLaunchKernelGGL(rtd_jacobi_kernel<32>, grid, dim3(64), 0, s, d);
+      if (part == 2) hipLaunchKernelGGL(rtd_post_kernel<32>, grid, dim3(64), 0, s, d);
+      break;
     default: break;
   }
-#undef RTD_EIG_CASE
+#undef RTD_EIG_FUSED
 }
