@@ -53,6 +53,16 @@ __device__ __forceinline__ double fast_rcp(double x) {
   y = y * (2.0 - x * y);
   return y;
 }
+// one Newton step from the ~5e-8 hardware seeds: ~4e-15 relative (tools/hiptests/seed_accuracy.hip), enough for
+// quantities that only steer a rotation angle
+__device__ __forceinline__ double approx_rsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  return y * (1.5 - 0.5 * x * y * y);
+}
+__device__ __forceinline__ double approx_rcp(double x) {
+  const double y = __builtin_amdgcn_rcp(x);
+  return y * (2.0 - x * y);
+}
 
 // a sweep is the last one when every pair it met had cos^2(angle) <= RTD_JAC_TOL (quadratic convergence
 // squares the residual angle during that sweep)
@@ -83,9 +93,9 @@ struct JacobiStep {
       const double delta = lo ? (beta - alpha) : (alpha - beta);
       const double g2 = 2.0 * gamma;
       const double r2 = delta * delta + g2 * g2;
-      const double rho = r2 * fast_rsqrt(r2);
+      const double rho = r2 * approx_rsqrt(r2);
       const double den = delta + copysign(rho, delta);
-      const double tt = g2 * fast_rcp(den);
+      const double tt = g2 * approx_rcp(den);
       c = fast_rsqrt(1.0 + tt * tt);
       const double s = tt * c;
       sg = lo ? -s : s;
