@@ -67,7 +67,7 @@ __device__ __forceinline__ double approx_rcp(double x) {
 // a sweep is the last one when every pair it met had cos^2(angle) <= RTD_JAC_TOL (quadratic convergence
 // squares the residual angle during that sweep)
 #ifndef RTD_JAC_TOL
-#define RTD_JAC_TOL 1e-20
+#define RTD_JAC_TOL 1e-16
 #endif
 
 // One parallel step of the one-sided (Hestenes) Jacobi iteration on the columns of W (H = W W^T at the

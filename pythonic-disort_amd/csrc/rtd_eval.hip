@@ -28,7 +28,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
   double* um = smem + M * Q;    // [M][Q] Fourier modes of the intensity at this point
   __shared__ int s_l;
   __shared__ double s_ts;
-  const int t = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+  const int t = (int)(blockIdx.x % ev.ntau), c = (int)(blockIdx.x / ev.ntau), tid = threadIdx.x;
   const double tau = ev.tau[(long)c * ev.ntau + t];
   const double* tau_arr = d.tau + (long)c * L;
   const double* ts0 = d.taus0 + (long)c * (L + 1);
@@ -173,7 +173,7 @@ __global__ void rtd_export_kernel(RtdDev d, int col, double* GC, double* K, doub
 }  // namespace
 
 void rtd_launch_eval(const RtdDev& d, const RtdEval& e, hipStream_t s) {
-  const dim3 grid((unsigned)e.ntau, (unsigned)d.C);
+  const dim3 grid((unsigned)((long)e.ntau * d.C));  // 1-D: no 65535 limit on the column count
   const size_t shm = (size_t)2 * d.M * 2 * d.NP * sizeof(double);
   switch (d.NP) {
     case 4: hipLaunchKernelGGL(rtd_eval_kernel<4>, grid, dim3(EVAL_THREADS), shm, s, d, e); break;

@@ -48,7 +48,7 @@ __global__ void rtd_nt_tables_kernel(RtdDev d, RtdNt nt) {
 }
 
 __global__ void rtd_nt_apply_kernel(RtdDev d, RtdNt nt, RtdEval ev) {
-  const int t = blockIdx.x, c = blockIdx.y;
+  const int t = (int)(blockIdx.x % ev.ntau), c = (int)(blockIdx.x / ev.ntau);
   const int N = d.N, L = d.L, Qr = 2 * N;
   const double tau = ev.tau[(long)c * ev.ntau + t];
   const double* tau_arr = d.tau + (long)c * L;
@@ -109,5 +109,5 @@ void rtd_launch_nt_tables(const RtdDev& d, const RtdNt& nt, hipStream_t s) {
 }
 
 void rtd_launch_nt_apply(const RtdDev& d, const RtdNt& nt, const RtdEval& e, hipStream_t s) {
-  hipLaunchKernelGGL(rtd_nt_apply_kernel, dim3((unsigned)e.ntau, (unsigned)d.C), dim3(128), 0, s, d, nt, e);
+  hipLaunchKernelGGL(rtd_nt_apply_kernel, dim3((unsigned)((long)e.ntau * d.C)), dim3(128), 0, s, d, nt, e);
 }
