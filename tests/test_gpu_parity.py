@@ -256,3 +256,55 @@ def test_baseline_literal_configs(amd, name):
     fd = Fm(tau_pts)
     assert np.allclose(fd[0], z["flux_down_diffuse"], rtol=1e-9, atol=1e-11 * scale)
     assert np.allclose(fd[1], z["flux_down_direct"], rtol=1e-12, atol=1e-300)
+
+
+EDGE_CASES = {
+    # two streams (N = 1, padded to 4 lanes), single layer
+    "two_streams": dict(tau_arr=0.7, omega_arr=0.6, NQuad=2, Leg_coeffs_all=np.array([1.0, 0.3, 0.1]), mu0=0.4, I0=2.0, phi0=1.0),
+    # fewer Legendre moments / Fourier modes than streams, matrix-form Dirichlet BCs, mixed zero-omega layers
+    "nleg_lt_nquad": dict(tau_arr=np.array([0.2, 0.9, 1.0, 4.0]), omega_arr=np.array([0.0, 0.8, 0.0, 0.3]), NQuad=12,
+                          Leg_coeffs_all=np.tile(0.6 ** np.arange(13), (4, 1)), mu0=0.9, I0=1.0, phi0=0.0, NLeg=7, NFourier=5,
+                          b_pos=np.outer(np.linspace(0.1, 0.6, 6), [1.0, 0.5, 0.25, 0.1, 0.05]),
+                          b_neg=np.linspace(0.3, 0.1, 6)),
+    # no sources except a thermal cubic; BDRF given as a callable mode plus a scalar mode
+    "thermal_cubic_bdrf": dict(tau_arr=np.array([0.5, 1.5]), omega_arr=np.array([0.4, 0.7]), NQuad=8,
+                               Leg_coeffs_all=np.tile(0.5 ** np.arange(9), (2, 1)), mu0=0.0, I0=0.0, phi0=0.0,
+                               s_poly_coeffs=np.array([[1.0, 0.5, 0.2, 0.05], [2.0, -0.3, 0.1, 0.01]]),
+                               BDRF_Fourier_modes=[lambda mu, nmup: 0.2 + 0.1 * np.outer(mu, nmup), 0.05]),
+    # very thick and very thin layers next to each other, near-grazing beam
+    "thick_thin": dict(tau_arr=np.cumsum([1e-6, 40.0, 1e-4, 5.0, 1e-6]), omega_arr=np.array([0.9, 0.99, 0.2, 0.95, 0.5]),
+                       NQuad=16, Leg_coeffs_all=np.tile(0.8 ** np.arange(17), (5, 1)), mu0=0.05, I0=3.0, phi0=2.0,
+                       f_arr=np.full(5, 0.8**16), b_pos=0.2),
+    "only_flux": dict(tau_arr=np.array([1.0, 2.0, 3.5]), omega_arr=np.array([0.5, 0.9, 0.7]), NQuad=16,
+                      Leg_coeffs_all=np.tile(0.7 ** np.arange(17), (3, 1)), mu0=0.6, I0=1.5, phi0=0.3, only_flux=True,
+                      BDRF_Fourier_modes=[0.3]),
+}
+
+
+@pytest.mark.parametrize("name", list(EDGE_CASES))
+def test_edge_cases_vs_oracle(amd, name):
+    """Shapes and corner sizes the reference accepts: N = 1, NLeg/NFourier < NQuad, matrix BCs, omega = 0 layers,
+    high-order thermal polynomials, callable BDRF modes, 1e-6 ... 40 layer thicknesses, only_flux; evaluated at 0,
+    every interface, tau_L and interior points (scalar and array tau)."""
+    from oracle import disort_oracle as O
+    kw = EDGE_CASES[name]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = amd.pydisort(**kw)
+        ref = O.pydisort(**kw)
+    assert len(got) == len(ref) and np.array_equal(got[0], ref[0])
+    tau_arr = np.atleast_1d(kw["tau_arr"])
+    tau = np.unique(np.concatenate(([0.0], tau_arr, 0.5 * tau_arr, [0.999999 * tau_arr[-1]])))
+    scale = max(np.max(np.abs(ref[3](tau))), 1e-300)
+    assert np.max(np.abs(got[3](tau) - ref[3](tau))) / scale < TOL
+    assert np.allclose(got[1](tau), ref[1](tau), rtol=1e-8, atol=1e-10 * scale)
+    for a, b in zip(got[2](tau), ref[2](tau)):
+        assert np.allclose(a, b, rtol=1e-8, atol=1e-10 * scale)
+    assert np.shape(got[1](0.3 * tau_arr[-1])) == np.shape(ref[1](0.3 * tau_arr[-1])) == ()
+    if len(got) > 4:
+        phi = np.array([0.0, 1.3, 5.0])
+        assert np.max(np.abs(got[4](tau, phi) - ref[4](tau, phi))) / scale < TOL
+        assert np.shape(got[4](tau[1], 0.5)) == np.shape(ref[4](tau[1], 0.5))
+        e1 = got[4](tau, phi, False, True)[1]
+        e2 = ref[4](tau, phi, False, True)[1]
+        assert abs(e1 - e2) < 1e-6 * max(1.0, abs(e2))
