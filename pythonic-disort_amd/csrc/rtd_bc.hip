@@ -102,8 +102,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int K>
 __device__ __forceinline__ double bcast16(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xF, 0xF, false);  // row_newbcast:K
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xF, 0xF, false);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + K, 0xF, 0xF, false);  // row_newbcast:K (every source lane exists: `old` is never used)
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + K, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
 

@@ -138,8 +138,8 @@ template <int NP, int K>
 __device__ __forceinline__ double bcast_lane(double v) {
   if constexpr (NP == 16) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xF, 0xF, false);  // row_newbcast:K
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + K, 0xF, 0xF, false);  // row_newbcast:K (every source lane exists: `old` is never used)
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + K, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
   } else {
     return __shfl(v, K, NP);
@@ -154,15 +154,18 @@ struct CholStep {
   static __device__ __forceinline__ void run(double (&col)[NP], const int j) {
     const double akk = bcast_lane<NP, K>(col[K]);
     const double rinv = fast_rsqrt(akk);
-    const double ljk = (j > K) ? col[K] * rinv : 0.0;  // L[j][K] by symmetry; 0 freezes the finished columns
-    const bool own = (j == K);
+    // one formula for every lane: col[i] <- col[i] * scale - L[i][K] * ljk
+    //   owner of column K (j == K): scale = 1/sqrt(akk), ljk = 0   ->  L[i][K]
+    //   trailing columns  (j > K):  scale = 1, ljk = L[j][K] (by symmetry)  ->  rank-1 update
+    //   finished columns  (j < K):  scale = 1, ljk = 0  ->  unchanged
+    const double ljk = (j > K) ? col[K] * rinv : 0.0;
+    const double scale = (j == K) ? rinv : 1.0;
 #pragma unroll
     for (int i = K + 1; i < NP; ++i) {
       const double lik = bcast_lane<NP, K>(col[i]) * rinv;
-      const double upd = col[i] - lik * ljk;
-      col[i] = own ? lik : upd;
+      col[i] = fma(-lik, ljk, col[i] * scale);
     }
-    col[K] = own ? akk * rinv : col[K];
+    col[K] = (j == K) ? akk * rinv : col[K];
     CholStep<NP, K + 1>::run(col, j);
   }
 };
