@@ -21,6 +21,7 @@
 // Two kernels: rtd_iface_kernel (all (column, mode, interface) in parallel: Wp, Wq, rho) and
 // rtd_sweep_kernel (per (column, mode): forward carry recursion, bottom boundary, backward sweep).
 // NP lanes per problem, 64/NP problems per wavefront; lane i owns row i of the carry system.
+#include <cstdlib>
 #include <type_traits>
 
 #include "rtd_device.h"
@@ -206,6 +207,112 @@ __global__ __launch_bounds__(64) void rtd_iface_kernel(RtdDev d) {
   if (valid) {
     ws[Ws<NP>::RT + j] = 0.25 * rt;
     ws[Ws<NP>::RB + j] = 0.25 * rb;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Interface kernel, NP = 16, on the matrix cores: one wavefront per IFACE_CHUNK consecutive interfaces of one
+// (c, m).  The two 16x16x16 FP64 products  A_l^T Y_{l+1}  and  Y_l^T A_{l+1}  are 4 + 4 v_mfma_f64_16x16x4_f64;
+// operands are loaded straight from HBM in the MFMA A/B layouts (lane: row/column lane & 15, k = lane >> 4 --
+// 128-byte coalesced segments) and layer l+1's operands are reused as layer l's for the next interface; results
+// are stored from the C/D layout (column lane & 15, rows (lane >> 4) + 4 r).  No LDS, no barriers.
+// ------------------------------------------------------------------------------------------------
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+#ifndef RTD_IFACE_CHUNK
+#define RTD_IFACE_CHUNK 5
+#endif
+constexpr int IFACE_CHUNK = RTD_IFACE_CHUNK;
+
+__global__ __launch_bounds__(256) void rtd_iface_mfma_kernel(RtdDev d) {
+  constexpr int NP = 16, Q = 32;
+  const int lane = threadIdx.x & 63;
+  const int Lm1 = d.L - 1;
+  const int nchunk = (Lm1 + IFACE_CHUNK - 1) / IFACE_CHUNK;
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= (long)d.C * d.M * nchunk) return;  // whole wavefronts exit together
+  const long cm = wid / nchunk;
+  const int l_begin = (int)(wid % nchunk) * IFACE_CHUNK;
+  const int l_end = min(l_begin + IFACE_CHUNK, Lm1);
+  const int m = (int)(cm % d.M), c = (int)(cm / d.M);
+  const int col = lane & 15, kq = lane >> 4;
+  const double* ts0 = d.taus0 + (long)c * (d.L + 1);
+  const bool iso = d.Ns > 0 && m == 0;
+  const double mu0 = d.beam ? d.mu0[c] : 1.0;
+  // operands of layer l in the MFMA A layout (= B layout of the same matrix): element [i = 4 s + kq][col]
+  double a0[4], y0[4], a1[4], y1[4];
+  {
+    const double* A0 = d.Am + (cm * d.L + l_begin) * NP * NP;
+    const double* Y0 = d.Ym + (cm * d.L + l_begin) * NP * NP;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      a0[s] = A0[(4 * s + kq) * NP + col];
+      y0[s] = Y0[(4 * s + kq) * NP + col];
+    }
+  }
+  for (int l = l_begin; l < l_end; ++l) {
+    const long p0 = cm * d.L + l, p1 = p0 + 1;
+    const double* A1 = d.Am + p1 * NP * NP;
+    const double* Y1 = d.Ym + p1 * NP * NP;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      a1[s] = A1[(4 * s + kq) * NP + col];
+      y1[s] = Y1[(4 * s + kq) * NP + col];
+    }
+    // particular-solution jump r_l (:184-205, :242-245): (r_up +- r_dn)_i for the four i = 4 s + kq of this lane
+    const double tb = ts0[l + 1];
+    const double att = d.beam ? exp(-tb / mu0) : 0.0;
+    v4f64 vv = {0.0, 0.0, 0.0, 0.0}, uu = {0.0, 0.0, 0.0, 0.0};
+    double rt = 0.0, rb = 0.0;
+    const double kcol0 = d.kk[p0 * NP + col];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int i = 4 * s + kq;
+      vv = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], y1[s], vv, 0, 0, 0);  // (A_l^T Y')[r][c] += A_l[i][r] Y'[i][c]
+      uu = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[s], a1[s], uu, 0, 0, 0);  // (Y_l^T A')[r][c] += Y_l[i][r] A'[i][c]
+      double ru = 0.0, rd = 0.0;
+      if (d.beam) {
+        ru = (d.Bv[p1 * Q + i] - d.Bv[p0 * Q + i]) * att;
+        rd = (d.Bv[p1 * Q + NP + i] - d.Bv[p0 * Q + NP + i]) * att;
+      }
+      if (iso) {
+        const double* dq0 = d.dq + ((long)c * d.L + l) * d.Ns * Q;
+        const double* dq1 = dq0 + (long)d.Ns * Q;
+        double tp = 1.0;
+        for (int q = 0; q < d.Ns; ++q) {
+          ru += (dq1[q * Q + i] - dq0[q * Q + i]) * tp;
+          rd += (dq1[q * Q + NP + i] - dq0[q * Q + NP + i]) * tp;
+          tp *= tb;
+        }
+      }
+      // rho = G_l^-1 r:  V^-1[j][i] = T_i A[i][j],  U^-1[j][i] = -k_j T_i Y[i][j]   (j = col)
+      const double Ti = d.T[i];
+      const double pa = Ti * a0[s] * (ru + rd), pb = -kcol0 * Ti * y0[s] * (ru - rd);
+      rt += pa + pb;
+      rb += pa - pb;
+    }
+    // sum the partial rho over the four k-quarters of the wavefront (lanes col, col+16, col+32, col+48)
+    rt += __shfl_xor(rt, 16, 64);
+    rb += __shfl_xor(rb, 16, 64);
+    rt += __shfl_xor(rt, 32, 64);
+    rb += __shfl_xor(rb, 32, 64);
+    double* ws = d.Fws + (cm * Lm1 + l) * Ws<NP>::SLOT;
+    const double rk1 = 1.0 / d.kk[p1 * NP + col];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = kq + 4 * q;  // C/D layout of v_mfma_f64_16x16x4_f64
+      const double u = uu[q] * d.kk[p0 * NP + r] * rk1;  // U^-1 U' = diag(k) Y^T A' diag(1/k')
+      ws[Ws<NP>::WP + r * NP + col] = 0.5 * (vv[q] + u);
+      ws[Ws<NP>::WQ + r * NP + col] = 0.5 * (vv[q] - u);
+    }
+    if (kq == 0) {
+      ws[Ws<NP>::RT + col] = 0.25 * rt;
+      ws[Ws<NP>::RB + col] = 0.25 * rb;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      a0[s] = a1[s];
+      y0[s] = y1[s];
+    }
   }
 }
 
@@ -507,7 +614,18 @@ void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
   switch (d.NP) {
     RTD_BC_CASE(4)
     RTD_BC_CASE(8)
-    RTD_BC_CASE(16)
+    case 16:  // RTD_IFACE_LDS=1 selects the LDS/VALU variant of the interface kernel (A/B comparison)
+      if (part == 0 && nif > 0) {
+        static const bool use_lds = getenv("RTD_IFACE_LDS") != nullptr;
+        if (use_lds)
+          hipLaunchKernelGGL(rtd_iface_kernel<16>, gi, dim3(64), 0, s, d);
+        else
+          hipLaunchKernelGGL(rtd_iface_mfma_kernel,
+                             dim3((unsigned)(((long)d.C * d.M * ((d.L - 1 + IFACE_CHUNK - 1) / IFACE_CHUNK) + 3) / 4)),
+                             dim3(256), 0, s, d);
+      }
+      if (part == 1) hipLaunchKernelGGL(rtd_sweep_kernel<16>, gs, dim3(64), 0, s, d);
+      break;
     RTD_BC_CASE(32)
     default: break;
   }
