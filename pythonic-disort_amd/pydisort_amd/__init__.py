@@ -5,7 +5,7 @@ returned callables; ``pydisort_batch`` solves many independent atmospheric colum
 numerics run in hand-written HIP kernels (librtd.so) reached through the C ABI of include/rtd.h.
 """
 from .pydisort import pydisort  # noqa: F401
-from .batch import pydisort_batch, BatchSolution  # noqa: F401
+from .batch import pydisort_batch, BatchSolution, solve_columns_streamed  # noqa: F401
 from . import subroutines  # noqa: F401
 
-__all__ = ["pydisort", "pydisort_batch", "BatchSolution", "subroutines"]
+__all__ = ["pydisort", "pydisort_batch", "BatchSolution", "solve_columns_streamed", "subroutines"]

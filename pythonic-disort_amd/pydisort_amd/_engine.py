@@ -26,10 +26,18 @@ class Plan:
         self._h = h
         mu, w = _f64(prep["mu"]), _f64(prep["W"])
         _lib.check(lib.rtd_plan_set_quadrature(h, _lib.dptr(mu), _lib.dptr(w)))
+        self.set_columns(prep)
+
+    def set_columns(self, prep):
+        """Upload the prepared per-column inputs (same dimensions as the plan): a plan can be reused for many batches."""
+        for k in ("C", "L", "N", "P", "M", "Ns", "NBDRF"):
+            if prep[k] != self.prep[k]:
+                raise ValueError(f"prepared batch does not match the plan: {k} = {prep[k]} vs {self.prep[k]}")
         keys = ["omega_s", "tau", "tau_s0", "scale_tau", "wleg", "mu0", "I0", "phi0", "rescale",
                 "b_pos", "b_neg", "s_s", "bdrf_q", "bdrf_q0"]
         arrs = [_f64(prep[k]) for k in keys]
-        _lib.check(lib.rtd_plan_set_columns(h, *[_lib.dptr(a) for a in arrs]))
+        _lib.check(self._lib.rtd_plan_set_columns(self._h, *[_lib.dptr(a) for a in arrs]))
+        self.prep = prep
         self.solved = False
 
     def close(self):

@@ -103,3 +103,79 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
         plan.set_nt(*_nt.nt_inputs(prep, omega_arr, f_arr, Leg, NLeg, mu0))
     sol = BatchSolution(plan, prep)
     return sol.mu_arr, sol
+
+
+def solve_columns_streamed(cfg, tau, phi, chunk_columns=4096, device=0, only_flux=False):
+    """Throughput form for column counts that do not fit one plan (a cfg4 column needs ~8 MB of HBM): the columns
+    are solved chunk by chunk through ONE reused plan (same device buffers, new inputs per chunk) and only the
+    evaluated results come back.
+
+    cfg : dict of ``pydisort_batch`` keyword arguments with a leading column axis (tau_arr, omega_arr, Leg_coeffs_all,
+          mu0, I0, phi0, optional f_arr, b_pos, b_neg, s_poly_coeffs, bdrf_q, bdrf_q0, NLeg, NFourier); NQuad scalar.
+    tau : [C, ntau] evaluation depths; phi : [nphi].
+    Returns dict(u [C, NQuad, ntau, nphi] (absent when only_flux), u0, flux_up, flux_down_diffuse, flux_down_direct)."""
+    tau = np.asarray(tau, float)
+    C = tau.shape[0]
+    per_col = ("tau_arr", "omega_arr", "Leg_coeffs_all", "mu0", "I0", "phi0", "f_arr", "b_pos", "b_neg",
+               "s_poly_coeffs", "bdrf_q", "bdrf_q0")
+    out = {}
+    plan = None
+    for c0 in range(0, C, chunk_columns):
+        c1 = min(c0 + chunk_columns, C)
+        sub = {k: (v[c0:c1] if (k in per_col and isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == C) else v)
+               for k, v in cfg.items()}
+        if plan is not None and c1 - c0 != plan.C:  # last, shorter chunk: new plan
+            plan.close()
+            plan = None
+        if plan is None:
+            _, sol = pydisort_batch(only_flux=only_flux, device=device, **sub)
+            plan = sol.plan
+        else:
+            prep = _prepared_like(plan.prep, sub, only_flux)
+            plan.set_columns(prep)
+            plan.solve()
+        res = plan.evaluate(np.ascontiguousarray(tau[c0:c1]), None if only_flux else phi,
+                            want=("u0", "flux") if only_flux else ("u", "u0", "flux"))
+        for k, v in res.items():
+            if v is None:
+                continue
+            if k not in out:
+                out[k] = np.empty((C,) + v.shape[1:])
+            out[k][c0:c1] = v
+    if plan is not None:
+        plan.close()
+    return out
+
+
+def _prepared_like(prep0, sub, only_flux):
+    """Host preparation of another chunk with the dimensions of an existing plan."""
+    tau_arr = np.atleast_2d(np.asarray(sub["tau_arr"], float))
+    C, L = tau_arr.shape
+    NQuad = sub["NQuad"]
+    N = NQuad // 2
+    NLeg, NFourier = prep0["P"], prep0["M"]
+    Leg = np.asarray(sub["Leg_coeffs_all"], float)
+    if Leg.ndim == 2:
+        Leg = np.broadcast_to(Leg[None], (C,) + Leg.shape)
+
+    def bc(b):
+        b = np.asarray(b, float)
+        out = np.zeros((C, N, NFourier))
+        if b.ndim == 0 or b.shape == (C,):
+            out[:, :, 0] = np.broadcast_to(b, (C,))[:, None]
+        elif b.shape == (C, N):
+            out[:, :, 0] = b
+        else:
+            out[:] = b
+        return out
+
+    sp = sub.get("s_poly_coeffs")
+    sp = np.zeros((C, L, 0)) if sp is None or prep0["Ns"] == 0 else np.asarray(sp, float).reshape(C, L, -1)
+    bq = sub.get("bdrf_q")
+    bq = np.zeros((C, 0, N, N)) if bq is None else np.asarray(bq, float)
+    bq0 = sub.get("bdrf_q0")
+    bq0 = np.zeros((C, 0, N)) if bq0 is None else np.asarray(bq0, float)
+    return prepare_columns(tau_arr, np.broadcast_to(np.asarray(sub["omega_arr"], float), (C, L)), NQuad, Leg,
+                           np.broadcast_to(np.asarray(sub["mu0"], float), (C,)), np.broadcast_to(np.asarray(sub["I0"], float), (C,)),
+                           np.broadcast_to(np.asarray(sub["phi0"], float), (C,)), NLeg, NFourier, bc(sub.get("b_pos", 0)),
+                           bc(sub.get("b_neg", 0)), np.broadcast_to(np.asarray(sub.get("f_arr", 0), float), (C, L)), sp, bq, bq0)

@@ -308,3 +308,16 @@ def test_edge_cases_vs_oracle(amd, name):
         e1 = got[4](tau, phi, False, True)[1]
         e2 = ref[4](tau, phi, False, True)[1]
         assert abs(e1 - e2) < 1e-6 * max(1.0, abs(e2))
+
+
+def test_streamed_chunks_equal_one_batch(amd):
+    """solve_columns_streamed (one reused plan, several chunks incl. a shorter last one) == one big batch, bit for bit."""
+    from pydisort_amd import synthetic
+    C = 50
+    cfg = synthetic.cfg4_columns(C, L=6, NQuad=16)
+    tau = np.concatenate((np.zeros((C, 1)), cfg["tau_arr"]), axis=1)
+    phi = np.array([0.0, 2.0])
+    _, sol = amd.pydisort_batch(**cfg)
+    want_u, want_f = sol.u(tau, phi), sol.flux_up(tau)
+    got = amd.solve_columns_streamed(cfg, tau, phi, chunk_columns=16)
+    assert np.array_equal(got["u"], want_u) and np.array_equal(got["flux_up"], want_f)
