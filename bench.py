@@ -48,6 +48,45 @@ def measured_traffic(kernel):
         return None
 
 
+def extra_measurements(device):
+    """Secondary numbers of SURVEY section 8(d) on rank 0: max |dI| of the HIP path against the oracle on the sample
+    columns of the cpu_baseline leg, and the only_flux (one Fourier mode) throughput."""
+    import pydisort_amd
+    from pydisort_amd import synthetic
+    out = {}
+    if _ORACLE_SAMPLES:
+        worst_abs = worst_rel = 0.0
+        phi = np.array([0.0, np.pi / 2, np.pi])
+        for first, want in _ORACLE_SAMPLES:
+            cfg = synthetic.cfg4_columns(1, first=first)
+            _, sol = pydisort_amd.pydisort_batch(device=device, **cfg)
+            tau = np.concatenate((np.zeros((1, 1)), cfg["tau_arr"]), axis=1)
+            got = sol.u(tau, phi)[0]
+            diff = np.abs(got - want)
+            sig = np.abs(want) > 1e-8 * np.max(np.abs(want))
+            worst_abs = max(worst_abs, float(diff.max()))
+            worst_rel = max(worst_rel, float((diff[sig] / np.abs(want[sig])).max()))
+            sol.plan.close()
+        out["parity"] = {"max_abs_dI": worst_abs, "max_rel_dI": worst_rel, "columns_checked": len(_ORACLE_SAMPLES),
+                         "against": "CPU oracle (pinned to the reference) on the same seeded cfg4 columns"}
+    C = 16384
+    cfg = synthetic.cfg4_columns(C, first=50_000)
+    _, sol = pydisort_amd.pydisort_batch(only_flux=True, device=device, **cfg)
+    plan = sol.plan
+    tau = np.concatenate((np.zeros((C, 1)), cfg["tau_arr"]), axis=1)
+    plan.set_eval_points(tau, np.array([0.0]))
+    plan.run()
+    plan.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        plan.run()
+    plan.synchronize()
+    out["only_flux"] = {"value": 5 * C / (time.perf_counter() - t0), "unit": "column-solves/sec",
+                        "workload": "cfg4 with only_flux=True (one Fourier mode), 16384 columns per pass"}
+    plan.close()
+    return out
+
+
 def shard_columns(rank, world, columns_per_gpu):
     """Weak-scaling column shard of a rank: global column indices [first, first + count)."""
     return rank * columns_per_gpu, columns_per_gpu
@@ -69,11 +108,18 @@ def _cpu_worker(args):
     with threadpool_limits(1):
         cfg = synthetic.cfg4_columns(n, first=first)
         phi = np.array([0.0, np.pi / 2, np.pi])
+        keep = None
         for i in range(n):
             res = O.pydisort(**synthetic.column_kwargs(cfg, i))
             tau = np.concatenate(([0.0], cfg["tau_arr"][i]))
-            res[4](tau, phi), res[1](tau), res[2](tau)
-    return n
+            u = res[4](tau, phi)
+            res[1](tau), res[2](tau)
+            if i == 0:
+                keep = u
+    return n, first, keep
+
+
+_ORACLE_SAMPLES = []
 
 
 def cpu_baseline(cols_per_core=6):
@@ -86,8 +132,11 @@ def cpu_baseline(cols_per_core=6):
     with ctx.Pool(cores) as pool:
         pool.map(_cpu_worker, [(0, 1)] * cores)  # warm imports
         t0 = time.perf_counter()
-        done = sum(pool.map(_cpu_worker, jobs))
+        results = pool.map(_cpu_worker, jobs)
         dt = time.perf_counter() - t0
+    done = sum(r[0] for r in results)
+    global _ORACLE_SAMPLES  # (global column index, oracle u[Q, 21, 3]) of a few columns, for the parity field
+    _ORACLE_SAMPLES = [(r[1], r[2]) for r in results[:8]]
     return dict(value=done / dt, unit="column-solves/sec", cores=cores, kind="port",
                 sample=f"{done} cfg4 columns (L=20, NQuad=32, 32 Fourier modes, u at 21 tau x 3 phi + fluxes), "
                        f"{cores} processes x 1 BLAS thread, {dt:.1f} s")
@@ -184,6 +233,9 @@ def main():
     stage = plan.timing(reset=True)
     sweeps = plan.max_sweeps()
 
+    extras = {}
+    if rank == 0 and world == 1:
+        extras = extra_measurements(local)
     if rank == 0:
         fl = algorithmic_flops()
         ms = {k: (v[0] / max(v[1], 1)) for k, v in stage.items()}
@@ -215,6 +267,7 @@ def main():
                          "whole_path_frac": fl["total"] * C * a.steps / elapsed / 1e12 / FP64_PEAK_TFLOPS},
             "cpu_baseline": cpu,
         }
+        out.update(extras)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
