@@ -22,14 +22,29 @@ namespace {
 
 // compiler-only barrier: keeps the scheduler from hoisting a whole unrolled loop's LDS loads
 #define RTD_FENCE() asm volatile("" ::: "memory")
+#ifndef RTD_XOR_DPP
+#define RTD_XOR_DPP 0  /* A/B: DPP for the one-move masks is 2 % slower -- the Jacobi sweeps are VALU-bound, the LDS crossbar is free */
+#endif
+
+// DPP control of a lane permutation "lane ^ MASK" inside a 16-lane row that one DPP move can express, else -1:
+// quad permutes for 1, 2, 3; row_half_mirror = ^7; row_ror:8 = ^8; row_mirror = ^15
+constexpr __host__ __device__ int dpp_xor_ctrl(int mask) {
+  return mask == 1 ? 0xB1 : mask == 2 ? 0x4E : mask == 3 ? 0x1B : mask == 7 ? 0x141 : mask == 8 ? 0x128 : mask == 15 ? 0x140 : -1;
+}
 
 template <int MASK>
 __device__ __forceinline__ double xor_lane(double v) {
-  // value of lane (lane ^ MASK); MASK < 32.  ds_swizzle bit-mode: and=0x1f, or=0, xor=MASK
-  constexpr int pat = (MASK << 10) | 0x1F;
+  // value of lane (lane ^ MASK); MASK < 32
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_ds_swizzle(lo, pat);
-  hi = __builtin_amdgcn_ds_swizzle(hi, pat);
+  constexpr int ctrl = dpp_xor_ctrl(MASK);
+  if constexpr (ctrl >= 0 && RTD_XOR_DPP) {  // one VALU move per dword, no LDS crossbar
+    lo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false);
+  } else {  // ds_swizzle bit-mode: and = 0x1f, or = 0, xor = MASK
+    constexpr int pat = (MASK << 10) | 0x1F;
+    lo = __builtin_amdgcn_ds_swizzle(lo, pat);
+    hi = __builtin_amdgcn_ds_swizzle(hi, pat);
+  }
   return __hiloint2double(hi, lo);
 }
 
