@@ -178,6 +178,7 @@ def main():
 
     dist = None
     gather = None
+    comm_thread = None
     collective = "none (single rank)"
     if world > 1 or a.force_dist:
         import torch.distributed as dist
@@ -192,15 +193,30 @@ def main():
                 print(f"[bench] RCCL unavailable: {e!r}", file=sys.stderr)
         dist.broadcast_object_list(uid, src=0)
         ok = 0
+        comm_thread = None
         if uid[0] is not None:
-            try:
-                plan.comm_init(uid[0], rank, world)
-                plan.run()
-                plan.allgather_fluxes()
-                plan.synchronize()
+            # RCCL bootstrap in a watchdog thread: a rank that cannot reach its peers must not hang the benchmark
+            import threading
+            state = {}
+
+            def bootstrap():
+                try:
+                    plan.comm_init(uid[0], rank, world)
+                    plan.run()
+                    plan.allgather_fluxes()
+                    plan.synchronize()
+                    state["ok"] = True
+                except Exception as e:  # keep the benchmark alive on a misconfigured node
+                    state["err"] = e
+
+            comm_thread = threading.Thread(target=bootstrap, daemon=True)
+            comm_thread.start()
+            comm_thread.join(timeout=float(os.environ.get("RTD_RCCL_TIMEOUT", "120")))
+            if state.get("ok"):
                 ok = 1
-            except Exception as e:  # keep the benchmark alive on a misconfigured node
-                print(f"[bench] rank {rank}: RCCL data plane unavailable: {e!r}", file=sys.stderr)
+            else:
+                print(f"[bench] rank {rank}: RCCL data plane unavailable: {state.get('err', 'bootstrap timed out')!r}",
+                      file=sys.stderr)
         import torch
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -271,6 +287,9 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+        if comm_thread is not None and comm_thread.is_alive():
+            sys.stdout.flush()
+            os._exit(0)  # a rank stuck inside the RCCL bootstrap cannot be joined
 
 
 if __name__ == "__main__":
