@@ -12,11 +12,29 @@ namespace {
 
 constexpr int EVAL_THREADS = 256;
 
-template <int NP>
-__device__ __forceinline__ double group_reduce(double v) {
+// Transposed reduction inside an NP-lane group: every lane enters with NP partial terms v[0..NP) (term i belongs to
+// row i) and leaves with the complete sum of row `jj` -- NP-1 cross-lane moves instead of NP log2(NP).
+template <int NP, int O>
+struct TransposeStep {
+  static __device__ __forceinline__ void run(double (&v)[NP], int jj) {
+    const bool hi = (jj & O) != 0;
 #pragma unroll
-  for (int o = NP / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, NP);
-  return v;
+    for (int i = 0; i < O; ++i) {  // compile-time bounds: v[] stays in registers
+      const double keep = hi ? v[i + O] : v[i];
+      const double send = hi ? v[i] : v[i + O];
+      v[i] = keep + __shfl_xor(send, O, NP);
+    }
+    TransposeStep<NP, O / 2>::run(v, jj);
+  }
+};
+template <int NP>
+struct TransposeStep<NP, 0> {
+  static __device__ __forceinline__ void run(double (&)[NP], int) {}
+};
+template <int NP>
+__device__ __forceinline__ double transpose_reduce(double (&v)[NP], int jj) {
+  TransposeStep<NP, NP / 2>::run(v, jj);
+  return v[0];
 }
 
 template <int NP>
@@ -69,26 +87,36 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
   // down-stream of a quadrature node share the two row sums  P = Y_i . (en+ep),  Qs = A_i . (en-ep)/k
   const int grp = tid / NP, jj = tid % NP;
   constexpr int NGRP = EVAL_THREADS / NP;
-  for (int item = grp; item < M * NP; item += NGRP) {
-    const int m = item / NP, i = item % NP;
+  for (int m = grp; m < M; m += NGRP) {  // one NP-lane group per Fourier mode; lane jj ends up owning node i = jj
     const long ml = ((long)c * M + m) * L + l;
-    const double ps = d.Ym[(ml * NP + i) * NP + jj] * e_s[m * Q + jj];
-    const double qs = d.Am[(ml * NP + i) * NP + jj] * e_s[m * Q + NP + jj];
-    const double P = group_reduce<NP>(ps), Qs = group_reduce<NP>(qs);
-    if (jj < 2) {  // lane 0: up-stream i, lane 1: down-stream i
-      const int i2 = jj == 0 ? i : NP + i;
-      double v = (jj == 0 ? P - Qs : P + Qs) / d.T[i];
-      if (beam) v += d.Bv[ml * Q + i2] * bfac;
-      if (m == 0 && d.Ns > 0) {  // isotropic-source particular solution (subroutines.py:786-862)
-        const double* dq = d.dq + ((long)c * L + l) * d.Ns * Q;
-        double tp = antider ? ts : 1.0;
-        for (int q = 0; q < d.Ns; ++q) {
-          v += dq[q * Q + i2] * (antider ? tp / ((q + 1) * sc) : tp);
-          tp *= ts;
-        }
-      }
-      um[m * Q + i2] = v;
+    const double* Yl = d.Ym + ml * NP * NP + jj;
+    const double* Al = d.Am + ml * NP * NP + jj;
+    const double e1 = e_s[m * Q + jj], e2 = e_s[m * Q + NP + jj];
+    double ps[NP], qs[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      ps[i] = Yl[i * NP] * e1;
+      qs[i] = Al[i * NP] * e2;
     }
+    const double P = transpose_reduce<NP>(ps, jj), Qs = transpose_reduce<NP>(qs, jj);
+    const double it = 1.0 / d.T[jj];
+    double vu = (P - Qs) * it, vd = (P + Qs) * it;
+    if (beam) {
+      vu += d.Bv[ml * Q + jj] * bfac;
+      vd += d.Bv[ml * Q + NP + jj] * bfac;
+    }
+    if (m == 0 && d.Ns > 0) {  // isotropic-source particular solution (subroutines.py:786-862)
+      const double* dq = d.dq + ((long)c * L + l) * d.Ns * Q;
+      double tp = antider ? ts : 1.0;
+      for (int q = 0; q < d.Ns; ++q) {
+        const double f = antider ? tp / ((q + 1) * sc) : tp;
+        vu += dq[q * Q + jj] * f;
+        vd += dq[q * Q + NP + jj] * f;
+        tp *= ts;
+      }
+    }
+    um[m * Q + jj] = vu;
+    um[m * Q + NP + jj] = vd;
   }
   __syncthreads();
   const double rescale = d.rescale[c];
