@@ -79,6 +79,10 @@ __device__ __forceinline__ double approx_rcp(double x) {
   return y * (2.0 - x * y);
 }
 
+#ifndef RTD_EIGEN_WAVES
+#define RTD_EIGEN_WAVES 3  /* waves per SIMD the fused eigen kernel is compiled for (LDS: 10 KB per wave) */
+#endif
+
 // a sweep is the last one when every pair it met had cos^2(angle) <= RTD_JAC_TOL (quadratic convergence
 // squares the residual angle during that sweep)
 #ifndef RTD_JAC_TOL
@@ -126,6 +130,31 @@ template <int NP>
 struct JacobiStep<NP, NP> {
   static __device__ __forceinline__ void run(double (&)[NP], double&, const int, int&) {}
 };
+
+// Transposed reduction: every lane enters with NP terms v[0..NP) (term i belongs to row i) and leaves with the sum of
+// row `j` over the NP lanes of its group -- NP-1 swizzle-adds in registers, no LDS memory.
+template <int NP, int O>
+struct TransposeStep {
+  static __device__ __forceinline__ void run(double (&v)[NP], const int j) {
+    const bool hi = (j & O) != 0;
+#pragma unroll
+    for (int i = 0; i < O; ++i) {
+      const double keep = hi ? v[i + O] : v[i];
+      const double send = hi ? v[i] : v[i + O];
+      v[i] = keep + xor_lane<O>(send);
+    }
+    TransposeStep<NP, O / 2>::run(v, j);
+  }
+};
+template <int NP>
+struct TransposeStep<NP, 0> {
+  static __device__ __forceinline__ void run(double (&)[NP], const int) {}
+};
+template <int NP>
+__device__ __forceinline__ double transpose_reduce(double (&v)[NP], const int j) {
+  TransposeStep<NP, NP / 2>::run(v, j);
+  return v[0];
+}
 
 // sum over the NP lanes of a group (result in every lane)
 template <int NP>
@@ -548,11 +577,10 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
 // total) and the Lw / Qw workspaces.
 // ------------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(64, 2) void rtd_eigen_kernel(RtdDev d) {
+__global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d) {
   constexpr int GPW = 64 / NP;
   constexpr int LD = NP + 1;
   __shared__ double sL[GPW][NP * LD];  // Cholesky factor L of Pm
-  __shared__ double sQ[GPW][NP * LD];  // Qm, later scratch for cross-lane reductions
   __shared__ double sV[GPW][3][NP];
   const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
   const ProbId id = locate<NP>(d);
@@ -560,8 +588,6 @@ __global__ __launch_bounds__(64, 2) void rtd_eigen_kernel(RtdDev d) {
   const bool valid = id.valid;
   const long base = id.pid;
   double* L_ = sL[grp];
-  double* Q_ = sQ[grp];
-  double* R_ = Q_;  // the beam stage is done with Qm before it needs scratch; the thermal stage runs after it
   double* v0 = sV[grp][0];
   double* v1 = sV[grp][1];
   double* v2 = sV[grp][2];
@@ -607,7 +633,6 @@ __global__ __launch_bounds__(64, 2) void rtd_eigen_kernel(RtdDev d) {
       const double Si = d.S[i];
       pcol[i] = (i == j ? invmu_j : 0.0) - Si * acc_e[i] * S_j;  // Pm = M^-1 - S Ae S
       qcol[i] = (i == j ? invmu_j : 0.0) - Si * acc_o[i] * S_j;  // Qm = M^-1 - S Ao S
-      Q_[i * LD + j] = qcol[i];
     }
     cholesky_columns<NP>(pcol, j);  // Pm = L L^T
     cholesky_columns<NP>(qcol, j);  // Qm = R R^T
@@ -647,7 +672,7 @@ __global__ __launch_bounds__(64, 2) void rtd_eigen_kernel(RtdDev d) {
 
   // eigenvector blocks (:190-198): V = T^-1 L^-T Z, U = (alpha+beta) V / k = -T^-1 L Z / k; stored as
   // Y = L^-T Z and A = L Z, from which Gp = (Y - A/k)/T, Gm = (Y + A/k)/T, V^-1 = A^T T, U^-1 = -k Y^T T
-  double ya[NP], aa[NP];
+  double ya[NP];
 #pragma unroll
   for (int i = NP - 1; i >= 0; --i) {
     double a = zc[i];
@@ -656,22 +681,10 @@ __global__ __launch_bounds__(64, 2) void rtd_eigen_kernel(RtdDev d) {
     ya[i] = a / L_[i * LD + i];
     RTD_FENCE();
   }
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    double a = 0.0;
-#pragma unroll
-    for (int r = 0; r <= i; ++r) a += L_[i * LD + r] * zc[r];
-    aa[i] = a;
-    RTD_FENCE();
-  }
   if (valid) {
     double* Ym = d.Ym + base * NP * NP;
-    double* Am = d.Am + base * NP * NP;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      Ym[i * NP + j] = ya[i];
-      Am[i * NP + j] = aa[i];
-    }
+    for (int i = 0; i < NP; ++i) Ym[i * NP + j] = ya[i];
     d.kk[base * NP + j] = kj;
     const double* ts0 = d.taus0 + (long)c * (d.L + 1);
     d.Ek[base * NP + j] = exp(-kj * (ts0[l + 1] - ts0[l]));
@@ -697,9 +710,19 @@ __global__ __launch_bounds__(64, 2) void rtd_eigen_kernel(RtdDev d) {
     const double txd = 2.0 * T_j * xe * invmu_j;  // T (x+ - x-)
     v0[j] = txd;
     __syncthreads();
-    double qv = 0.0;
+    // Qm v0 through Qm = L^-T H L^-1 = Y k^2 Y^T (exact for the rotated columns whatever their convergence):
+    // lane e forms k_e^2 (Y^T v0)_e, the sum over the eigen-index is a transposed reduction in registers
+    double qv;
+    {
+      double tq = 0.0;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) qv += Q_[i * LD + j] * v0[i];
+      for (int i = 0; i < NP; ++i) tq += ya[i] * v0[i];
+      tq *= k2;
+      double x[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) x[i] = ya[i] * tq;
+      qv = transpose_reduce<NP>(x, j);
+    }
     const double rhat = 2.0 * T_j * xo * invmu_j / mu0 - qv;
     v1[j] = rhat;
     __syncthreads();
@@ -712,13 +735,14 @@ __global__ __launch_bounds__(64, 2) void rtd_eigen_kernel(RtdDev d) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) h += zc[i] * v2[i];
     h /= (1.0 / (mu0 * mu0) - k2);
-    // e = Z h (cross-lane sum through LDS)
+    // e = Z h (sum over the eigen-index = lanes)
+    double e;
+    {
+      double x[NP];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) R_[i * LD + j] = zc[i] * h;
-    __syncthreads();
-    double e = 0.0;
-#pragma unroll
-    for (int r = 0; r < NP; ++r) e += R_[j * LD + r];
+      for (int i = 0; i < NP; ++i) x[i] = zc[i] * h;
+      e = transpose_reduce<NP>(x, j);
+    }
     // shat = L^-T e by back substitution distributed over the lanes
     double sh = 0.0;
     static_for<0, NP>([&](auto ic) {
@@ -746,11 +770,26 @@ __global__ __launch_bounds__(64, 2) void rtd_eigen_kernel(RtdDev d) {
     }
   }
   __syncthreads();
+  // A = L Z after the beam stage: its 2 NP registers are not live while that stage runs
+  double aa[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    double a = 0.0;
+#pragma unroll
+    for (int r = 0; r <= i; ++r) a += L_[i * LD + r] * zc[r];
+    aa[i] = a;
+    RTD_FENCE();
+  }
+  if (valid) {
+    double* Am = d.Am + base * NP * NP;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) Am[i * NP + j] = aa[i];
+  }
 
   // isotropic (thermal) source, Fourier mode 0 only (subroutines.py:746-862, _assemble.py:124).
-  // Every group runs the barriers below; only groups with m == 0 store.
-  if (d.Ns > 0) {
-    const bool act = (m == 0);
+  // A wave holds layers of ONE (c, m), so the branch is wave-uniform.
+  if (d.Ns > 0 && m == 0) {
+    const bool act = true;
     // q = L^-1 (T / mu) by forward substitution distributed over the lanes
     double cur = T_j * invmu_j, q_j = 0.0;
     static_for<0, NP>([&](auto ic) {
@@ -782,20 +821,16 @@ __global__ __launch_bounds__(64, 2) void rtd_eigen_kernel(RtdDev d) {
       // up-streams: Gp a + Gm b ; down-streams: Gm a + Gp b  (sum over eigen-index = lanes), with
       // Gp = (Y - A/k)/T, Gm = (Y + A/k)/T:  up = [Y (a+b) - A (a-b)/k]/T, down = [Y (a+b) + A (a-b)/k]/T
       const double sab = a + b, dab = (a - b) * rk;
-      __syncthreads();
+      double xu[NP], xd[NP];
 #pragma unroll
-      for (int i = 0; i < NP; ++i) R_[i * LD + j] = (ya[i] * sab - aa[i] * dab) / d.T[i];
-      __syncthreads();
-      double up = 0.0;
-#pragma unroll
-      for (int r = 0; r < NP; ++r) up += R_[j * LD + r];
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < NP; ++i) R_[i * LD + j] = (ya[i] * sab + aa[i] * dab) / d.T[i];
-      __syncthreads();
-      double dn = 0.0;
-#pragma unroll
-      for (int r = 0; r < NP; ++r) dn += R_[j * LD + r];
+      for (int i = 0; i < NP; ++i) {
+        const double py = ya[i] * sab, pa = aa[i] * dab;
+        xu[i] = py - pa;
+        xd[i] = py + pa;
+      }
+      const double rT = 1.0 / T_j;
+      const double up = transpose_reduce<NP>(xu, j) * rT;
+      const double dn = transpose_reduce<NP>(xd, j) * rT;
       if (valid && act) {
         double* dq = d.dq + (((long)c * d.L + l) * d.Ns + q) * 2 * NP;
         dq[j] = up;
