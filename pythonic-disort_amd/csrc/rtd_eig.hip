@@ -191,37 +191,33 @@ __device__ __forceinline__ double bcast_lane(double v) {
 }
 
 // In-register Cholesky of a symmetric positive definite matrix held one column per lane (col[i] = A[i][j]);
-// on exit col[i] = L[i][j] for i >= j and 0 above the diagonal.  The trailing matrix is kept symmetric so
-// that L[j][k] is available in the lane's own registers; the updates are branch-free.
+// on exit col[i] = L[i][j] for i >= j and 0 above the diagonal; returns 1 / L[j][j].  The trailing matrix is kept
+// symmetric so that A^(K)[j][K] is available in the lane's own registers, and the scaling of a finished column by
+// 1/sqrt(pivot) is deferred to the end: a step is one broadcast and one FMA per element,
+//   col_j[i] -= A^(K)[i][K] * A^(K)[j][K] / A^(K)[K][K]   for j > K (factor 0 for the finished columns j <= K).
 template <int NP, int K>
 struct CholStep {
-  static __device__ __forceinline__ void run(double (&col)[NP], const int j) {
+  static __device__ __forceinline__ void run(double (&col)[NP], double& diag, const int j) {
     const double akk = bcast_lane<NP, K>(col[K]);
-    const double rinv = fast_rsqrt(akk);
-    // one formula for every lane: col[i] <- col[i] * scale - L[i][K] * ljk
-    //   owner of column K (j == K): scale = 1/sqrt(akk), ljk = 0   ->  L[i][K]
-    //   trailing columns  (j > K):  scale = 1, ljk = L[j][K] (by symmetry)  ->  rank-1 update
-    //   finished columns  (j < K):  scale = 1, ljk = 0  ->  unchanged
-    const double ljk = (j > K) ? col[K] * rinv : 0.0;
-    const double scale = (j == K) ? rinv : 1.0;
+    const double f = (j > K) ? col[K] * fast_rcp(akk) : 0.0;
+    diag = (j == K) ? akk : diag;
 #pragma unroll
-    for (int i = K + 1; i < NP; ++i) {
-      const double lik = bcast_lane<NP, K>(col[i]) * rinv;
-      col[i] = fma(-lik, ljk, col[i] * scale);
-    }
-    col[K] = (j == K) ? akk * rinv : col[K];
-    CholStep<NP, K + 1>::run(col, j);
+    for (int i = K + 1; i < NP; ++i) col[i] = fma(-bcast_lane<NP, K>(col[i]), f, col[i]);
+    CholStep<NP, K + 1>::run(col, diag, j);
   }
 };
 template <int NP>
 struct CholStep<NP, NP> {
-  static __device__ __forceinline__ void run(double (&)[NP], const int) {}
+  static __device__ __forceinline__ void run(double (&)[NP], double&, const int) {}
 };
 template <int NP>
-__device__ __forceinline__ void cholesky_columns(double (&col)[NP], const int j) {
-  CholStep<NP, 0>::run(col, j);
+__device__ __forceinline__ double cholesky_columns(double (&col)[NP], const int j) {
+  double diag = 1.0;
+  CholStep<NP, 0>::run(col, diag, j);
+  const double rinv = fast_rsqrt(diag);
 #pragma unroll
-  for (int i = 0; i < NP; ++i) col[i] = (i >= j) ? col[i] : 0.0;
+  for (int i = 0; i < NP; ++i) col[i] = (i >= j) ? col[i] * rinv : 0.0;
+  return rinv;
 }
 
 // problem index of this lane's group; invalid groups redo the last layer and skip their stores
@@ -581,7 +577,7 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
   constexpr int GPW = 64 / NP;
   constexpr int LD = NP + 1;
   __shared__ double sL[GPW][NP * LD];  // Cholesky factor L of Pm
-  __shared__ double sV[GPW][3][NP];
+  __shared__ double sV[GPW][4][NP];
   const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
   const ProbId id = locate<NP>(d);
   const int P = d.P, m = id.m, c = id.c, l = id.l;
@@ -591,6 +587,7 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
   double* v0 = sV[grp][0];
   double* v1 = sV[grp][1];
   double* v2 = sV[grp][2];
+  double* dinv = sV[grp][3];  // 1 / L[i][i]
   const double* wl = d.wleg + ((long)c * d.L + l) * P;
   const double om = d.omega[(long)c * d.L + l];
   const double* Ym = d.Y + (long)m * P * NP;
@@ -634,7 +631,7 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
       pcol[i] = (i == j ? invmu_j : 0.0) - Si * acc_e[i] * S_j;  // Pm = M^-1 - S Ae S
       qcol[i] = (i == j ? invmu_j : 0.0) - Si * acc_o[i] * S_j;  // Qm = M^-1 - S Ao S
     }
-    cholesky_columns<NP>(pcol, j);  // Pm = L L^T
+    dinv[j] = cholesky_columns<NP>(pcol, j);  // Pm = L L^T
     cholesky_columns<NP>(qcol, j);  // Qm = R R^T
 #pragma unroll
     for (int i = 0; i < NP; ++i) L_[i * LD + j] = pcol[i];
@@ -662,10 +659,9 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
   double k2 = 0.0;
 #pragma unroll
   for (int i = 0; i < NP; ++i) k2 += w[i] * w[i];
-  const double kj = sqrt(k2);
+  const double rk0 = fast_rsqrt(k2), kj = k2 * rk0;
   double zc[NP];
   {
-    const double rk0 = 1.0 / kj;
 #pragma unroll
     for (int i = 0; i < NP; ++i) zc[i] = w[i] * rk0;
   }
@@ -678,7 +674,7 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
     double a = zc[i];
 #pragma unroll
     for (int r = i + 1; r < NP; ++r) a -= L_[r * LD + i] * ya[r];
-    ya[i] = a / L_[i * LD + i];
+    ya[i] = a * dinv[i];
     RTD_FENCE();
   }
   if (valid) {
@@ -695,7 +691,7 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
   //  T dd = mu0 [ T (x+ - x-) - Pm T s ],  Qm Pm = L^-T Z k^2 Z^T L^T
   if (d.beam) {
     const double mu0 = d.mu0[c];
-    const double fac = d.I0[c] / (4.0 * M_PI) * (m == 0 ? 1.0 : 2.0) * om;
+    const double fac = d.I0[c] * (0.25 / M_PI) * (m == 0 ? 1.0 : 2.0) * om;
     const double* Y0 = d.Y0 + ((long)c * d.M + m) * P;
     double xe = 0.0, xo = 0.0, cmax = 0.0;  // X^e_j, X^o_j of this lane's stream
     for (int ell = m; ell < P; ell += 2) {
@@ -723,7 +719,8 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
       for (int i = 0; i < NP; ++i) x[i] = ya[i] * tq;
       qv = transpose_reduce<NP>(x, j);
     }
-    const double rhat = 2.0 * T_j * xo * invmu_j / mu0 - qv;
+    const double rmu0 = fast_rcp(mu0);
+    const double rhat = 2.0 * T_j * xo * invmu_j * rmu0 - qv;
     v1[j] = rhat;
     __syncthreads();
     double g = 0.0;  // g = L^T rhat
@@ -734,7 +731,7 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
     double h = 0.0;  // h = Z^T g / (1/mu0^2 - k^2)
 #pragma unroll
     for (int i = 0; i < NP; ++i) h += zc[i] * v2[i];
-    h /= (1.0 / (mu0 * mu0) - k2);
+    h *= fast_rcp(rmu0 * rmu0 - k2);
     // e = Z h (sum over the eigen-index = lanes)
     double e;
     {
@@ -747,7 +744,7 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
     double sh = 0.0;
     static_for<0, NP>([&](auto ic) {
       constexpr int i = NP - 1 - decltype(ic)::value;
-      const double si = bcast_lane<NP, i>(e) / L_[i * LD + i];
+      const double si = bcast_lane<NP, i>(e) * dinv[i];
       sh = (j == i) ? si : sh;
       e -= (j < i) ? L_[i * LD + j] * si : 0.0;
     });
@@ -761,7 +758,7 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
     double ps = 0.0;  // Pm shat = L t
 #pragma unroll
     for (int r = 0; r < NP; ++r) ps += L_[j * LD + r] * v2[r];
-    const double rT = 1.0 / T_j;
+    const double rT = fast_rcp(T_j);
     const double s_j = sh * rT;
     const double d_j = mu0 * (txd - ps) * rT;
     if (valid) {
@@ -794,7 +791,7 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
     double cur = T_j * invmu_j, q_j = 0.0;
     static_for<0, NP>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      const double qi = bcast_lane<NP, i>(cur) / L_[i * LD + i];
+      const double qi = bcast_lane<NP, i>(cur) * dinv[i];
       q_j = (j == i) ? qi : q_j;
       cur -= (j > i) ? L_[j * LD + i] * qi : 0.0;
     });
@@ -806,7 +803,7 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
     zn *= -0.5 * kj;
     if (valid && act) d.zneg[((long)c * d.L + l) * NP + j] = zn;
     const double* sp = d.spoly + ((long)c * d.L + l) * d.Ns;
-    const double rk = 1.0 / kj;
+    const double rk = rk0;
     for (int q = 0; q < d.Ns; ++q) {
       // b_q(K) = sum_{jj>=q} jj!/q! a_jj K^-(jj-q+1), K = -k (first N eigen-columns) and +k
       double bneg = 0.0, bpos = 0.0, ratio = 1.0, pw_pos = rk, pw_neg = -rk;
