@@ -60,7 +60,7 @@ __device__ __forceinline__ double group_max(double v) {
 // xor-1 and xor-2 quad permutes, row_half_mirror, row_mirror; one v_max_f32 each.
 template <int CTRL>
 __device__ __forceinline__ float dpp_max_f32(float v) {
-  const int o = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false);
+  const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
   return fmaxf(v, __int_as_float(o));
 }
 template <int NP>
@@ -103,8 +103,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int K>
 __device__ __forceinline__ double bcast16(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + K, 0xF, 0xF, false);  // row_newbcast:K (every source lane exists: `old` is never used)
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + K, 0xF, 0xF, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xF, 0xF, true);  // row_newbcast:K; bound_ctrl + full masks: no `old` operand, no copy
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 
@@ -334,7 +334,7 @@ struct GjStep {
       // constant and the pivot row travels by DPP row broadcasts (VALU) instead of ds_bpermute (LDS crossbar, the
       // pipe that bounds this kernel).  ~95 % of the steps of real atmospheres qualify; the others take the fully
       // pivoted path below.  Growth is bounded as in partial pivoting with threshold 1/4.
-      const int kd = __builtin_amdgcn_update_dpp(0, __float_as_int(key), 0x150 + K, 0xF, 0xF, false);
+      const int kd = __builtin_amdgcn_update_dpp(0, __float_as_int(key), 0x150 + K, 0xF, 0xF, true);
       fast = __all(__int_as_float(kd) >= 0.25f * kmax && __int_as_float(kd) > 0.0f);
     }
     if (fast) {
@@ -627,6 +627,493 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_SWEEP_WAVES : 1)) void rtd_swee
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fused boundary-condition kernel, NP = 16: ONE wavefront per (column, mode) does the interface operators, the
+// forward carry recursion, the bottom boundary and the backward sweep, with every 16 x 16 matrix held in the
+// operand / accumulator layout of v_mfma_f64_16x16x4_f64 ("D layout": lane = 16 kq + col, register q holds the
+// element [row 4 q + kq][col]).  In that layout one MFMA chain gives X^T Y for two D-layout matrices, X^T for
+// Y = I, so the recursion is carried in transposed form:
+//      H = S^T ,   Ta'^T = -(Wq^T (H E) + Wp^T) ,   Tb'^T = -E' (Wp^T (H E) + Wq^T) ,   H' = Tb'^T Ta'^-T
+// (column-pivoted Gauss-Jordan on the stacked rows [Ta'^T ; Tb'^T ; t'^T]: columns = lanes, the same elimination
+// as the two-kernel path seen through a transpose).  W and W^T come from the eigen stage's Y, A straight from HBM
+// (each layer is read once per direction); nothing but H_l, s_l and rho_b is stored for the backward sweep, which
+// applies W through its factors:  Wq x + Wp y = [A_l^T Y' (x + y) + k_l Y_l^T A' ((y - x)/k')] / 2.
+// Against the two-kernel path this removes the Wp/Wq round trip through HBM (about 40 % of the stage's traffic).
+// ------------------------------------------------------------------------------------------------
+#ifndef RTD_BCF_WAVES
+#define RTD_BCF_WAVES 3
+#endif
+
+__device__ __forceinline__ v4f64 mm_t(const v4f64& X, const v4f64& Y) {  // X^T Y
+  v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[0], Y[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[1], Y[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[2], Y[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[3], Y[3], acc, 0, 0, 0);
+  return acc;
+}
+// sum over the four lane-rows (kq) of the wavefront; the result is replicated over them
+__device__ __forceinline__ double sum_kq(double p) {
+  p += xor_lane<16>(p);
+  p += __shfl_xor(p, 32, 64);
+  return p;
+}
+// sum_rows X[r][col] v[r]  with v in row form (register q = v[4 q + kq]); result in column form
+__device__ __forceinline__ double col_dot(const v4f64& X, const v4f64& vr) {
+  return sum_kq(X[0] * vr[0] + X[1] * vr[1] + X[2] * vr[2] + X[3] * vr[3]);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return v + __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a lane-row (replicated over them): quad permutes, half mirror, mirror
+__device__ __forceinline__ double row_sum16(double v) {
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  v = dpp_add<0x140>(v);
+  return v;
+}
+// sum_cols X[row][c] u[c]  with u in column form; result in row form
+__device__ __forceinline__ v4f64 row_dot(const v4f64& X, const double uc) {
+  v4f64 r;
+  r[0] = row_sum16(X[0] * uc);
+  r[1] = row_sum16(X[1] * uc);
+  r[2] = row_sum16(X[2] * uc);
+  r[3] = row_sum16(X[3] * uc);
+  return r;
+}
+// column form -> row form of a 16-vector
+__device__ __forceinline__ v4f64 col_to_row(const double vc, const int rowbase, const int kq) {
+  v4f64 r;
+  r[0] = bperm((rowbase | kq) << 2, vc);
+  r[1] = bperm((rowbase | (4 + kq)) << 2, vc);
+  r[2] = bperm((rowbase | (8 + kq)) << 2, vc);
+  r[3] = bperm((rowbase | (12 + kq)) << 2, vc);
+  return r;
+}
+__device__ __forceinline__ double push_lane(int addr, double v) {  // this lane's v lands in lane addr / 4
+  const int lo = __builtin_amdgcn_ds_permute(addr, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_permute(addr, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// Column-pivoted Gauss-Jordan on the stacked rows [Ta^T ; Tb^T (NB registers) ; t^T]: step K makes row K of Ta^T a
+// unit vector.  The pivot is the largest unused column of that row (threshold 1/4 in favour of the diagonal, as
+// in GjStep); on exit the lane-column that was the pivot of step pc holds column pc of Tb^T Ta^-T and t^T Ta^-T.
+template <int NB, int K>
+struct GjT {
+  static __device__ __forceinline__ void run(double (&ta)[4], double (&tb)[4], double& tv, int& pc, const int col, const int rowbase) {
+    constexpr int QK = K >> 2, RK = K & 3;
+    const double x = bperm(((RK << 4) | col) << 2, ta[QK]);  // row K of Ta^T, replicated over the lane-rows
+    const float key = (pc < 0) ? fabsf((float)x) : -1.0f;
+    const float kmax = group_max_key<16>(key);
+    const float kd = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(key), 0x150 + K, 0xF, 0xF, true));
+    const bool fast = __all(kd >= 0.25f * kmax && kd > 0.0f);
+    double f, rp;
+    bool isp;
+    if (fast) {
+      isp = (col == K);
+      rp = fast_rcp(bcast16<K>(x));
+      f = isp ? 0.0 : x * rp;
+      static_for<QK, 4>([&](auto qc) {  // rows below 4 QK are finished: the pivot column is zero there
+        constexpr int q = decltype(qc)::value;
+        ta[q] -= f * bcast16<K>(ta[q]);
+      });
+      static_for<0, NB>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        tb[q] -= f * bcast16<K>(tb[q]);
+      });
+      tv -= f * bcast16<K>(tv);
+    } else {
+      const unsigned int bits = (unsigned int)(__ballot(key == kmax) & 0xffffull);
+      const int src = __ffs((int)bits) - 1;
+      isp = (col == src);
+      const int addr = (rowbase | src) << 2;
+      rp = fast_rcp(bperm(addr, x));
+      f = isp ? 0.0 : x * rp;
+      static_for<QK, 4>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        ta[q] -= f * bperm(addr, ta[q]);
+      });
+      static_for<0, NB>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        tb[q] -= f * bperm(addr, tb[q]);
+      });
+      tv -= f * bperm(addr, tv);
+    }
+    if (isp) {
+      pc = K;
+      static_for<QK, 4>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        ta[q] *= rp;
+      });
+      static_for<0, NB>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        tb[q] *= rp;
+      });
+      tv *= rp;
+    }
+    GjT<NB, K + 1>::run(ta, tb, tv, pc, col, rowbase);
+  }
+};
+template <int NB>
+struct GjT<NB, 16> {
+  static __device__ __forceinline__ void run(double (&)[4], double (&)[4], double&, int&, const int, const int) {}
+};
+
+// Speculative, branch-free form of the same elimination with the diagonal as pivot at every step: straight-line
+// code (the 16 steps schedule into each other), no pivot search.  A step whose diagonal candidate is more than a
+// factor RTD_GJ_GROWTH smaller than another unused entry of its row (or zero) raises `bad`; the caller then
+// repeats the elimination from its saved inputs with the pivoted GjT.  On the benchmark atmospheres 95 % of the
+// eliminations pass (tools/..., RTD_BC_STATS experiment in DESIGN.md).
+// The pivot column is scaled by the same FMA as the others: its own broadcast value is itself, so f = 1 - 1/pivot
+// gives v - f v = v / pivot.
+#ifndef RTD_GJ_GROWTH
+#define RTD_GJ_GROWTH 8.0
+#endif
+template <int NB, int K>
+struct GjFast {
+  static __device__ __forceinline__ void run(double (&ta)[4], double (&tb)[4], double& tv, int& bad, const int col) {
+    constexpr int QK = K >> 2, RK = K & 3;
+    const double x = bperm(((RK << 4) | col) << 2, ta[QK]);  // row K of Ta^T, replicated over the lane-rows
+    const double xk = bcast16<K>(x);
+    const double ax = (col > K) ? fabs(x) : 0.0, lim = RTD_GJ_GROWTH * fabs(xk);
+    bad |= (ax > lim) ? 1 : 0;
+    bad |= (lim > 0.0) ? 0 : 1;
+    const double rp = fast_rcp(xk);
+    const double f = (col == K) ? 1.0 - rp : x * rp;
+    static_for<QK, 4>([&](auto qc) {  // rows below 4 QK are finished: the pivot column is zero there
+      constexpr int q = decltype(qc)::value;
+      ta[q] = fma(-f, bcast16<K>(ta[q]), ta[q]);
+    });
+    static_for<0, NB>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      tb[q] = fma(-f, bcast16<K>(tb[q]), tb[q]);
+    });
+    tv = fma(-f, bcast16<K>(tv), tv);
+    GjFast<NB, K + 1>::run(ta, tb, tv, bad, col);
+  }
+};
+template <int NB>
+struct GjFast<NB, 16> {
+  static __device__ __forceinline__ void run(double (&)[4], double (&)[4], double&, int&, const int) {}
+};
+
+__global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
+  constexpr int NP = 16, Q = 32, NN = NP * NP;
+  const int lane = threadIdx.x, kq = lane >> 4, col = lane & 15, rowbase = lane & 48;
+  const long cm = blockIdx.x;
+  const int m = (int)(cm % d.M), c = (int)(cm / d.M);
+  const int L = d.L, Lm1 = L - 1;
+  const double* Ym = d.Ym + cm * L * NN;
+  const double* Am = d.Am + cm * L * NN;
+  const double* kk = d.kk + cm * L * NP;
+  const double* Ek = d.Ek + cm * L * NP;
+  const double* Bv = d.Bv + cm * L * Q;
+  const double* ts0 = d.taus0 + (long)c * (L + 1);
+  const double* dq = d.dq + (long)c * L * d.Ns * Q;
+  double* wsb = d.Fws + cm * Lm1 * Ws<NP>::SLOT;
+  double* coef = d.coef + cm * L * Q;
+  const bool iso = d.Ns > 0 && m == 0;
+  const bool beam = d.beam != 0;
+  const double mu0 = beam ? d.mu0[c] : 1.0;
+  auto vpoly = [&](int l, double t, int idx) {
+    double a = 0.0, tp = 1.0;
+    for (int q = 0; q < d.Ns; ++q) {
+      a += dq[((long)l * d.Ns + q) * Q + idx] * tp;
+      tp *= t;
+    }
+    return a;
+  };
+  // (kq, col are passed in so that the loops can hand over an opaque copy of the lane index: the compiler then
+  //  rebuilds the few address VGPRs per iteration instead of keeping dozens of hoisted ones alive and spilling)
+  auto load_d = [](const double* p, const int kq, const int col) {  // row-major 16 x 16 matrix -> D layout
+    v4f64 x;
+    x[0] = p[kq * NP + col];
+    x[1] = p[(4 + kq) * NP + col];
+    x[2] = p[(8 + kq) * NP + col];
+    x[3] = p[(12 + kq) * NP + col];
+    return x;
+  };
+  auto load_row = [](const double* p, const int kq) {  // a 16-vector in row form
+    v4f64 x;
+    x[0] = p[kq];
+    x[1] = p[4 + kq];
+    x[2] = p[8 + kq];
+    x[3] = p[12 + kq];
+    return x;
+  };
+  auto make_eye = [](const int kq, const int col) {
+    v4f64 e;
+    e[0] = (kq == col) ? 1.0 : 0.0;
+    e[1] = (4 + kq == col) ? 1.0 : 0.0;
+    e[2] = (8 + kq == col) ? 1.0 : 0.0;
+    e[3] = (12 + kq == col) ? 1.0 : 0.0;
+    return e;
+  };
+  const double rT_col = fast_rcp(d.T[col]);
+
+  __shared__ double sSave[9][64];  // inputs of the running elimination, read back only when its speculation fails
+  v4f64 a0 = load_d(Am, kq, col), y0 = load_d(Ym, kq, col);
+  const int lsecond = min(1, Lm1);
+  v4f64 a1 = load_d(Am + (long)lsecond * NN, kq, col), y1 = load_d(Ym + (long)lsecond * NN, kq, col);
+  double k0c = kk[col], k1c = kk[lsecond * NP + col];
+  // carry rows (transposed): top boundary, down-streams at tau = 0 (:161-179, :284-285):
+  //   Ta = Gm_0 = (Y + A/k)/T-rows,  Tb = Gp_0 E_0 = (Y - A/k)/T-rows E_0
+  double ta[4], tb[4];
+  {
+    const v4f64 eye = make_eye(kq, col);
+    const v4f64 yt = mm_t(y0, eye), at = mm_t(a0, eye);
+    const v4f64 k_row = load_row(kk, kq), e_row = load_row(Ek, kq);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double av = at[q] * fast_rcp(k_row[q]);
+      ta[q] = (yt[q] + av) * rT_col;
+      tb[q] = (yt[q] - av) * rT_col * e_row[q];
+    }
+  }
+  double tv = d.bneg[cm * NP + col];
+  if (beam) tv -= Bv[NP + col];
+  if (iso) tv -= dq[NP + col];
+
+  for (int l = 0; l < L; ++l) {
+    // ---- loads: layer l+2's operands (consumed by the NEXT iteration: a full elimination hides their HBM latency)
+    //      and this interface's small vectors (consumed after the elimination)
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const int kq = lv >> 4, col = lv & 15, rowbase = lv & 48;
+    const int ln = min(l + 1, Lm1), l2 = min(l + 2, Lm1);
+    const v4f64 a2 = load_d(Am + (long)l2 * NN, kq, col), y2 = load_d(Ym + (long)l2 * NN, kq, col);
+    const double k2c = kk[l2 * NP + col];
+    const double e0c = Ek[l * NP + col];
+    const v4f64 e1r = load_row(Ek + ln * NP, kq);
+    // ---- elimination: [Ta^T ; Tb^T ; t^T] -> H = S^T (in tb), s (in tv)
+    {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        sSave[q][lane] = ta[q];
+        sSave[4 + q][lane] = tb[q];
+      }
+      sSave[8][lane] = tv;
+      int bad = 0;
+      GjFast<4, 0>::run(ta, tb, tv, bad, col);
+      if (__any(bad)) {  // some diagonal pivot was too small: pivoted elimination from the saved inputs
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          ta[q] = sSave[q][lane];
+          tb[q] = sSave[4 + q][lane];
+        }
+        tv = sSave[8][lane];
+        int pc = -1;
+        GjT<4, 0>::run(ta, tb, tv, pc, col, rowbase);
+        if (__any(pc != col)) {  // bring the columns back to their natural order
+          const int addr = (rowbase | pc) << 2;
+          tb[0] = push_lane(addr, tb[0]);
+          tb[1] = push_lane(addr, tb[1]);
+          tb[2] = push_lane(addr, tb[2]);
+          tb[3] = push_lane(addr, tb[3]);
+          tv = push_lane(addr, tv);
+        }
+      }
+    }
+    if (l == Lm1) break;
+    double* ws = wsb + (long)l * Ws<NP>::SLOT;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ws[Ws<NP>::S + (4 * q + kq) * NP + col] = tb[q];
+    if (kq == 0) ws[Ws<NP>::SV + col] = tv;
+    v4f64 bu0 = {0.0, 0.0, 0.0, 0.0}, bd0 = bu0, bu1 = bu0, bd1 = bu0;
+    if (beam) {
+      bu0 = load_row(Bv + l * Q, kq);
+      bd0 = load_row(Bv + l * Q + NP, kq);
+      bu1 = load_row(Bv + ln * Q, kq);
+      bd1 = load_row(Bv + ln * Q + NP, kq);
+    }
+    // ---- interface products  M1 = A_l^T Y',  M2s = diag(k) Y_l^T A' diag(1/k')  and their transposes; the diagonal
+    //      scalings are column scalings of the operands
+    v4f64 y0s, a1s;
+    {
+      const double rk1c = fast_rcp(k1c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        y0s[q] = y0[q] * k0c;
+        a1s[q] = a1[q] * rk1c;
+      }
+    }
+    const v4f64 m1 = mm_t(a0, y1), m1t = mm_t(y1, a0), m2s = mm_t(y0s, a1s), m2st = mm_t(a1s, y0s);
+    // particular-solution jump r_l at the interface (:184-205, :242-245) and rho = G_l^-1 r_l:
+    //   rho_t/b = 1/4 [ V^-1 (r_up + r_dn) +- U^-1 (r_up - r_dn) ],  V^-1[j][i] = T_i A[i][j],  U^-1[j][i] = -k_j T_i Y[i][j]
+    const double tbnd = ts0[l + 1];
+    const double att = beam ? exp(-tbnd / mu0) : 0.0;
+    const v4f64 t_row = load_row(d.T, kq);
+    double rt = 0.0, rb = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int i = 4 * s + kq;
+      double ru = (bu1[s] - bu0[s]) * att, rd = (bd1[s] - bd0[s]) * att;
+      if (iso) {
+        ru += vpoly(l + 1, tbnd, i) - vpoly(l, tbnd, i);
+        rd += vpoly(l + 1, tbnd, NP + i) - vpoly(l, tbnd, NP + i);
+      }
+      const double pa = t_row[s] * a0[s] * (ru + rd), pb = -t_row[s] * y0s[s] * (ru - rd);
+      rt += pa + pb;
+      rb += pa - pb;
+    }
+    rt = 0.25 * sum_kq(rt);
+    rb = 0.25 * sum_kq(rb);
+    if (kq == 0) ws[Ws<NP>::RB + col] = rb;
+    // ---- carry of the next layer:  Ta'^T = -(Wq^T H E + Wp^T),  Tb'^T = -E' (Wp^T H E + Wq^T)  with
+    //      Wp/Wq = (M1 +- M2s)/2:  X = M1^T H E, Z = M2s^T H E
+    v4f64 he;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) he[q] = tb[q] * e0c;
+    const v4f64 xx = mm_t(m1, he), zz = mm_t(m2s, he);
+    const v4f64 hcur = {tb[0], tb[1], tb[2], tb[3]};
+    const double tnew = rt - e0c * (tv - col_dot(hcur, col_to_row(rb, rowbase, kq)));  // t' = rho_t - E (s - S rho_b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ta[q] = -0.5 * (xx[q] - zz[q] + m1t[q] + m2st[q]);
+      tb[q] = -0.5 * (xx[q] + zz[q] + m1t[q] - m2st[q]) * e1r[q];
+    }
+    tv = tnew;
+    a0 = a1;
+    y0 = y1;
+    a1 = a2;
+    y1 = y2;
+    k0c = k1c;
+    k1c = k2c;
+  }
+
+  // ---- bottom boundary (up-streams at tau_L) (:208-232, :248-254, :288-293):  Ba C- + Bb C+ = br,
+  //      with C- = s - S C+  ->  (Bb - Ba S) C+ = br - Ba s;  Ba = [(I - R) P0 - (I + R) Q0] E_L, Bb = (I - R) P0 + (I + R) Q0,
+  //      P0 = Y/T-rows, Q0 = A/(k T-rows), R = (1 + delta_m0) q (mu w).  Solved transposed like the carry.
+  double cminus, cplus;
+  {
+    const int l = Lm1;
+    const double rkLc = fast_rcp(kk[l * NP + col]);
+    const v4f64 eLr = load_row(Ek + l * NP, kq), t_row = load_row(d.T, kq), eye = make_eye(kq, col);
+    v4f64 p0, q0, x1 = eye, x2 = eye, rtr = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double rTr = fast_rcp(t_row[q]);
+      p0[q] = y0[q] * rTr;
+      q0[q] = a0[q] * rTr * rkLc;
+    }
+    const bool refl = m < d.NBDRF;
+    if (refl) {
+      const double delta = (m == 0) ? 2.0 : 1.0;
+      const double* qt = d.bdrfq + (((long)c * d.NBDRF + m) * NP + col) * NP;  // row j = col of q^m
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j2 = 4 * q + kq;
+        const double r = delta * qt[j2] * d.mu[j2] * d.w[j2];  // R^T in the D layout: [row j2][col j] = R[j][j2]
+        rtr[q] = r;
+        x1[q] -= r;
+        x2[q] += r;
+      }
+    }
+    const v4f64 g1 = mm_t(p0, x1), g2 = mm_t(q0, x2);  // ((I - R) P0)^T, ((I + R) Q0)^T
+    v4f64 bat;
+    double mt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bat[q] = eLr[q] * (g1[q] - g2[q]);
+      mt[q] = g1[q] + g2[q];
+    }
+    const v4f64 hcur = {tb[0], tb[1], tb[2], tb[3]};
+    const v4f64 sd = mm_t(hcur, eye);     // S in the D layout
+    const v4f64 hb = mm_t(sd, bat);       // S^T Ba^T
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mt[q] -= hb[q];  // (Bb - Ba S)^T
+    double br = d.bpos[cm * NP + col];
+    const double tL = ts0[L];
+    const double att = beam ? exp(-tL / mu0) : 0.0;
+    if (refl) {
+      if (beam) {
+        const double rbm = col_dot(rtr, load_row(Bv + l * Q + NP, kq));
+        const double Xs = mu0 * d.I0[c] / M_PI * d.bdrfq0[((long)c * d.NBDRF + m) * NP + col];
+        br += (Xs + rbm - Bv[l * Q + col]) * att;
+      }
+      if (iso) {
+        v4f64 vr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vr[q] = vpoly(l, tL, NP + 4 * q + kq);
+        br += col_dot(rtr, vr) - vpoly(l, tL, col);
+      }
+    } else {
+      if (beam) br -= Bv[l * Q + col] * att;
+      if (iso) br -= vpoly(l, tL, col);
+    }
+    double rhs = br - col_dot(bat, col_to_row(tv, rowbase, kq));
+    double none[4] = {0.0, 0.0, 0.0, 0.0};
+    {
+      const double mt_in[4] = {mt[0], mt[1], mt[2], mt[3]};
+      const double rhs_in = rhs;
+      int bad = 0;
+      GjFast<0, 0>::run(mt, none, rhs, bad, col);
+      if (__any(bad)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mt[q] = mt_in[q];
+        rhs = rhs_in;
+        int pc = -1;
+        GjT<0, 0>::run(mt, none, rhs, pc, col, rowbase);
+        if (__any(pc != col)) rhs = push_lane((rowbase | pc) << 2, rhs);
+      }
+    }
+    cplus = rhs;
+    cminus = tv - col_dot(hcur, col_to_row(cplus, rowbase, kq));
+    if (kq == 0) {
+      coef[(long)l * Q + col] = cminus;
+      coef[(long)l * Q + NP + col] = cplus;
+    }
+  }
+  // ---- backward sweep: C+_l = Wq C-' + Wp E' C+' + rho_b ;  C-_l = s_l - S_l C+_l, with W applied through its
+  //      factors.  The loads of layer l-1 are issued while layer l is processed.
+  a1 = a0;
+  y1 = y0;
+  double k1b = kk[Lm1 * NP + col], e1b = Ek[Lm1 * NP + col];
+  if (Lm1 == 0) return;  // single layer: no interface, no workspace
+  int lp = Lm1 - 1;
+  v4f64 pa = load_d(Am + (long)lp * NN, kq, col), py = load_d(Ym + (long)lp * NN, kq, col), ph = load_d(wsb + (long)lp * Ws<NP>::SLOT + Ws<NP>::S, kq, col);
+  double psl = wsb[(long)lp * Ws<NP>::SLOT + Ws<NP>::SV + col], prb = wsb[(long)lp * Ws<NP>::SLOT + Ws<NP>::RB + col];
+  double pk = kk[lp * NP + col], pe = Ek[lp * NP + col];
+  for (int l = Lm1 - 1; l >= 0; --l) {
+    a0 = pa;
+    y0 = py;
+    const v4f64 hl = ph;
+    const double sl = psl, rb = prb, k0b = pk, e0b = pe;
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const int kq = lv >> 4, col = lv & 15, rowbase = lv & 48;
+    lp = max(l - 1, 0);
+    pa = load_d(Am + (long)lp * NN, kq, col);
+    py = load_d(Ym + (long)lp * NN, kq, col);
+    ph = load_d(wsb + (long)lp * Ws<NP>::SLOT + Ws<NP>::S, kq, col);
+    psl = wsb[(long)lp * Ws<NP>::SLOT + Ws<NP>::SV + col];
+    prb = wsb[(long)lp * Ws<NP>::SLOT + Ws<NP>::RB + col];
+    pk = kk[lp * NP + col];
+    pe = Ek[lp * NP + col];
+    const double x = cminus, y = e1b * cplus;
+    const v4f64 w1 = row_dot(y1, x + y), w2 = row_dot(a1, (y - x) * fast_rcp(k1b));
+    const double cp = rb + 0.5 * (col_dot(a0, w1) + k0b * col_dot(y0, w2));
+    const double cmn = sl - col_dot(hl, col_to_row(cp, rowbase, kq));
+    if (kq == 0) {
+      coef[(long)l * Q + col] = cmn;
+      coef[(long)l * Q + NP + col] = cp;
+    }
+    cminus = cmn;
+    cplus = cp;
+    a1 = a0;
+    y1 = y0;
+    k1b = k0b;
+    e1b = e0b;
+  }
+}
+
 }  // namespace
 
 void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
@@ -643,7 +1130,14 @@ void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
   switch (d.NP) {
     RTD_BC_CASE(4)
     RTD_BC_CASE(8)
-    case 16:  // RTD_IFACE_LDS=1 selects the LDS/VALU variant of the interface kernel (A/B comparison)
+    case 16: {
+      // default: the fused MFMA kernel (launched as part 1; part 0 is empty).  RTD_BC_SPLIT=1 selects the two-kernel
+      // path (interface operators through HBM), RTD_IFACE_LDS=1 its LDS/VALU interface kernel (A/B comparisons).
+      static const bool split = getenv("RTD_BC_SPLIT") != nullptr;
+      if (!split) {
+        if (part == 1) hipLaunchKernelGGL(rtd_bc_mfma_kernel, dim3((unsigned)((long)d.C * d.M)), dim3(64), 0, s, d);
+        break;
+      }
       if (part == 0 && nif > 0) {
         static const bool use_lds = getenv("RTD_IFACE_LDS") != nullptr;
         if (use_lds)
@@ -655,6 +1149,7 @@ void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
       }
       if (part == 1) hipLaunchKernelGGL(rtd_sweep_kernel<16>, gs, dim3(64), 0, s, d);
       break;
+    }
     RTD_BC_CASE(32)
     default: break;
   }

@@ -38,8 +38,8 @@ __device__ __forceinline__ double xor_lane(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   constexpr int ctrl = dpp_xor_ctrl(MASK);
   if constexpr (ctrl >= 0 && RTD_XOR_DPP) {  // one VALU move per dword, no LDS crossbar
-    lo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xF, 0xF, true);
   } else {  // ds_swizzle bit-mode: and = 0x1f, or = 0, xor = MASK
     constexpr int pat = (MASK << 10) | 0x1F;
     lo = __builtin_amdgcn_ds_swizzle(lo, pat);
@@ -182,8 +182,8 @@ template <int NP, int K>
 __device__ __forceinline__ double bcast_lane(double v) {
   if constexpr (NP == 16) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + K, 0xF, 0xF, false);  // row_newbcast:K (every source lane exists: `old` is never used)
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + K, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xF, 0xF, true);  // row_newbcast:K; bound_ctrl + full masks: no `old` operand, no copy
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
   } else {
     return __shfl(v, K, NP);
