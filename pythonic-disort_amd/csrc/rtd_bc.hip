@@ -653,11 +653,43 @@ __device__ __forceinline__ v4f64 mm_t(const v4f64& X, const v4f64& Y) {  // X^T 
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[3], Y[3], acc, 0, 0, 0);
   return acc;
 }
+#ifndef RTD_ROW_SWAP
+#define RTD_ROW_SWAP 0  /* cross-row moves with v_permlane16/32_swap (VALU latency) instead of ds_bpermute (LDS latency) */
+#endif
+typedef unsigned int u2x32 __attribute__((ext_vector_type(2)));
+// v_permlane16_swap(a, b): a' = rows (a0, b0, a2, b2), b' = rows (a1, b1, a3, b3);
+// v_permlane32_swap(a, b): a' = rows (a0, a1, b0, b1), b' = rows (a2, a3, b2, b3)   (tools/hiptests/permlane_swap.hip)
+template <int R>
+__device__ __forceinline__ unsigned int bcast_row32(unsigned int x) {
+  const u2x32 a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  const unsigned int y = (R & 1) ? a[1] : a[0];  // rows (x0,x0,x2,x2) or (x1,x1,x3,x3)
+  const u2x32 b = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+  return (R & 2) ? b[1] : b[0];
+}
+// value held by lane-row R (compile-time) in the same column, for every lane-row
+template <int R>
+__device__ __forceinline__ double bcast_row(double v, const int col) {
+#if RTD_ROW_SWAP
+  const unsigned int lo = bcast_row32<R>((unsigned int)__double2loint(v)), hi = bcast_row32<R>((unsigned int)__double2hiint(v));
+  return __hiloint2double((int)hi, (int)lo);
+#else
+  return bperm(((R << 4) | col) << 2, v);
+#endif
+}
 // sum over the four lane-rows (kq) of the wavefront; the result is replicated over them
 __device__ __forceinline__ double sum_kq(double p) {
+#if RTD_ROW_SWAP
+  const u2x32 al = __builtin_amdgcn_permlane16_swap((unsigned int)__double2loint(p), (unsigned int)__double2loint(p), false, false);
+  const u2x32 ah = __builtin_amdgcn_permlane16_swap((unsigned int)__double2hiint(p), (unsigned int)__double2hiint(p), false, false);
+  const double s = __hiloint2double((int)ah[0], (int)al[0]) + __hiloint2double((int)ah[1], (int)al[1]);  // rows (01, 01, 23, 23)
+  const u2x32 bl = __builtin_amdgcn_permlane32_swap((unsigned int)__double2loint(s), (unsigned int)__double2loint(s), false, false);
+  const u2x32 bh = __builtin_amdgcn_permlane32_swap((unsigned int)__double2hiint(s), (unsigned int)__double2hiint(s), false, false);
+  return __hiloint2double((int)bh[0], (int)bl[0]) + __hiloint2double((int)bh[1], (int)bl[1]);
+#else
   p += xor_lane<16>(p);
   p += __shfl_xor(p, 32, 64);
   return p;
+#endif
 }
 // sum_rows X[r][col] v[r]  with v in row form (register q = v[4 q + kq]); result in column form
 __device__ __forceinline__ double col_dot(const v4f64& X, const v4f64& vr) {
@@ -780,12 +812,15 @@ template <int NB, int K>
 struct GjFast {
   static __device__ __forceinline__ void run(double (&ta)[4], double (&tb)[4], double& tv, int& bad, const int col) {
     constexpr int QK = K >> 2, RK = K & 3;
-    const double x = bperm(((RK << 4) | col) << 2, ta[QK]);  // row K of Ta^T, replicated over the lane-rows
+    const double x = bcast_row<RK>(ta[QK], col);  // row K of Ta^T, replicated over the lane-rows
     const double xk = bcast16<K>(x);
     const double ax = (col > K) ? fabs(x) : 0.0, lim = RTD_GJ_GROWTH * fabs(xk);
     bad |= (ax > lim) ? 1 : 0;
     bad |= (lim > 0.0) ? 0 : 1;
-    const double rp = fast_rcp(xk);
+    // one Newton step from the hardware seed (~4e-15): an inexact multiplier only perturbs entries that are never
+    // read again, an inexact pivot scale perturbs column K of the result by the same relative amount
+    const double r0 = __builtin_amdgcn_rcp(xk);
+    const double rp = r0 * (2.0 - xk * r0);
     const double f = (col == K) ? 1.0 - rp : x * rp;
     static_for<QK, 4>([&](auto qc) {  // rows below 4 QK are finished: the pivot column is zero there
       constexpr int q = decltype(qc)::value;

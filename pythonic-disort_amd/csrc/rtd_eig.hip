@@ -83,10 +83,12 @@ __device__ __forceinline__ double approx_rcp(double x) {
 #define RTD_EIGEN_WAVES 3  /* waves per SIMD the fused eigen kernel is compiled for (LDS: 10 KB per wave) */
 #endif
 
-// a sweep is the last one when every pair it met had cos^2(angle) <= RTD_JAC_TOL (quadratic convergence
-// squares the residual angle during that sweep)
+// a sweep is the last one when every pair it met had cos^2(angle) <= RTD_JAC_TOL before its rotation (quadratic
+// convergence squares the residual angle during that sweep).  Measured on the benchmark columns against the CPU
+// oracle: 1e-16 .. 1e-11 give the same max |dI| (1.6e-11 abs, 4.1e-10 rel: other roundoff dominates), 1e-9 gives
+// 1.4e-8 rel, 1e-7 gives 5e-7; 1e-11 saves a third of a sweep on average.
 #ifndef RTD_JAC_TOL
-#define RTD_JAC_TOL 1e-16
+#define RTD_JAC_TOL 1e-11
 #endif
 
 // One parallel step of the one-sided (Hestenes) Jacobi iteration on the columns of W (H = W W^T at the
@@ -732,30 +734,21 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
 #pragma unroll
     for (int i = 0; i < NP; ++i) h += zc[i] * v2[i];
     h *= fast_rcp(rmu0 * rmu0 - k2);
-    // e = Z h (sum over the eigen-index = lanes)
-    double e;
+    // shat = L^-T Z h = Y h  and  t = L^T shat = Z h  (sums over the eigen-index = lanes): no triangular solve
+    double sh, e;
     {
       double x[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) x[i] = ya[i] * h;
+      sh = transpose_reduce<NP>(x, j);
 #pragma unroll
       for (int i = 0; i < NP; ++i) x[i] = zc[i] * h;
       e = transpose_reduce<NP>(x, j);
     }
-    // shat = L^-T e by back substitution distributed over the lanes
-    double sh = 0.0;
-    static_for<0, NP>([&](auto ic) {
-      constexpr int i = NP - 1 - decltype(ic)::value;
-      const double si = bcast_lane<NP, i>(e) * dinv[i];
-      sh = (j == i) ? si : sh;
-      e -= (j < i) ? L_[i * LD + j] * si : 0.0;
-    });
-    v1[j] = sh;
     __syncthreads();
-    double tv = 0.0;  // t = L^T shat
-#pragma unroll
-    for (int r = 0; r < NP; ++r) tv += L_[r * LD + j] * v1[r];
-    v2[j] = tv;
+    v2[j] = e;
     __syncthreads();
-    double ps = 0.0;  // Pm shat = L t
+    double ps = 0.0;  // Pm shat = L (L^T shat) = L t
 #pragma unroll
     for (int r = 0; r < NP; ++r) ps += L_[j * LD + r] * v2[r];
     const double rT = fast_rcp(T_j);
@@ -787,19 +780,10 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
   // A wave holds layers of ONE (c, m), so the branch is wave-uniform.
   if (d.Ns > 0 && m == 0) {
     const bool act = true;
-    // q = L^-1 (T / mu) by forward substitution distributed over the lanes
-    double cur = T_j * invmu_j, q_j = 0.0;
-    static_for<0, NP>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      const double qi = bcast_lane<NP, i>(cur) * dinv[i];
-      q_j = (j == i) ? qi : q_j;
-      cur -= (j > i) ? L_[j * LD + i] * qi : 0.0;
-    });
-    v0[j] = q_j;
-    __syncthreads();
-    double zn = 0.0;  // zneg_j = -k_j/2 sum_i Z[i][j] q[i]
+    // zneg_j = -k_j/2 [Z^T L^-1 (T/mu)]_j = -k_j/2 sum_i Y[i][j] T_i/mu_i   (Y = L^-T Z: no triangular solve)
+    double zn = 0.0;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) zn += zc[i] * v0[i];
+    for (int i = 0; i < NP; ++i) zn += ya[i] * (d.T[i] * d.invmu[i]);
     zn *= -0.5 * kj;
     if (valid && act) d.zneg[((long)c * d.L + l) * NP + j] = zn;
     const double* sp = d.spoly + ((long)c * d.L + l) * d.Ns;
