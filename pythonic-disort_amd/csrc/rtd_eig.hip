@@ -229,7 +229,7 @@ struct ProbId {
   bool valid;
 };
 template <int NP>
-__device__ __forceinline__ ProbId locate(const RtdDev& d) {
+__device__ __forceinline__ ProbId locate(const RtdDev& d, const int tx = threadIdx.x) {
   // One wavefront = the 64/NP consecutive layers of ONE (column, mode): c and m depend on blockIdx only, so
   // they are wave-uniform and the Legendre-table reads (indexed by m and l only) become scalar loads.
   constexpr int GPW = 64 / NP;
@@ -239,7 +239,7 @@ __device__ __forceinline__ ProbId locate(const RtdDev& d) {
   ProbId p;
   p.m = (int)(cmi % d.M);
   p.c = (int)(cmi / d.M);
-  p.l = chunk * GPW + (int)(threadIdx.x / NP);
+  p.l = chunk * GPW + tx / NP;
   p.valid = p.l < d.L;
   if (!p.valid) p.l = d.L - 1;  // redo the last layer, skip the stores
   p.pid = cmi * d.L + p.l;
@@ -580,15 +580,12 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
   constexpr int LD = NP + 1;
   __shared__ double sL[GPW][NP * LD];  // Cholesky factor L of Pm
   __shared__ double sV[GPW][4][NP];
+  double w[NP];  // column j of F = L^T R, then of k Z
+  {  // ---- stage 1: assembly, Cholesky factors, F, Jacobi.  Only w (and the LDS tile of L) leaves this block.
   const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
   const ProbId id = locate<NP>(d);
   const int P = d.P, m = id.m, c = id.c, l = id.l;
-  const bool valid = id.valid;
-  const long base = id.pid;
   double* L_ = sL[grp];
-  double* v0 = sV[grp][0];
-  double* v1 = sV[grp][1];
-  double* v2 = sV[grp][2];
   double* dinv = sV[grp][3];  // 1 / L[i][i]
   const double* wl = d.wleg + ((long)c * d.L + l) * P;
   const double om = d.omega[(long)c * d.L + l];
@@ -623,8 +620,7 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
 #pragma unroll
     for (int i = 0; i < NP; ++i) acc_e[i] = acc_o[i] = 0.0;
   }
-  const double invmu_j = d.invmu[j], S_j = d.S[j], T_j = d.T[j];
-  double w[NP];  // column j of F = L^T R, then of k Z
+  const double invmu_j = d.invmu[j], S_j = d.S[j];
   {
     double pcol[NP], qcol[NP];
 #pragma unroll
@@ -658,6 +654,25 @@ __global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d
     if (!__any(notconv)) break;
   }
   if (threadIdx.x == 0 && nsweep > *(volatile int*)d.sweeps) atomicMax(d.sweeps, nsweep);
+  }
+  // ---- stage 2: eigenvector blocks and particular solutions.  The lane's identifiers are rebuilt from an opaque copy
+  //      of the lane index, so that none of them is kept (and spilled) across the Jacobi loop.
+  int tx = threadIdx.x;
+  asm volatile("" : "+v"(tx));
+  const int grp = tx / NP, j = tx % NP;
+  const ProbId id = locate<NP>(d, tx);
+  const int P = d.P, m = id.m, c = id.c, l = id.l;
+  const bool valid = id.valid;
+  const long base = id.pid;
+  double* L_ = sL[grp];
+  double* v0 = sV[grp][0];
+  double* v1 = sV[grp][1];
+  double* v2 = sV[grp][2];
+  double* dinv = sV[grp][3];  // 1 / L[i][i]
+  const double* wl = d.wleg + ((long)c * d.L + l) * P;
+  const double om = d.omega[(long)c * d.L + l];
+  const double* Ym = d.Y + (long)m * P * NP;
+  const double invmu_j = d.invmu[j], T_j = d.T[j];
   double k2 = 0.0;
 #pragma unroll
   for (int i = 0; i < NP; ++i) k2 += w[i] * w[i];
