@@ -283,7 +283,7 @@ int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** out) {
     };
 #define A(ptr, n) carve(&ptr, (n));
     A(mu, NP) A(w, NP) A(invmu, NP) A(S, NP) A(T, NP)
-    A(d.Y, M * P * NP) A(d.Y0, C * M * P)
+    A(d.Y, M * P * NP) A(d.Y0, C * M * P) A(d.att, C * (L + 1))
     A(omega, C * L) A(tau, C * L) A(taus0, C * (L + 1)) A(scale, C * L) A(wleg, C * L * P)
     A(mu0, C) A(I0, C) A(phi0, C) A(rescale, C)
     A(bpos, C * M * NP) A(bneg, C * M * NP) A(spoly, C * L * Ns) A(bq, C * NB * NP * NP) A(bq0, C * NB * NP)

@@ -983,7 +983,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     // particular-solution jump r_l at the interface (:184-205, :242-245) and rho = G_l^-1 r_l:
     //   rho_t/b = 1/4 [ V^-1 (r_up + r_dn) +- U^-1 (r_up - r_dn) ],  V^-1[j][i] = T_i A[i][j],  U^-1[j][i] = -k_j T_i Y[i][j]
     const double tbnd = ts0[l + 1];
-    const double att = beam ? exp(-tbnd / mu0) : 0.0;
+    const double att = beam ? d.att[(long)c * (L + 1) + l + 1] : 0.0;
     const v4f64 t_row = load_row(d.T, kq);
     double rt = 0.0, rb = 0.0;
 #pragma unroll
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     for (int q = 0; q < 4; ++q) mt[q] -= hb[q];  // (Bb - Ba S)^T
     double br = d.bpos[cm * NP + col];
     const double tL = ts0[L];
-    const double att = beam ? exp(-tL / mu0) : 0.0;
+    const double att = beam ? d.att[(long)c * (L + 1) + L] : 0.0;
     if (refl) {
       if (beam) {
         const double rbm = col_dot(rtr, load_row(Bv + l * Q + NP, kq));

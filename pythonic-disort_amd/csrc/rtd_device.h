@@ -25,6 +25,7 @@ struct RtdDev {
   // Legendre tables
   double* Y;   // [M][P][NP]   normalised associated Legendre functions at the quadrature nodes
   double* Y0;  // [C][M][P]    the same at -mu0 of each column
+  double* att;  // [C][L+1]    beam attenuation exp(-tau*_l / mu0) at the scaled layer boundaries (beam only)
   // per-column inputs
   const double *omega, *tau, *taus0, *scale, *wleg, *mu0, *I0, *phi0, *rescale;
   const double *bpos, *bneg;  // [C][M][NP]

@@ -874,6 +874,10 @@ __global__ void rtd_tables_mu0_kernel(RtdDev d) {
   if (t >= (long)d.C * d.M) return;
   const int c = (int)(t / d.M), m = (int)(t % d.M);
   ybar_column(m, d.P, -d.mu0[c], d.Y0 + t * d.P, 1);
+  if (m == 0) {  // beam attenuation at the scaled layer boundaries, used by the boundary-condition kernel
+    const double rmu0 = 1.0 / d.mu0[c];
+    for (int l = 0; l <= d.L; ++l) d.att[(long)c * (d.L + 1) + l] = exp(-d.taus0[(long)c * (d.L + 1) + l] * rmu0);
+  }
 }
 
 }  // namespace
