@@ -802,7 +802,7 @@ struct GjT<NB, 16> {
 // code (the 16 steps schedule into each other), no pivot search.  A step whose diagonal candidate is more than a
 // factor RTD_GJ_GROWTH smaller than another unused entry of its row (or zero) raises `bad`; the caller then
 // repeats the elimination from its saved inputs with the pivoted GjT.  On the benchmark atmospheres 95 % of the
-// eliminations pass (tools/..., RTD_BC_STATS experiment in DESIGN.md).
+// eliminations pass (counted with a temporary statistics build).
 // The pivot column is scaled by the same FMA as the others: its own broadcast value is itself, so f = 1 - 1/pivot
 // gives v - f v = v / pivot.
 #ifndef RTD_GJ_GROWTH
