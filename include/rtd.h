@@ -125,8 +125,8 @@ int rtd_plan_get_tensors(rtd_plan* plan, int32_t column, double* GC, double* K, 
 /* When enabled, rtd_plan_run/solve bracket each kernel with HIP events on the plan's stream. */
 int rtd_plan_enable_timing(rtd_plan* plan, int32_t enable);
 /* accumulated milliseconds per kernel since the last reset: [0] Legendre tables, [1] rtd_asm_kernel,
- * [2] rtd_jacobi_kernel (NQuad <= 32: the fused rtd_eigen_kernel), [3] rtd_post_kernel, [4] rtd_iface_kernel,
- * [5] rtd_sweep_kernel (16 < NQuad <= 32: the fused rtd_bc_mfma_kernel, slot 4 is then empty), [6] rtd_eval_kernel;
+ * [2] rtd_jacobi_kernel, or the fused rtd_eigen_kernel when NQuad <= 32, [3] rtd_post_kernel, [4] rtd_iface_kernel,
+ * [5] rtd_sweep_kernel, or the fused rtd_bc_mfma_kernel when 16 < NQuad <= 32 (slot 4 is then empty), [6] rtd_eval_kernel;
  * launches counted in nlaunch[7]. Synchronises. */
 int rtd_plan_get_timing(rtd_plan* plan, double ms[7], int64_t nlaunch[7], int32_t reset);
 /* maximum Jacobi sweeps used by any eigenproblem of the last solve (diagnostic) */
