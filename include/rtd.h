@@ -77,6 +77,16 @@ int rtd_plan_set_columns(rtd_plan* plan, const double* scaled_omega, const doubl
                          const double* b_pos, const double* b_neg, const double* s_poly,
                          const double* bdrf_q, const double* bdrf_q0);
 
+/* BDRF Fourier modes formed on the device.  The reference takes the surface as callables
+ * BDRF_Fourier_modes[m](mu, -mu') evaluated on the quadrature grid (_solve_for_coeffs.py:121-134); for a reflectance
+ * rho(mu, mu', dphi) its tests integrate every mode on the host (pydisotest/6_test.py:194-201).  Here the caller passes
+ * rho sampled at dphi_p = 2 pi p / nphi, p < nphi, and the device forms the plan's NBDRF modes
+ *   q^m = (2 - delta_m0)/nphi  sum_p rho_p cos(m dphi_p)      (trapezoid rule of 1/((1+delta_m0) pi) Int rho cos(m dphi))
+ *   rho_qq [C][N][N][nphi]   rho(mu_i, mu_j, dphi_p)
+ *   rho_q0 [C][N][nphi]      rho(mu_i, mu0, dphi_p)   (NULL when there is no beam)
+ * Call after rtd_plan_set_columns (whose bdrf_q / bdrf_q0 may then be NULL) and before rtd_plan_solve. */
+int rtd_plan_set_bdrf_samples(rtd_plan* plan, int32_t nphi, const double* rho_qq, const double* rho_q0);
+
 /* --- solve: _solve_for_gen_and_part_sols + _solve_for_coeffs on the device ---------------- */
 /* Asynchronous on the plan's stream. */
 int rtd_plan_solve(rtd_plan* plan);

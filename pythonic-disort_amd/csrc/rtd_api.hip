@@ -412,8 +412,9 @@ int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* 
     q0.assign((size_t)(C * NB * NP), 0.0);
     for (int64_t cb = 0; cb < C * NB; ++cb)
       for (int64_t i = 0; i < N; ++i) {
-        q0[cb * NP + i] = bdrf_q0[cb * N + i];
-        for (int64_t j = 0; j < N; ++j) q[(cb * NP + i) * NP + j] = bdrf_q[(cb * N + i) * N + j];
+        if (bdrf_q0) q0[cb * NP + i] = bdrf_q0[cb * N + i];
+        if (bdrf_q)
+          for (int64_t j = 0; j < N; ++j) q[(cb * NP + i) * NP + j] = bdrf_q[(cb * N + i) * N + j];
       }
     UP(d.bdrfq, q.data(), C * NB * NP * NP);
     UP(d.bdrfq0, q0.data(), C * NB * NP);
@@ -421,6 +422,33 @@ int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* 
 #undef UP
   HIP_TRY(hipStreamSynchronize(s));  // host staging vectors go out of scope
   p->have_cols = true;
+  p->solved = false;
+  return 0;
+}
+
+int rtd_plan_set_bdrf_samples(rtd_plan* p, int32_t nphi, const double* rho_qq, const double* rho_q0) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  if (!p->have_cols) return fail(RTD_ERR_STATE, "set_columns must precede set_bdrf_samples");
+  const RtdDev& d = p->d;
+  if (d.NBDRF <= 0) return fail(RTD_ERR_ARG, "the plan was created with nbdrf = 0");
+  if (nphi < 2 || nphi > 16384 || !rho_qq) return fail(RTD_ERR_ARG, "need 2 <= nphi <= 16384 and rho_qq");
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  const int64_t nqq = (int64_t)d.C * d.N * d.N * nphi, nq0 = rho_q0 ? (int64_t)d.C * d.N * nphi : 0;
+  double* tmp = nullptr;
+  HIP_TRY(hipMalloc(&tmp, (size_t)(nqq + nq0) * sizeof(double)));
+  hipError_t e = hipMemcpyAsync(tmp, rho_qq, (size_t)nqq * sizeof(double), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && nq0)
+    e = hipMemcpyAsync(tmp + nqq, rho_q0, (size_t)nq0 * sizeof(double), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemsetAsync(const_cast<double*>(d.bdrfq), 0, (size_t)d.C * d.NBDRF * d.NP * d.NP * sizeof(double), s);
+  if (e == hipSuccess) e = hipMemsetAsync(const_cast<double*>(d.bdrfq0), 0, (size_t)d.C * d.NBDRF * d.NP * sizeof(double), s);
+  if (e == hipSuccess) {
+    rtd_launch_bdrf_modes(d, nphi, tmp, nq0 ? tmp + nqq : nullptr, s);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return fail(RTD_ERR_HIP, hipGetErrorString(e));
   p->solved = false;
   return 0;
 }

@@ -393,7 +393,7 @@ struct GjStep<NP, NB, NP> {
 // Sweep kernel: per (c, m): forward carry recursion over the layers, bottom BC, backward sweep.
 // ------------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(64, (NP <= 16 ? RTD_SWEEP_WAVES : 1)) void rtd_sweep_kernel(RtdDev d) {
+__global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1))) void rtd_sweep_kernel(RtdDev d) {
   constexpr int GPW = 64 / NP, LD = NP + 1, Q = 2 * NP;
   __shared__ double sA[GPW][NP * LD];  // Wq (forward) / S (bottom)
   __shared__ double sB[GPW][NP * LD];  // Wp

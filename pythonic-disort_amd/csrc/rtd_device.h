@@ -64,5 +64,6 @@ void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part);   // 0 iface, 1 sw
 void rtd_launch_eval(const RtdDev& d, const RtdEval& e, hipStream_t s);
 void rtd_launch_nt_tables(const RtdDev& d, const RtdNt& nt, hipStream_t s);
 void rtd_launch_nt_apply(const RtdDev& d, const RtdNt& nt, const RtdEval& e, hipStream_t s);
+void rtd_launch_bdrf_modes(const RtdDev& d, int nphi, const double* rho_qq, const double* rho_q0, hipStream_t s);
 void rtd_launch_export(const RtdDev& d, int col, double* GC, double* K, double* B, double* Gim, double* G,
                        hipStream_t s);

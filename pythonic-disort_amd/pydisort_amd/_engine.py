@@ -51,6 +51,23 @@ class Plan:
         except Exception:
             pass
 
+    def set_bdrf_samples(self, rho_qq, rho_q0=None):
+        """Form the plan's NBDRF BDRF Fourier modes on the device from samples of the reflectance on a uniform grid
+        of relative azimuths dphi_p = 2 pi p / nphi:  rho_qq [C, N, N, nphi] = rho(mu_i, mu_j, dphi_p) and, with a
+        beam, rho_q0 [C, N, nphi] = rho(mu_i, mu0, dphi_p).  Replaces the tables given to ``set_columns``."""
+        Cn, N = self.prep["C"], self.prep["N"]
+        rho_qq = _f64(rho_qq)
+        if rho_qq.ndim != 4 or rho_qq.shape[:3] != (Cn, N, N):
+            raise ValueError("rho_qq must have the shape [C, N, N, nphi].")
+        nphi = rho_qq.shape[3]
+        q0 = None
+        if rho_q0 is not None:
+            q0 = _f64(rho_q0)
+            if q0.shape != (Cn, N, nphi):
+                raise ValueError("rho_q0 must have the shape [C, N, nphi].")
+        _lib.check(self._lib.rtd_plan_set_bdrf_samples(self._h, nphi, _lib.dptr(rho_qq), _lib.dptr(q0) if q0 is not None else None))
+        self.solved = False
+
     def set_nt(self, weighted_leg_all, f_arr, ims_coef, ims_par):
         """Enable device-side Nakajima-Tanaka corrections of `u` (arrays with a leading column axis)."""
         a = [_f64(v) for v in (weighted_leg_all, f_arr, ims_coef, ims_par)]

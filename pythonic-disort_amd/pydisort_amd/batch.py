@@ -42,11 +42,14 @@ class BatchSolution:
 
 def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLeg=None, NFourier=None,
                    b_pos=0, b_neg=0, only_flux=False, f_arr=0, NT_cor=False, bdrf_q=None, bdrf_q0=None,
-                   s_poly_coeffs=None, device=0):
+                   s_poly_coeffs=None, device=0, bdrf_samples=None, NBDRF=None):
     """Like ``pydisort`` with a leading column axis on every atmospheric input:
     tau_arr, omega_arr, f_arr [C, L]; Leg_coeffs_all [C, L, NLeg_all]; mu0, I0, phi0 [C];
     b_pos / b_neg: scalar, [C], [C, N] or [C, N, NFourier]; s_poly_coeffs [C, L, Ns];
     bdrf_q [C, NBDRF, N, N] and bdrf_q0 [C, NBDRF, N]: BDRF Fourier modes tabulated on the quadrature grid.
+    bdrf_samples=(rho_qq [C, N, N, nphi], rho_q0 [C, N, nphi] or None) instead: the reflectance itself sampled at
+    dphi_p = 2 pi p / nphi; its first NBDRF (default NFourier) Fourier modes are then formed on the device
+    (``subroutines.sample_BDRF`` builds the samples from a function rho(mu, mu', dphi)).
     NT_cor=True adds the Nakajima-Tanaka corrections to ``u`` on the device (needs a beam in every column,
     f_arr > 0 and more Legendre coefficients than NLeg).
     All columns share NQuad, NLeg, NFourier and the layer count.  Returns (mu_arr, BatchSolution)."""
@@ -91,9 +94,18 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
         else np.asarray(s_poly_coeffs, float).reshape(C, L, -1)
     bq = np.zeros((C, 0, N, N)) if bdrf_q is None else np.asarray(bdrf_q, float)
     bq0 = np.zeros((C, 0, N)) if bdrf_q0 is None else np.asarray(bdrf_q0, float)
+    if bdrf_samples is not None:
+        if bdrf_q is not None:
+            raise ValueError("Give either bdrf_q / bdrf_q0 or bdrf_samples, not both.")
+        nb = NFourier if NBDRF is None else int(NBDRF)
+        if not 0 < nb <= NFourier:
+            raise ValueError("Need 0 < NBDRF <= NFourier.")
+        bq, bq0 = np.zeros((C, nb, N, N)), np.zeros((C, nb, N))  # placeholders: the device fills the tables
     prep = prepare_columns(tau_arr, omega_arr, NQuad, Leg, mu0, I0, phi0, NLeg, NFourier, bc(b_pos), bc(b_neg),
                            f_arr, sp, bq, bq0)
     plan = Plan(prep, device=device)
+    if bdrf_samples is not None:
+        plan.set_bdrf_samples(bdrf_samples[0], bdrf_samples[1] if np.any(I0 > 0) else None)
     plan.solve()
     if NT_cor and not only_flux:
         if not (np.all(I0 > 0) and np.any(f_arr > 0) and NLeg < Leg.shape[2]):

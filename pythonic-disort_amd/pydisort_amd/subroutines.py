@@ -185,6 +185,40 @@ def cache_BDRF_Fourier_modes(N, BDRF_Fourier_modes, mu0=0):
     return cached
 
 
+def sample_BDRF(BDRF, NQuad, mu0=None, nphi=256):
+    """Samples of a reflectance ``BDRF(mu, mu_p, dphi)`` (broadcasting over arrays mu [N,1], mu_p [1,N] and a scalar
+    dphi) for the device-side Fourier integration (``Plan.set_bdrf_samples`` / ``pydisort_batch(bdrf_samples=...)``):
+    returns (rho_qq [N, N, nphi], rho_q0 [N, nphi] or None) at the double-Gauss nodes of ``NQuad`` streams and
+    dphi_p = 2 pi p / nphi.  The device forms q^m = 1/((1 + delta_m0) pi) Int_0^2pi BDRF cos(m dphi) ddphi by the
+    trapezoid rule; the reference's tests integrate each mode on the host instead (pydisotest/6_test.py:194-201)."""
+    N = NQuad // 2
+    mu, _ = double_gauss(N)
+    rho_qq = np.empty((N, N, nphi))
+    rho_q0 = None if mu0 is None else np.empty((N, nphi))
+    for p in range(nphi):
+        dphi = 2 * pi * p / nphi
+        rho_qq[:, :, p] = BDRF(mu[:, None], mu[None, :], dphi)
+        if mu0 is not None:
+            rho_q0[:, p] = np.asarray(BDRF(mu[:, None], np.atleast_1d(float(mu0))[None, :], dphi))[:, 0]
+    return rho_qq, rho_q0
+
+
+def Hapke_BDRF(B0, HH, W):
+    """Hapke's reflectance as used by DISORT's test problem 6 (cf. pydisotest/6_test.py:11-25): returns
+    rho(mu, mu_p, dphi) with the opposition surge B0 HH / (HH + tan(alpha/2)), the Legendre phase term 1 + cos(alpha)/2
+    and the two-stream H functions; alpha is the phase angle between the incident and the reflected directions."""
+    gamma = np.sqrt(1 - W)
+
+    def rho(mu, mu_p, dphi):
+        mu, mu_p = np.asarray(mu, float), np.asarray(mu_p, float)
+        cos_a = np.clip(mu * mu_p - np.sqrt(1 - mu**2) * np.sqrt(1 - mu_p**2) * np.cos(dphi), -1.0, 1.0)
+        surge = B0 * HH / (HH + np.tan(np.arccos(cos_a) / 2))
+        h = (1 + 2 * mu) / (1 + 2 * mu * gamma) * (1 + 2 * mu_p) / (1 + 2 * mu_p * gamma)
+        return W / 4 / (mu + mu_p) * ((1 + surge) * (1 + cos_a / 2) + h - 1)
+
+    return rho
+
+
 def affine_transform_poly_coeffs(poly_coeffs, a_arr, b_arr):
     """Rows of coefficients [C_0..C_n] of C(x); returns, per row, the coefficients [D_0..D_n] of the same function
     written in y = a x + b (:574-610)."""

@@ -85,3 +85,24 @@ def test_interpolate_and_actinic_flux_on_device_solution():
     w = S.Gauss_Legendre_quad(N)[1]
     assert np.allclose(fa_up(tau), 2 * np.pi * w @ u0(tau)[:N])
     assert np.all(np.isfinite(fa_dn(tau)))
+
+
+def test_hapke_samples_reproduce_reference_bdrf_tables():
+    """SURVEY 8(f) f4, host half: Hapke_BDRF + sample_BDRF + the trapezoid cosine sum (what the device kernel computes)
+    against the Fourier-mode tables the reference produced with scipy's quad_vec for test 6d (captured in the golden
+    file).  Off the opposition cusp the rule is spectrally accurate; on it (mu = mu', dphi = pi) it is second order."""
+    import numpy as np
+    import goldens
+    from pydisort_amd import subroutines as sub
+    call = goldens.load("6d")[0]
+    kw = call["kwargs"]
+    nphi = 4096
+    rho_qq, rho_q0 = sub.sample_BDRF(sub.Hapke_BDRF(1.0, 0.06, 0.6), kw["NQuad"], float(kw["mu0"]), nphi=nphi)
+    p = np.arange(nphi)
+    for m, f in enumerate(kw["BDRF_Fourier_modes"]):
+        c = (1 if m == 0 else 2) / nphi * np.cos(2 * np.pi * m * p / nphi)
+        q, q0 = rho_qq @ c, rho_q0 @ c
+        off = ~np.eye(q.shape[0], dtype=bool)
+        assert np.max(np.abs(q - f.tab)[off]) < 1e-9      # the reference's quad_vec tolerance
+        assert np.max(np.abs(q - f.tab)) < 1e-5           # cusp of the opposition surge on the diagonal
+        assert np.max(np.abs(q0 - f.tab0)) < 1e-9
