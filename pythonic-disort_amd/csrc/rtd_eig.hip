@@ -108,19 +108,17 @@ struct JacobiStep {
     }
     const double beta = xor_lane<T>(alpha);
     const bool lo = (j & high_bit(T)) == 0;  // j < j^T
-    double c = 1.0, sg = 0.0;
-    if (gamma != 0.0) {
-      // tan(2 theta) = 2 gamma / (a_hi - a_lo);  t = tan(theta) without cancellation
-      const double delta = lo ? (beta - alpha) : (alpha - beta);
-      const double g2 = 2.0 * gamma;
-      const double r2 = delta * delta + g2 * g2;
-      const double rho = r2 * approx_rsqrt(r2);
-      const double den = delta + copysign(rho, delta);
-      const double tt = g2 * approx_rcp(den);
-      c = fast_rsqrt(1.0 + tt * tt);
-      const double s = tt * c;
-      sg = lo ? -s : s;
-    }
+    // tan(2 theta) = 2 gamma / (a_hi - a_lo);  t = tan(theta) without cancellation.  Branch-free: the tiny term keeps
+    // gamma = 0 (decoupled or already orthogonal columns, also with equal norms) at t = 0, c = 1 without a 0/0.
+    const double delta = lo ? (beta - alpha) : (alpha - beta);
+    const double g2 = 2.0 * gamma;
+    const double r2 = delta * delta + (g2 * g2 + 1e-280);
+    const double rho = r2 * approx_rsqrt(r2);
+    const double den = delta + copysign(rho, delta);
+    const double tt = g2 * approx_rcp(den);
+    const double c = fast_rsqrt(1.0 + tt * tt);
+    const double s = tt * c;
+    const double sg = lo ? -s : s;
     notconv |= (gamma * gamma > RTD_JAC_TOL * alpha * beta) ? 1 : 0;
     alpha = c * c * alpha + sg * (sg * beta + 2.0 * c * gamma);
 #pragma unroll

@@ -1,4 +1,5 @@
-for lib in variants/librtd_bw4.so variants/librtd_bw2.so; do
-  echo "lib=$lib"
-  RTD_LIB=$lib python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['kernel_ms_per_step']['bc'])"
+for rep in 1 2 3; do
+for lib in pythonic-disort_amd/pydisort_amd/librtd.so variants/librtd_head.so; do
+  RTD_LIB=$lib python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', round(d['value']), round(d['roofline']['kernel_ms_per_step']['eigen'],3), round(d['roofline']['kernel_ms_per_step']['bc'],3))"
+done
 done
