@@ -23,7 +23,8 @@ namespace {
 // compiler-only barrier: keeps the scheduler from hoisting a whole unrolled loop's LDS loads
 #define RTD_FENCE() asm volatile("" ::: "memory")
 #ifndef RTD_XOR_DPP
-#define RTD_XOR_DPP 0  /* A/B: DPP for the one-move masks is 2 % slower -- the Jacobi sweeps are VALU-bound, the LDS crossbar is free */
+#define RTD_XOR_DPP 0x818E  /* bit set of the xor masks done by ONE DPP move per dword (1, 2, 3, 7, 8, 15) instead of ds_swizzle:
+                               A/B on one box 6.03 -> 5.94 ms (with bound_ctrl moves; with the old copy-then-move form it lost 2 %) */
 #endif
 
 // DPP control of a lane permutation "lane ^ MASK" inside a 16-lane row that one DPP move can express, else -1:
@@ -37,7 +38,7 @@ __device__ __forceinline__ double xor_lane(double v) {
   // value of lane (lane ^ MASK); MASK < 32
   int lo = __double2loint(v), hi = __double2hiint(v);
   constexpr int ctrl = dpp_xor_ctrl(MASK);
-  if constexpr (ctrl >= 0 && RTD_XOR_DPP) {  // one VALU move per dword, no LDS crossbar
+  if constexpr (ctrl >= 0 && ((RTD_XOR_DPP >> MASK) & 1)) {  // one VALU move per dword, no LDS crossbar (RTD_XOR_DPP = bit set of masks)
     lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xF, 0xF, true);
     hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xF, 0xF, true);
   } else {  // ds_swizzle bit-mode: and = 0x1f, or = 0, xor = MASK

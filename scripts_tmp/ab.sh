@@ -1,5 +1,5 @@
-for rep in 1 2 3; do
-for lib in pythonic-disort_amd/pydisort_amd/librtd.so variants/librtd_head.so; do
+for rep in 1 2; do
+for lib in pythonic-disort_amd/pydisort_amd/librtd.so variants/librtd_dpp0x6.so variants/librtd_dpp0xE.so variants/librtd_dpp0x818E.so; do
   RTD_LIB=$lib python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', round(d['value']), round(d['roofline']['kernel_ms_per_step']['eigen'],3), round(d['roofline']['kernel_ms_per_step']['bc'],3))"
 done
 done
