@@ -800,7 +800,8 @@ struct GjT<NB, 16> {
 
 // Speculative, branch-free form of the same elimination with the diagonal as pivot at every step: straight-line
 // code (the 16 steps schedule into each other), no pivot search.  A step whose diagonal candidate is more than a
-// factor RTD_GJ_GROWTH smaller than another unused entry of its row (or zero) raises `bad`; the caller then
+// factor RTD_GJ_GROWTH smaller than another unused entry of its row raises `bad` (a zero pivot leaves inf / nan in the
+// result, which the caller tests); the caller then
 // repeats the elimination from its saved inputs with the pivoted GjT.  On the benchmark atmospheres 95 % of the
 // eliminations pass (counted with a temporary statistics build).
 // The pivot column is scaled by the same FMA as the others: its own broadcast value is itself, so f = 1 - 1/pivot
@@ -814,14 +815,12 @@ struct GjFast {
     constexpr int QK = K >> 2, RK = K & 3;
     const double x = bcast_row<RK>(ta[QK], col);  // row K of Ta^T, replicated over the lane-rows
     const double xk = bcast16<K>(x);
-    const double ax = (col > K) ? fabs(x) : 0.0, lim = RTD_GJ_GROWTH * fabs(xk);
-    bad |= (ax > lim) ? 1 : 0;
-    bad |= (lim > 0.0) ? 0 : 1;
     // one Newton step from the hardware seed (~4e-15): an inexact multiplier only perturbs entries that are never
     // read again, an inexact pivot scale perturbs column K of the result by the same relative amount
     const double r0 = __builtin_amdgcn_rcp(xk);
     const double rp = r0 * (2.0 - xk * r0);
     const double f = (col == K) ? 1.0 - rp : x * rp;
+    bad |= (col > K && fabs(f) > RTD_GJ_GROWTH) ? 1 : 0;  // a zero pivot shows up as a non-finite result (checked by the caller)
     static_for<QK, 4>([&](auto qc) {  // rows below 4 QK are finished: the pivot column is zero there
       constexpr int q = decltype(qc)::value;
       ta[q] = fma(-f, bcast16<K>(ta[q]), ta[q]);
@@ -937,6 +936,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       sSave[8][lane] = tv;
       int bad = 0;
       GjFast<4, 0>::run(ta, tb, tv, bad, col);
+      bad |= (fabs(tv) + fabs(tb[0]) + fabs(tb[1]) + fabs(tb[2]) + fabs(tb[3]) < 1e300) ? 0 : 1;  // zero pivot: inf / nan
       if (__any(bad)) {  // some diagonal pivot was too small: pivoted elimination from the saved inputs
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1090,6 +1090,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       const double rhs_in = rhs;
       int bad = 0;
       GjFast<0, 0>::run(mt, none, rhs, bad, col);
+      bad |= (fabs(rhs) < 1e300) ? 0 : 1;
       if (__any(bad)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) mt[q] = mt_in[q];
