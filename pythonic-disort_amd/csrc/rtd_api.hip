@@ -1,4 +1,5 @@
 // rtd_api.hip -- host side of the C ABI declared in include/rtd.h (plan life cycle, uploads, launches).
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -264,6 +265,7 @@ int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** out) {
                 Ns = dims->nscoeffs, NB = dims->nbdrf, Q2 = 2 * NP;
   d.C = (int)C; d.L = (int)L; d.N = N; d.NP = (int)NP; d.P = (int)P; d.M = (int)M; d.Ns = (int)Ns;
   d.NBDRF = (int)NB; d.beam = dims->beam ? 1 : 0;
+  d.flags = getenv("RTD_BC_FORCE_PIVOT") ? 1 : 0;
   int rc = 0;
   double *mu = nullptr, *w = nullptr, *invmu = nullptr, *S = nullptr, *T = nullptr, *omega = nullptr, *tau = nullptr,
          *taus0 = nullptr, *scale = nullptr, *wleg = nullptr, *mu0 = nullptr, *I0 = nullptr, *phi0 = nullptr,

@@ -20,6 +20,7 @@
 struct RtdDev {
   // sizes
   int C, L, N, NP, P, M, Ns, NBDRF, beam;
+  int flags;  // bit 0: the fused BC kernel skips its speculative elimination (test hook, env RTD_BC_FORCE_PIVOT)
   // quadrature (padded to NP)
   const double *mu, *w, *invmu, *S, *T;  // S = sqrt(w/mu), T = sqrt(w*mu) (1 for padding)
   // Legendre tables

@@ -11,6 +11,7 @@ Tolerance (written here, north star = 1e-6 relative on intensities): 1e-9 of the
 scale of the call, 1e-6 for the near-conservative cases (omega = 1 - 1e-6) where two LAPACK orderings
 of the reference's own algorithm already differ by ~1e-8.
 """
+import os
 import warnings
 from math import pi
 
@@ -412,3 +413,19 @@ def test_device_bdrf_modes_equal_host_cosine_sums(amd):
     assert np.max(np.abs(sa.flux_up(t) - sb.flux_up(t))) <= 1e-12 * np.max(np.abs(sa.flux_up(t)))
     sa.plan.close()
     sb.plan.close()
+
+
+@pytest.mark.gpu
+def test_fused_bc_kernel_pivoted_path_on_goldens():
+    """The fused boundary-condition kernel eliminates speculatively (diagonal pivots) and falls back to the fully
+    pivoted elimination when a pivot is small.  RTD_BC_FORCE_PIVOT=1 sends EVERY elimination through the fallback
+    (and its column un-permutation): the golden replay and the random cases with 18..32 streams must still pass."""
+    import subprocess
+    import sys
+    env = dict(os.environ, RTD_BC_FORCE_PIVOT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"),
+                        os.path.join(os.path.dirname(__file__), "test_gpu_random_parity.py"),
+                        "-k", "reference_golden or stamnes or synthetic_config or random or edge_cases or cfg4_batch"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
