@@ -808,7 +808,7 @@ struct GjT<NB, 16> {
 // Threshold: a multiplier |f| > RTD_GJ_GROWTH flags the elimination.  The pivoted redo is COLD code -- each one costs
 // ~45 000 cycles of instruction-cache misses, so at threshold 8 the 3.1 % of flagged eliminations cost 20 % of the
 // kernel (5.2 ms against 4.1 ms with the fallback compiled out).  64 is the classical relaxed threshold of sparse
-// direct solvers (u = 1/64: local growth <= 65, i.e. ~1e-14 instead of 1e-16 relative): 0.4 % flagged, 4.4 ms,
+// direct solvers (u = 1/64: local growth <= 65, i.e. ~1e-14 instead of 1e-16 relative): well under 1 % flagged, 4.3 ms,
 // parity against the oracle unchanged to all printed digits (1.62e-11 abs, 4.10e-10 rel; also at 512).
 #ifndef RTD_GJ_GROWTH
 #define RTD_GJ_GROWTH 64.0
