@@ -805,11 +805,12 @@ struct GjT<NB, 16> {
 // repeats the elimination from its saved inputs with the pivoted GjT (counts from a temporary statistics build).
 // The pivot column is scaled by the same FMA as the others: its own broadcast value is itself, so f = 1 - 1/pivot
 // gives v - f v = v / pivot.
-// Threshold: a multiplier |f| > RTD_GJ_GROWTH flags the elimination.  The pivoted redo is COLD code -- each one costs
-// ~45 000 cycles of instruction-cache misses, so at threshold 8 the 3.1 % of flagged eliminations cost 20 % of the
-// kernel (5.2 ms against 4.1 ms with the fallback compiled out).  64 is the classical relaxed threshold of sparse
-// direct solvers (u = 1/64: local growth <= 65, i.e. ~1e-14 instead of 1e-16 relative): well under 1 % flagged, 4.3 ms,
-// parity against the oracle unchanged to all printed digits (1.62e-11 abs, 4.10e-10 rel; also at 512).
+// Threshold: a multiplier |f| > RTD_GJ_GROWTH flags the elimination.  The pivoted redo is slow (LDS-latency-bound
+// ds_bpermute chains; measured ~45 000 cycles each, 3 % more instructions but 20 % more kernel time at threshold 8, where
+// 3.1 % of the eliminations are flagged: 5.2 ms against 4.1 ms with the fallback compiled out; the instruction cache is
+// not the reason, SQC_ICACHE_MISSES stays at ~1 600 per launch).  64 is the classical relaxed threshold of sparse direct
+// solvers (u = 1/64: local growth <= 65, i.e. ~1e-14 instead of 1e-16 relative): well under 1 % flagged, 4.3 ms, parity
+// against the oracle unchanged to all printed digits (1.62e-11 abs, 4.10e-10 rel; also at 512).
 #ifndef RTD_GJ_GROWTH
 #define RTD_GJ_GROWTH 64.0
 #endif
