@@ -798,6 +798,20 @@ struct GjT<NB, 16> {
   static __device__ __forceinline__ void run(double (&)[4], double (&)[4], double&, int&, const int, const int) {}
 };
 
+// value of lane K (compile-time) of this lane's 16-lane row through the LDS crossbar: ds_swizzle bit mode,
+// lane' = (lane & 0x10) | K inside each half wavefront.  Same move count as the DPP form (two per double) but on the
+// LDS pipe, which idles in the fused kernel while the VALU is its bound.
+#ifndef RTD_GJ_SWZ
+#define RTD_GJ_SWZ 0  /* 1: the Tb / t rows of the speculative elimination travel by ds_swizzle instead of DPP: 2 % slower (A/B) */
+#endif
+template <int K>
+__device__ __forceinline__ double bcast16_lds(double v) {
+  constexpr int pat = (K << 5) | 0x10;
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
+  return __hiloint2double(hi, lo);
+}
+
 // Speculative, branch-free form of the same elimination with the diagonal as pivot at every step: straight-line
 // code (the 16 steps schedule into each other), no pivot search.  A step whose diagonal candidate is more than a
 // factor RTD_GJ_GROWTH smaller than another unused entry of its row raises `bad` (a zero pivot leaves inf / nan in the
@@ -832,9 +846,17 @@ struct GjFast {
     });
     static_for<0, NB>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
+#if RTD_GJ_SWZ
+      tb[q] = fma(-f, bcast16_lds<K>(tb[q]), tb[q]);
+#else
       tb[q] = fma(-f, bcast16<K>(tb[q]), tb[q]);
+#endif
     });
+#if RTD_GJ_SWZ
+    tv = fma(-f, bcast16_lds<K>(tv), tv);
+#else
     tv = fma(-f, bcast16<K>(tv), tv);
+#endif
     GjFast<NB, K + 1>::run(ta, tb, tv, bad, col);
   }
 };

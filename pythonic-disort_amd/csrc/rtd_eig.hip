@@ -117,11 +117,13 @@ struct JacobiStep {
     const double rho = r2 * approx_rsqrt(r2);
     const double den = delta + copysign(rho, delta);
     const double tt = g2 * approx_rcp(den);
-    const double c = fast_rsqrt(1.0 + tt * tt);
-    const double s = tt * c;
-    const double sg = lo ? -s : s;
+    // c from ONE Newton step (4e-15): the error scales BOTH columns of the pair by the same 1 + eps, so orthogonality and
+    // the directions z are untouched; only the norms k drift, by ~50 rotations x 4e-15 (parity unchanged)
+    const double c = approx_rsqrt(1.0 + tt * tt);
+    const double tsg = lo ? -tt : tt;
+    const double sg = tsg * c;
     notconv |= (gamma * gamma > RTD_JAC_TOL * alpha * beta) ? 1 : 0;
-    alpha = c * c * alpha + sg * (sg * beta + 2.0 * c * gamma);
+    alpha = fma(tsg, gamma, alpha);  // |c w + sg pw|^2 = alpha -+ t gamma for the rotation that annihilates gamma
 #pragma unroll
     for (int i = 0; i < NP; ++i) w[i] = c * w[i] + sg * pw[i];
     JacobiStep<NP, T + 1>::run(w, alpha, j, notconv);
