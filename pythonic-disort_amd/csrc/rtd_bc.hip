@@ -644,6 +644,9 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
 #ifndef RTD_BCF_WAVES
 #define RTD_BCF_WAVES 3
 #endif
+#ifndef RTD_BW_MFMA
+#define RTD_BW_MFMA 0  /* backward sweep: W applied through its factors on the VALU (0) or through M1^T, M2s^T from the matrix cores (1: 2 % slower, A/B) */
+#endif
 
 __device__ __forceinline__ v4f64 mm_t(const v4f64& X, const v4f64& Y) {  // X^T Y
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
@@ -1161,8 +1164,23 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     pk = kk[lp * NP + col];
     pe = Ek[lp * NP + col];
     const double x = cminus, y = e1b * cplus;
+#if RTD_BW_MFMA
+    // (M u)_j = sum_c M^T[c][j] u_c: column dots with M1^T = Y'^T A_l and M2s^T = (A'/k')^T (Y_l k) from the matrix cores
+    v4f64 y0s, a1s;
+    {
+      const double rk1b = fast_rcp(k1b);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        y0s[q] = y0[q] * k0b;
+        a1s[q] = a1[q] * rk1b;
+      }
+    }
+    const v4f64 m1t = mm_t(y1, a0), m2st = mm_t(a1s, y0s);
+    const double cp = rb + 0.5 * (col_dot(m1t, col_to_row(x + y, rowbase, kq)) + col_dot(m2st, col_to_row(y - x, rowbase, kq)));
+#else
     const v4f64 w1 = row_dot(y1, x + y), w2 = row_dot(a1, (y - x) * fast_rcp(k1b));
     const double cp = rb + 0.5 * (col_dot(a0, w1) + k0b * col_dot(y0, w2));
+#endif
     const double cmn = sl - col_dot(hl, col_to_row(cp, rowbase, kq));
     if (kq == 0) {
       coef[(long)l * Q + col] = cmn;
