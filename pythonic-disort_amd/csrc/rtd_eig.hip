@@ -198,6 +198,19 @@ __device__ __forceinline__ double bcast_lane(double v) {
 // symmetric so that A^(K)[j][K] is available in the lane's own registers, and the scaling of a finished column by
 // 1/sqrt(pivot) is deferred to the end: a step is one broadcast and one FMA per element,
 //   col_j[i] -= A^(K)[i][K] * A^(K)[j][K] / A^(K)[K][K]   for j > K (factor 0 for the finished columns j <= K).
+// the same broadcast through the LDS crossbar (ds_swizzle bit mode: lane' = (lane & ~(NP-1) & 0x1f) | K inside each half
+// wavefront): same move count as DPP, other pipe.  RTD_CHOL_SWZ selects it for the trailing updates of the Cholesky steps.
+#ifndef RTD_CHOL_SWZ
+#define RTD_CHOL_SWZ 0  /* A/B: 2.5 % slower than DPP */
+#endif
+template <int NP, int K>
+__device__ __forceinline__ double bcast_lane_lds(double v) {
+  constexpr int pat = (K << 5) | (0x1F & ~(NP - 1));
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
+  return __hiloint2double(hi, lo);
+}
+
 template <int NP, int K>
 struct CholStep {
   static __device__ __forceinline__ void run(double (&col)[NP], double& diag, const int j) {
@@ -205,7 +218,12 @@ struct CholStep {
     const double f = (j > K) ? col[K] * fast_rcp(akk) : 0.0;
     diag = (j == K) ? akk : diag;
 #pragma unroll
-    for (int i = K + 1; i < NP; ++i) col[i] = fma(-bcast_lane<NP, K>(col[i]), f, col[i]);
+    for (int i = K + 1; i < NP; ++i) {
+      if constexpr (RTD_CHOL_SWZ && NP <= 16)
+        col[i] = fma(-bcast_lane_lds<NP, K>(col[i]), f, col[i]);
+      else
+        col[i] = fma(-bcast_lane<NP, K>(col[i]), f, col[i]);
+    }
     CholStep<NP, K + 1>::run(col, diag, j);
   }
 };
