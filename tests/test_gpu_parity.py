@@ -429,3 +429,21 @@ def test_fused_bc_kernel_pivoted_path_on_goldens():
                         "-k", "reference_golden or stamnes or synthetic_config or random or edge_cases or cfg4_batch"],
                        env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_high_precision_truth_m0(amd):
+    """The HIP path against a 40-digit (mpmath) solution of the m = 0 discrete-ordinate problem computed straight from
+    the ODE system (tools/hp_truth_m0.py; fixture tests/golden/hp_truth_m0.npz): a benign six-layer atmosphere and one
+    with two omega = 1 - 1e-6 layers between absorbing ones.  The HIP path stays at rounding level on both; the
+    reference's algorithm in float64 (the oracle) is at 1.5e-13 and 6e-9 (test_oracle_against_high_precision_truth)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hp_cases", os.path.join(os.path.dirname(__file__), "..", "tools", "hp_cases.py"))
+    hp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hp)
+    Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "hp_truth_m0.npz"))
+    for name, kw in (("benign", hp.benign_case()), ("harsh", hp.harsh_case())):
+        _, fu, fd, u0 = amd.pydisort(**kw)
+        tau = np.concatenate(([0.0], kw["tau_arr"]))
+        truth = Z[name]
+        assert np.max(np.abs(u0(tau) - truth)) <= 1e-12 * np.max(np.abs(truth)), name

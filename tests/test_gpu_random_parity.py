@@ -84,3 +84,71 @@ def test_random_case_matches_oracle(seed):
         wantu = ref[4](tau, phi)
         su = max(float(np.max(np.abs(wantu))), scale)
         assert np.max(np.abs(got[4](tau, phi) - wantu)) / su < 1e-8
+
+
+def make_case_many_streams(seed):
+    """Cases for the fused boundary-condition kernel (18 <= NQuad <= 32, i.e. N = 9..16 padded to 16 lanes): more
+    layers, thick / thin / non-scattering / near-conservative layers mixed, every source type."""
+    rng = np.random.default_rng([2027, seed])
+    L = int(rng.integers(1, 26))
+    NQuad = int(rng.choice([18, 20, 22, 24, 26, 28, 30, 32]))
+    N = NQuad // 2
+    nall = NQuad + int(rng.integers(1, 8))
+    tau = np.cumsum(10.0 ** rng.uniform(-4, 1.5, L))
+    omega = rng.uniform(0.0, 0.999, L)
+    omega[rng.random(L) < 0.1] = 0.0
+    omega[rng.random(L) < 0.1] = 1 - 1e-6
+    g = rng.uniform(0.0, 0.92, L)
+    Leg = g[:, None] ** np.arange(nall)[None, :]
+    kw = dict(tau_arr=tau, omega_arr=omega, NQuad=NQuad, Leg_coeffs_all=Leg, mu0=0.0, I0=0.0, phi0=0.0)
+    beam = rng.random() < 0.75
+    if beam:
+        kw.update(mu0=float(rng.uniform(0.03, 1.0)), I0=float(rng.uniform(0.1, 5.0)), phi0=float(rng.uniform(0, 6.2)))
+    if rng.random() < 0.6:
+        kw["f_arr"] = g**NQuad
+    if rng.random() < 0.4:
+        ns = int(rng.integers(1, 4))
+        kw["s_poly_coeffs"] = rng.uniform(0.0, 1.0, (L, ns)) * 10.0 ** (-np.arange(ns))[None, :]
+    if rng.random() < 0.5:
+        kw["b_pos"] = float(rng.uniform(0, 1)) if rng.random() < 0.5 else rng.uniform(0, 1, N)
+    if rng.random() < 0.5:
+        kw["b_neg"] = float(rng.uniform(0, 1))
+    if not beam and "s_poly_coeffs" not in kw and "b_pos" not in kw and "b_neg" not in kw:
+        kw["b_neg"] = 0.5
+    r = rng.random()
+    if r < 0.3:
+        kw["BDRF_Fourier_modes"] = [float(rng.uniform(0.05, 0.9))]
+    elif r < 0.6:
+        a, b = rng.uniform(0.05, 0.4), rng.uniform(0.0, 0.5)
+        kw["BDRF_Fourier_modes"] = [lambda mu, nmup, a=a, b=b: a * (1 + b * np.outer(mu, nmup)),
+                                    lambda mu, nmup, a=a: 0.3 * a * np.outer(np.sqrt(1 - mu**2), np.sqrt(1 - np.asarray(nmup) ** 2))]
+    return kw
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_many_stream_case_matches_oracle(seed):
+    import pydisort_amd
+    from oracle import disort_oracle as O
+    kw = make_case_many_streams(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        try:
+            ref = O.pydisort(**kw)
+        except Exception:
+            pytest.skip("oracle rejects this random input")
+        got = pydisort_amd.pydisort(**kw)
+    tau_arr = kw["tau_arr"]
+    rng = np.random.default_rng(seed)
+    tau = np.sort(np.concatenate(([0.0, tau_arr[-1]], tau_arr[:-1], rng.uniform(0, tau_arr[-1], 5))))
+    phi = np.array([0.0, 0.7, 3.0, 5.5])
+    want = ref[4](tau, phi)
+    scale = max(float(np.max(np.abs(want))), 1e-300)
+    if not np.isfinite(scale) or np.max(np.abs(ref[1](tau))) > 1e8 * scale:
+        pytest.skip("oracle result is not finite / ill-conditioned")
+    # Layers with omega = 1 - 1e-6 limit the ORACLE, not the HIP path: against a 40-digit solution the reference's
+    # algorithm in float64 is off by 6e-9 on such a mix while the HIP path is at 2e-14 (tools/hp_truth_m0.py,
+    # test_high_precision_truth_m0); random mixes reach 3e-7.  Everything else agrees to rounding.
+    near_conservative = bool(np.any(kw["omega_arr"] > 1 - 1e-5))
+    tol = 1e-5 if near_conservative else 1e-9
+    assert np.max(np.abs(got[4](tau, phi) - want)) / scale < tol
+    assert np.allclose(got[1](tau), ref[1](tau), rtol=10 * tol, atol=tol * scale)

@@ -49,3 +49,25 @@ def test_oracle_on_baseline_literal_configs(name):
     scale = np.max(np.abs(z["u"]))
     assert np.max(np.abs(u(tau_pts, z["phi"]) - z["u"])) / scale < 1e-10
     assert np.allclose(Fp(tau_pts), z["flux_up"], rtol=1e-10, atol=1e-13 * scale)
+
+
+def test_oracle_against_high_precision_truth():
+    """How far the reference's algorithm in float64 (this oracle) is from a 40-digit solution (tools/hp_truth_m0.py):
+    rounding level on a benign atmosphere, ~6e-9 when omega = 1 - 1e-6 layers are present.  GPU parity tests against
+    the oracle use a looser tolerance for such inputs for this reason."""
+    import importlib.util
+    import os
+    import numpy as np
+    from oracle import disort_oracle as O
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("hp_cases", os.path.join(here, "..", "tools", "hp_cases.py"))
+    hp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hp)
+    Z = np.load(os.path.join(here, "golden", "hp_truth_m0.npz"))
+    for name, kw, tol in (("benign", hp.benign_case(), 1e-12), ("harsh", hp.harsh_case(), 1e-7)):
+        _, fu, fd, u0 = O.pydisort(**kw)
+        tau = np.concatenate(([0.0], kw["tau_arr"]))
+        truth = Z[name]
+        err = np.max(np.abs(u0(tau) - truth)) / np.max(np.abs(truth))
+        assert err <= tol, (name, err)
+        assert np.allclose(u0(tau), Z[name + "_oracle"], rtol=0, atol=1e-11 * np.max(np.abs(truth)))
