@@ -26,6 +26,7 @@ struct RtdDev {
   // Legendre tables
   double* Y;   // [M][P][NP]   normalised associated Legendre functions at the quadrature nodes
   double* Y0;  // [C][M][P]    the same at -mu0 of each column
+  const int* lperm;  // [C][L]  layer order of the eigen stage: layers of similar Jacobi sweep counts share a wavefront
   double* att;  // [C][L+1]    beam attenuation exp(-tau*_l / mu0) at the scaled layer boundaries (beam only)
   // per-column inputs
   const double *omega, *tau, *taus0, *scale, *wleg, *mu0, *I0, *phi0, *rescale;

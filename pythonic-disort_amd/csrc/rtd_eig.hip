@@ -258,9 +258,9 @@ __device__ __forceinline__ ProbId locate(const RtdDev& d, const int tx = threadI
   ProbId p;
   p.m = (int)(cmi % d.M);
   p.c = (int)(cmi / d.M);
-  p.l = chunk * GPW + tx / NP;
-  p.valid = p.l < d.L;
-  if (!p.valid) p.l = d.L - 1;  // redo the last layer, skip the stores
+  const int slot = chunk * GPW + tx / NP;
+  p.valid = slot < d.L;
+  p.l = d.lperm[(long)p.c * d.L + (p.valid ? slot : d.L - 1)];  // invalid groups redo the last slot and skip the stores
   p.pid = cmi * d.L + p.l;
   return p;
 }
