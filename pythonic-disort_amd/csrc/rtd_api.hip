@@ -267,6 +267,9 @@ int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** out) {
   d.C = (int)C; d.L = (int)L; d.N = N; d.NP = (int)NP; d.P = (int)P; d.M = (int)M; d.Ns = (int)Ns;
   d.NBDRF = (int)NB; d.beam = dims->beam ? 1 : 0;
   d.flags = getenv("RTD_BC_FORCE_PIVOT") ? 1 : 0;
+  const bool split32 = NP == 32 && getenv("RTD_EIG32_SPLIT") != nullptr;
+  d.Lw = nullptr;
+  d.Qw = nullptr;
   int rc = 0;
   double *mu = nullptr, *w = nullptr, *invmu = nullptr, *S = nullptr, *T = nullptr, *omega = nullptr, *tau = nullptr,
          *taus0 = nullptr, *scale = nullptr, *wleg = nullptr, *mu0 = nullptr, *I0 = nullptr, *phi0 = nullptr,
@@ -293,7 +296,7 @@ int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** out) {
     A(bpos, C * M * NP) A(bneg, C * M * NP) A(spoly, C * L * Ns) A(bq, C * NB * NP * NP) A(bq0, C * NB * NP)
     A(d.Ym, C * M * L * NP * NP) A(d.Am, C * M * L * NP * NP) A(d.kk, C * M * L * NP) A(d.Bv, C * M * L * Q2)
     A(d.dq, C * L * Ns * Q2) A(d.zneg, C * L * NP) A(d.coef, C * M * L * Q2)
-    A(d.Lw, NP == 32 ? C * M * L * NP * NP : 1) A(d.Qw, NP == 32 ? C * M * L * NP * NP : 1)  // 3-kernel eigen path only
+    if (split32) { A(d.Lw, C * M * L * NP * NP) A(d.Qw, C * M * L * NP * NP) }  // three-kernel eigen path only (RTD_EIG32_SPLIT)
     A(d.Fws, C * M * (L - 1) * Q2 * Q2) A(d.Ek, C * M * L * NP)
     A(d.sweeps, 1) A(d.status, 1)
 #undef A

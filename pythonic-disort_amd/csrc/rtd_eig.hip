@@ -14,6 +14,7 @@
 // Jacobi iteration.  One problem occupies NP lanes of a wavefront (64/NP problems per wave); lane j
 // owns column j of every matrix in registers; columns are exchanged with cross-lane swizzles,
 // rotation parameters and small vectors through LDS.
+#include <cstdlib>
 #include <type_traits>
 
 #include "rtd_device.h"
@@ -588,13 +589,13 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused eigen stage (NP <= 16): assembly, Cholesky factors, one-sided Jacobi and the eigenvector /
+// Fused eigen stage: assembly, Cholesky factors, one-sided Jacobi and the eigenvector /
 // particular-solution stage in ONE kernel per (c, m, l).  F, L, Qm and k Z never leave the CU (registers + LDS):
 // compared with the three-kernel pipeline this removes 10.6 KB of HBM traffic per problem (a third of the path's
 // total) and the Lw / Qw workspaces.
 // ------------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(64, RTD_EIGEN_WAVES) void rtd_eigen_kernel(RtdDev d) {
+__global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : 1)) void rtd_eigen_kernel(RtdDev d) {
   constexpr int GPW = 64 / NP;
   constexpr int LD = NP + 1;
   __shared__ double sL[GPW][NP * LD];  // Cholesky factor L of Pm
@@ -916,8 +917,8 @@ void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part) {
   // part 0: assembly + Cholesky + F, 1: Jacobi, 2: eigenvector blocks / particular solutions
   const int gpw = 64 / d.NP;
   const dim3 grid((unsigned)((long)d.C * d.M * ((d.L + gpw - 1) / gpw)));
-  // NP <= 16: one fused kernel (launched as part 1); NP = 32: three kernels (the fused form would not fit the
-  // register file) exchanging F, L, Qm, k Z through the Ym / Am / Lw / Qw buffers
+  // One fused kernel (launched as part 1).  RTD_EIG32_SPLIT=1 selects, for NP = 32, the earlier three-kernel pipeline
+  // that exchanges F, L, Qm, k Z through the Ym / Am / Lw / Qw buffers (A/B: 25.6 ms against 17.1 ms fused on cfg5).
 #define RTD_EIG_FUSED(NPV)                                                                      \
   case NPV:                                                                                     \
     if (part == 1) hipLaunchKernelGGL(rtd_eigen_kernel<NPV>, grid, dim3(64), 0, s, d);          \
@@ -927,6 +928,10 @@ void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part) {
     RTD_EIG_FUSED(8)
     RTD_EIG_FUSED(16)
     case 32:
+      if (d.Lw == nullptr) {  // default: fused (the plan did not allocate the exchange buffers)
+        if (part == 1) hipLaunchKernelGGL(rtd_eigen_kernel<32>, grid, dim3(64), 0, s, d);
+        break;
+      }
       if (part == 0) hipLaunchKernelGGL(rtd_asm_kernel<32>, grid, dim3(64), 0, s, d);
       if (part == 1) hipLaunchKernelGGL(rtd_jacobi_kernel<32>, grid, dim3(64), 0, s, d);
       if (part == 2) hipLaunchKernelGGL(rtd_post_kernel<32>, grid, dim3(64), 0, s, d);
