@@ -131,6 +131,27 @@ int rtd_plan_result_dev_ptrs(rtd_plan* plan, void** u_dev, int64_t* u_bytes, voi
 int rtd_plan_get_tensors(rtd_plan* plan, int32_t column, double* GC, double* K, double* B,
                          double* G_inv_mu_inv, double* G);
 
+/* --- one-call forms (rtd_solve_batch / rtd_solve_tensors) -------------------------------- */
+/* A struct of the prepared arguments of _assemble_intensity_and_fluxes (_assemble.py:8-32) with the column axis; the
+ * field meanings are those of rtd_plan_set_quadrature / rtd_plan_set_columns.  NULL optional fields as there. */
+typedef struct {
+  const double *mu_pos, *weights;                                         /* [N] */
+  const double *scaled_omega, *tau, *scaled_tau_with_0, *scale_tau, *wleg; /* per column and layer */
+  const double *mu0, *I0, *phi0, *rescale;                                /* [C] */
+  const double *b_pos, *b_neg, *s_poly, *bdrf_q, *bdrf_q0;                /* optional */
+} rtd_inputs;
+
+/* create plan -> upload -> solve -> evaluate at (tau [C][ntau], phi [nphi]) -> destroy, in one call: what one batched
+ * call of the reference's _assemble_intensity_and_fluxes + closures would return.  Output pointers may be NULL. */
+int rtd_solve_batch(const rtd_dims* dims, int32_t device, const rtd_inputs* in, int32_t ntau, const double* tau,
+                    int32_t nphi, const double* phi, double* u, double* u0, double* flux_up,
+                    double* flux_down_diffuse, double* flux_down_direct);
+
+/* the same up to the solve, returning the tensors the reference's closures capture for column `column`
+ * (GC, K, B, G_inv_mu_inv, G in the reference layout; _solve_for_coeffs.py:390). */
+int rtd_solve_tensors(const rtd_dims* dims, int32_t device, const rtd_inputs* in, int32_t column, double* GC, double* K,
+                      double* B, double* G_inv_mu_inv, double* G);
+
 /* --- measurement --------------------------------------------------------------------------- */
 /* When enabled, rtd_plan_run/solve bracket each kernel with HIP events on the plan's stream. */
 int rtd_plan_enable_timing(rtd_plan* plan, int32_t enable);

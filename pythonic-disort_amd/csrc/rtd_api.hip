@@ -647,6 +647,44 @@ int rtd_plan_get_tensors(rtd_plan* p, int32_t column, double* GC, double* K, dou
   return 0;
 }
 
+static int solve_once(const rtd_dims* dims, int32_t device, const rtd_inputs* in, rtd_plan** out) {
+  if (!dims || !in || !out) return fail(RTD_ERR_ARG, "null argument");
+  rtd_plan* p = nullptr;
+  int rc = rtd_plan_create(dims, device, &p);
+  if (rc) return rc;
+  rc = rtd_plan_set_quadrature(p, in->mu_pos, in->weights);
+  if (!rc)
+    rc = rtd_plan_set_columns(p, in->scaled_omega, in->tau, in->scaled_tau_with_0, in->scale_tau, in->wleg, in->mu0,
+                              in->I0, in->phi0, in->rescale, in->b_pos, in->b_neg, in->s_poly, in->bdrf_q, in->bdrf_q0);
+  if (!rc) rc = rtd_plan_solve(p);
+  if (rc) {
+    rtd_plan_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return 0;
+}
+
+int rtd_solve_batch(const rtd_dims* dims, int32_t device, const rtd_inputs* in, int32_t ntau, const double* tau,
+                    int32_t nphi, const double* phi, double* u, double* u0, double* flux_up, double* fdn, double* fdir) {
+  rtd_plan* p = nullptr;
+  int rc = solve_once(dims, device, in, &p);
+  if (rc) return rc;
+  rc = rtd_plan_evaluate(p, ntau, tau, nphi, phi, 0, u, u0, flux_up, fdn, fdir, nullptr);
+  rtd_plan_destroy(p);
+  return rc;
+}
+
+int rtd_solve_tensors(const rtd_dims* dims, int32_t device, const rtd_inputs* in, int32_t column, double* GC, double* K,
+                      double* B, double* Gim, double* G) {
+  rtd_plan* p = nullptr;
+  int rc = solve_once(dims, device, in, &p);
+  if (rc) return rc;
+  rc = rtd_plan_get_tensors(p, column, GC, K, B, Gim, G);
+  rtd_plan_destroy(p);
+  return rc;
+}
+
 int rtd_plan_enable_timing(rtd_plan* p, int32_t enable) {
   if (!p) return fail(RTD_ERR_ARG, "null plan");
   if (enable && !p->evt[0]) {

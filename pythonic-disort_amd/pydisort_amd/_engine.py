@@ -188,3 +188,50 @@ def device_count():
     lib = _lib.load()
     rc = lib.rtd_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+def _inputs_struct(prep):
+    """(rtd_inputs, keep-alive list) for the one-call entry points of include/rtd.h."""
+    keys = [("mu_pos", "mu"), ("weights", "W"), ("scaled_omega", "omega_s"), ("tau", "tau"),
+            ("scaled_tau_with_0", "tau_s0"), ("scale_tau", "scale_tau"), ("wleg", "wleg"), ("mu0", "mu0"), ("I0", "I0"),
+            ("phi0", "phi0"), ("rescale", "rescale"), ("b_pos", "b_pos"), ("b_neg", "b_neg"), ("s_poly", "s_s"),
+            ("bdrf_q", "bdrf_q"), ("bdrf_q0", "bdrf_q0")]
+    keep, s = [], _lib.rtd_inputs()
+    for field, k in keys:
+        a = _f64(prep[k])
+        keep.append(a)
+        setattr(s, field, _lib.dptr(a))
+    return s, keep
+
+
+def _dims(prep):
+    return _lib.rtd_dims(prep["C"], prep["L"], 2 * prep["N"], prep["P"], prep["M"], prep["Ns"], prep["NBDRF"],
+                         1 if prep["beam"] else 0)
+
+
+def solve_batch_once(prep, tau, phi, device=0):
+    """One call of the C ABI's ``rtd_solve_batch``: plan creation, upload, solve, evaluation and teardown inside the
+    library.  tau [C, ntau], phi [nphi] -> dict(u, u0, flux_up, flux_down_diffuse, flux_down_direct)."""
+    lib = _lib.load()
+    s, keep = _inputs_struct(prep)
+    dims = _dims(prep)
+    tau, phi = _f64(np.atleast_2d(tau)), _f64(np.atleast_1d(phi))
+    Cn, Q, nt, nph = prep["C"], 2 * prep["N"], tau.shape[1], phi.shape[0]
+    out = dict(u=np.empty((Cn, Q, nt, nph)), u0=np.empty((Cn, Q, nt)), flux_up=np.empty((Cn, nt)),
+               flux_down_diffuse=np.empty((Cn, nt)), flux_down_direct=np.empty((Cn, nt)))
+    _lib.check(lib.rtd_solve_batch(C.byref(dims), device, C.byref(s), nt, _lib.dptr(tau), nph, _lib.dptr(phi),
+                                   *[_lib.dptr(out[k]) for k in ("u", "u0", "flux_up", "flux_down_diffuse", "flux_down_direct")]))
+    return out
+
+
+def solve_tensors_once(prep, column=0, device=0):
+    """One call of ``rtd_solve_tensors``: the tensors the reference's closures capture for one column."""
+    lib = _lib.load()
+    s, keep = _inputs_struct(prep)
+    dims = _dims(prep)
+    M, L, Q = prep["M"], prep["L"], 2 * prep["N"]
+    out = dict(GC=np.empty((M, L, Q, Q)), K=np.empty((M, L, Q)), B=np.empty((M, L, Q)), G_inv_mu_inv=np.empty((L, Q)),
+               G=np.empty((M, L, Q, Q)))
+    _lib.check(lib.rtd_solve_tensors(C.byref(dims), device, C.byref(s), column,
+                                     *[_lib.dptr(out[k]) for k in ("GC", "K", "B", "G_inv_mu_inv", "G")]))
+    return out

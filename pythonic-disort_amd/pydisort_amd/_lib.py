@@ -16,6 +16,15 @@ class rtd_dims(C.Structure):
 
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
+
+
+class rtd_inputs(C.Structure):
+    """Prepared arguments of one batch for the one-call entry points (include/rtd.h: rtd_inputs)."""
+    _fields_ = [(n, _dp) for n in
+                ("mu_pos", "weights", "scaled_omega", "tau", "scaled_tau_with_0", "scale_tau", "wleg", "mu0", "I0",
+                 "phi0", "rescale", "b_pos", "b_neg", "s_poly", "bdrf_q", "bdrf_q0")]
+
+
 # every symbol include/rtd.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "rtd_version": (C.c_int, []),
@@ -29,6 +38,9 @@ SIGNATURES = {
     "rtd_plan_set_columns": (C.c_int, [_vp] + [_dp] * 14),
     "rtd_plan_set_bdrf_samples": (C.c_int, [_vp, C.c_int32, _dp, _dp]),
     "rtd_plan_solve": (C.c_int, [_vp]),
+    "rtd_solve_batch": (C.c_int, [C.POINTER(rtd_dims), C.c_int32, C.POINTER(rtd_inputs), C.c_int32, _dp, C.c_int32, _dp]
+                        + [_dp] * 5),
+    "rtd_solve_tensors": (C.c_int, [C.POINTER(rtd_dims), C.c_int32, C.POINTER(rtd_inputs), C.c_int32] + [_dp] * 5),
     "rtd_plan_evaluate": (C.c_int, [_vp, C.c_int32, _dp, C.c_int32, _dp, C.c_int32] + [_dp] * 6),
     "rtd_plan_set_nt": (C.c_int, [_vp, C.c_int32, _dp, _dp, _dp, _dp]),
     "rtd_plan_set_eval_points": (C.c_int, [_vp, C.c_int32, _dp, C.c_int32, _dp]),

@@ -447,3 +447,25 @@ def test_high_precision_truth_m0(amd):
         tau = np.concatenate(([0.0], kw["tau_arr"]))
         truth = Z[name]
         assert np.max(np.abs(u0(tau) - truth)) <= 1e-12 * np.max(np.abs(truth)), name
+
+
+@pytest.mark.gpu
+def test_one_call_entry_points_equal_the_plan_api(amd):
+    """rtd_solve_batch / rtd_solve_tensors (the one-call names of SURVEY section 8(b)) against the plan API on cfg3
+    columns (thermal + beam + BDRF + Dirichlet sources)."""
+    from pydisort_amd import synthetic, _engine
+    cfg = synthetic.cfg3_columns(5, big=False)
+    _, sol = amd.pydisort_batch(**cfg)
+    prep = sol.plan.prep
+    tau = np.concatenate((np.zeros((5, 1)), cfg["tau_arr"]), axis=1)
+    phi = np.array([0.0, 1.1, 3.0])
+    once = _engine.solve_batch_once(prep, tau, phi)
+    assert np.array_equal(once["u"], sol.u(tau, phi))
+    assert np.array_equal(once["flux_up"], sol.flux_up(tau))
+    fd = sol.flux_down(tau)
+    assert np.array_equal(once["flux_down_diffuse"], fd[0]) and np.array_equal(once["flux_down_direct"], fd[1])
+    t1 = _engine.solve_tensors_once(prep, column=3)
+    t2 = sol.plan.tensors(3)
+    for k in ("GC", "K", "B"):
+        assert np.array_equal(t1[k], t2[k]), k
+    sol.plan.close()
