@@ -87,6 +87,14 @@ int rtd_plan_set_columns(rtd_plan* plan, const double* scaled_omega, const doubl
  * Call after rtd_plan_set_columns (whose bdrf_q / bdrf_q0 may then be NULL) and before rtd_plan_solve. */
 int rtd_plan_set_bdrf_samples(rtd_plan* plan, int32_t nphi, const double* rho_qq, const double* rho_q0);
 
+/* Fourier-mode shard (the partition for fewer columns than GPUs): the plan's nfourier local modes
+ * stand for the modes first, first + stride, ... of `total` (the reference's NFourier; modes are independent through
+ * the eigen stage and the boundary-condition solve, _gen_part.py:91, _coeffs.py:111, and meet only in the Fourier sum,
+ * _assemble.py:256-260).  b_pos / b_neg of rtd_plan_set_columns are then those of the local modes.  The evaluators
+ * return the shard's partial sums (u0, fluxes and the thermal terms from the shard that owns mode 0 only); summing the
+ * shards gives the full result: rtd_comm_allreduce_results.  Default: first 0, stride 1, total = nfourier. */
+int rtd_plan_set_mode_shard(rtd_plan* plan, int32_t first, int32_t stride, int32_t total);
+
 /* --- solve: _solve_for_gen_and_part_sols + _solve_for_coeffs on the device ---------------- */
 /* Asynchronous on the plan's stream. */
 int rtd_plan_solve(rtd_plan* plan);
@@ -174,6 +182,9 @@ int rtd_comm_unique_id(char id[128]);
 int rtd_comm_init(rtd_plan* plan, const char id[128], int32_t rank, int32_t nranks);
 int rtd_comm_allgather_fluxes(rtd_plan* plan);               /* asynchronous on the plan's stream */
 int rtd_comm_fetch_gathered(rtd_plan* plan, double* out);    /* host [nranks][3][C][ntau] */
+/* mode shards: ncclAllReduce(sum) of the u, u0 and flux results of rtd_plan_run over the ranks, in place, asynchronous
+ * on the plan's stream (rtd_plan_fetch then returns the complete fields on every rank) */
+int rtd_comm_allreduce_results(rtd_plan* plan);
 int rtd_comm_destroy(rtd_plan* plan);
 
 enum {

@@ -267,6 +267,7 @@ int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** out) {
   d.C = (int)C; d.L = (int)L; d.N = N; d.NP = (int)NP; d.P = (int)P; d.M = (int)M; d.Ns = (int)Ns;
   d.NBDRF = (int)NB; d.beam = dims->beam ? 1 : 0;
   d.flags = getenv("RTD_BC_FORCE_PIVOT") ? 1 : 0;
+  d.m0 = 0; d.mstep = 1; d.mtot = (int)M;
   const bool split32 = NP == 32 && getenv("RTD_EIG32_SPLIT") != nullptr;
   d.Lw = nullptr;
   d.Qw = nullptr;
@@ -473,6 +474,20 @@ int rtd_plan_set_bdrf_samples(rtd_plan* p, int32_t nphi, const double* rho_qq, c
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   (void)hipFree(tmp);
   if (e != hipSuccess) return fail(RTD_ERR_HIP, hipGetErrorString(e));
+  p->solved = false;
+  return 0;
+}
+
+int rtd_plan_set_mode_shard(rtd_plan* p, int32_t first, int32_t stride, int32_t total) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  RtdDev& d = p->d;
+  if (first < 0 || stride < 1 || total < 1 || first + (int64_t)stride * (d.M - 1) > total - 1)
+    return fail(RTD_ERR_ARG, "mode shard: need 0 <= first, stride >= 1 and first + stride (nfourier - 1) <= total - 1");
+  if (total > d.P) return fail(RTD_ERR_ARG, "mode shard: total number of Fourier modes exceeds nleg");
+  d.m0 = first;
+  d.mstep = stride;
+  d.mtot = total;
+  p->tables_ready = false;
   p->solved = false;
   return 0;
 }
@@ -726,6 +741,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -744,6 +760,7 @@ RcclApi* rccl() {
       api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
       api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");
       api.AllGather = (decltype(api.AllGather))dlsym(api.h, "ncclAllGather");
+      api.AllReduce = (decltype(api.AllReduce))dlsym(api.h, "ncclAllReduce");
       api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
       api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
       if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) api.h = nullptr;
@@ -793,6 +810,22 @@ int rtd_comm_allgather_fluxes(rtd_plan* p) {
   if (rc) return rc;
   ncclResult_t nr = rccl()->AllGather(p->ev_fl, p->gathered, (size_t)n, ncclDouble, p->comm, p->stream);
   if (nr != ncclSuccess) return fail(RTD_ERR_HIP, std::string("ncclAllGather: ") + rccl()->GetErrorString(nr));
+  return 0;
+}
+
+int rtd_comm_allreduce_results(rtd_plan* p) {
+  if (!p || !p->comm) return fail(RTD_ERR_STATE, "communicator not initialised");
+  if (p->ev_ntau < 1) return fail(RTD_ERR_STATE, "no evaluation results to reduce");
+  RcclApi* r = rccl();
+  if (!r || !r->AllReduce) return fail(RTD_ERR_HIP, "ncclAllReduce not available");
+  HIP_TRY(hipSetDevice(p->device));
+  const int64_t C = p->d.C, Qr = 2 * p->d.N, nt = p->ev_ntau, np = p->ev_nphi;
+  struct { double* ptr; int64_t n; } bufs[3] = {{p->ev_u, np > 0 ? C * Qr * nt * np : 0}, {p->ev_u0, C * Qr * nt}, {p->ev_fl, 3 * C * nt}};
+  for (auto& b : bufs) {
+    if (!b.ptr || b.n <= 0) continue;
+    ncclResult_t nr = r->AllReduce(b.ptr, b.ptr, (size_t)b.n, ncclDouble, ncclSum, p->comm, p->stream);
+    if (nr != ncclSuccess) return fail(RTD_ERR_HIP, std::string("ncclAllReduce: ") + r->GetErrorString(nr));
+  }
   return 0;
 }
 

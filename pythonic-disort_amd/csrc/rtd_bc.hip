@@ -179,7 +179,8 @@ __global__ __launch_bounds__(64) void rtd_iface_kernel(RtdDev d) {
   const double* ts0 = d.taus0 + (long)c * (d.L + 1);
   const double tb = ts0[l + 1];
   const double att = d.beam ? exp(-tb / d.mu0[c]) : 0.0;
-  const bool iso = d.Ns > 0 && m == 0;
+  const int mg = d.m0 + d.mstep * m;  // the Fourier mode this local index stands for (mode shards)
+  const bool iso = d.Ns > 0 && mg == 0;
   const double kj = d.kk[p0 * NP + j];
   double rt = 0.0, rb = 0.0;
 #pragma unroll 4
@@ -236,7 +237,8 @@ __global__ __launch_bounds__(256) void rtd_iface_mfma_kernel(RtdDev d) {
   const int m = (int)(cm % d.M), c = (int)(cm / d.M);
   const int col = lane & 15, kq = lane >> 4;
   const double* ts0 = d.taus0 + (long)c * (d.L + 1);
-  const bool iso = d.Ns > 0 && m == 0;
+  const int mg = d.m0 + d.mstep * m;  // the Fourier mode this local index stands for (mode shards)
+  const bool iso = d.Ns > 0 && mg == 0;
   const double mu0 = d.beam ? d.mu0[c] : 1.0;
   // operands of layer l in the MFMA A layout (= B layout of the same matrix): element [i = 4 s + kq][col]
   double a0[4], y0[4], a1[4], y1[4];
@@ -421,7 +423,8 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
   const double* dq = d.dq + (long)c * L * d.Ns * Q;
   double* wsb = d.Fws + cm * Lm1 * Ws<NP>::SLOT;
   double* coef = d.coef + cm * L * Q;
-  const bool iso = d.Ns > 0 && m == 0;
+  const int mg = d.m0 + d.mstep * m;  // the Fourier mode this local index stands for (mode shards)
+  const bool iso = d.Ns > 0 && mg == 0;
   const bool beam = d.beam != 0;
   const double mu0 = beam ? d.mu0[c] : 1.0;
   auto vpoly = [&](int l, double t, int idx) {
@@ -512,9 +515,9 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
       qa[k] = amL[j * NP + k] * rTj;
     }
     double br = d.bpos[cm * NP + j];
-    if (m < d.NBDRF) {
-      const double delta = (m == 0) ? 2.0 : 1.0;
-      const double* qt = d.bdrfq + (((long)c * d.NBDRF + m) * NP + j) * NP;
+    if (mg < d.NBDRF) {
+      const double delta = (mg == 0) ? 2.0 : 1.0;
+      const double* qt = d.bdrfq + (((long)c * d.NBDRF + mg) * NP + j) * NP;
       double rbm = 0.0, rvm = 0.0;
       for (int j2 = 0; j2 < NP; ++j2) {
         const double Rij = delta * qt[j2] * d.mu[j2] * d.w[j2] / d.T[j2];  // R = (1 + delta_m0) q (mu w), times 1/T_j2
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
         if (iso) rvm += Rraw * vpoly(l, ts0[L], NP + j2);
       }
       if (beam) {
-        const double Xs = mu0 * d.I0[c] / M_PI * d.bdrfq0[((long)c * d.NBDRF + m) * NP + j];
+        const double Xs = mu0 * d.I0[c] / M_PI * d.bdrfq0[((long)c * d.NBDRF + mg) * NP + j];
         br += (Xs + rbm - Bv[l * Q + j]) * att;
       }
       if (iso) br += rvm - vpoly(l, ts0[L], j);
@@ -883,7 +886,8 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
   const double* dq = d.dq + (long)c * L * d.Ns * Q;
   double* wsb = d.Fws + cm * Lm1 * Ws<NP>::SLOT;
   double* coef = d.coef + cm * L * Q;
-  const bool iso = d.Ns > 0 && m == 0;
+  const int mg = d.m0 + d.mstep * m;  // the Fourier mode this local index stands for (mode shards)
+  const bool iso = d.Ns > 0 && mg == 0;
   const bool beam = d.beam != 0;
   const double mu0 = beam ? d.mu0[c] : 1.0;
   auto vpoly = [&](int l, double t, int idx) {
@@ -1068,10 +1072,10 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       p0[q] = y0[q] * rTr;
       q0[q] = a0[q] * rTr * rkLc;
     }
-    const bool refl = m < d.NBDRF;
+    const bool refl = mg < d.NBDRF;
     if (refl) {
-      const double delta = (m == 0) ? 2.0 : 1.0;
-      const double* qt = d.bdrfq + (((long)c * d.NBDRF + m) * NP + col) * NP;  // row j = col of q^m
+      const double delta = (mg == 0) ? 2.0 : 1.0;
+      const double* qt = d.bdrfq + (((long)c * d.NBDRF + mg) * NP + col) * NP;  // row j = col of q^m
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int j2 = 4 * q + kq;
@@ -1100,7 +1104,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     if (refl) {
       if (beam) {
         const double rbm = col_dot(rtr, load_row(Bv + l * Q + NP, kq));
-        const double Xs = mu0 * d.I0[c] / M_PI * d.bdrfq0[((long)c * d.NBDRF + m) * NP + col];
+        const double Xs = mu0 * d.I0[c] / M_PI * d.bdrfq0[((long)c * d.NBDRF + mg) * NP + col];
         br += (Xs + rbm - Bv[l * Q + col]) * att;
       }
       if (iso) {

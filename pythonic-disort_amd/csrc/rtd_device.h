@@ -20,6 +20,8 @@
 struct RtdDev {
   // sizes
   int C, L, N, NP, P, M, Ns, NBDRF, beam;
+  // Fourier-mode shard (secondary partition): local mode m stands for the mode m0 + mstep * m of mtot
+  int m0, mstep, mtot;
   int flags;  // bit 0: the fused BC kernel skips its speculative elimination (test hook, env RTD_BC_FORCE_PIVOT)
   // quadrature (padded to NP)
   const double *mu, *w, *invmu, *S, *T;  // S = sqrt(w/mu), T = sqrt(w*mu) (1 for padding)

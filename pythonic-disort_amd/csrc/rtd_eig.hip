@@ -246,6 +246,7 @@ __device__ __forceinline__ double cholesky_columns(double (&col)[NP], const int 
 struct ProbId {
   long pid;
   int c, m, l;
+  int mg;  // the Fourier mode the local index m stands for (mode shards: m0 + mstep * m)
   bool valid;
 };
 template <int NP>
@@ -258,6 +259,7 @@ __device__ __forceinline__ ProbId locate(const RtdDev& d, const int tx = threadI
   const int chunk = (int)((long)blockIdx.x % nchunk);
   ProbId p;
   p.m = (int)(cmi % d.M);
+  p.mg = d.m0 + d.mstep * p.m;
   p.c = (int)(cmi / d.M);
   const int slot = chunk * GPW + tx / NP;
   p.valid = slot < d.L;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_asm_kernel(RtdDev 
 #pragma unroll
   for (int i = 0; i < NP; ++i) acc_e[i] = acc_o[i] = 0.0;
   double cmax = 0.0;
-  for (int ell = m; ell < P; ell += 2) {
+  for (int ell = id.mg; ell < P; ell += 2) {
     {
       const double cl = 0.5 * om * wl[ell];
       cmax = fmax(cmax, fabs(cl));
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
   // isotropic (thermal) source, Fourier mode 0 only (subroutines.py:746-862, _assemble.py:124).
   // Every group runs the barriers below; only groups with m == 0 store.
   if (d.Ns > 0) {
-    const bool act = (m == 0);
+    const bool act = (id.mg == 0);
     // q = L^-1 (T / mu) by forward substitution distributed over the lanes
     double cur = T_j * invmu_j, q_j = 0.0;
     static_for<0, NP>([&](auto ic) {
@@ -523,10 +525,10 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
     const double om = d.omega[(long)c * d.L + l];
     const double* wl = d.wleg + ((long)c * d.L + l) * P;
     const double* Ym = d.Y + (long)m * P * NP;
-    const double fac = d.I0[c] / (4.0 * M_PI) * (m == 0 ? 1.0 : 2.0) * om;
+    const double fac = d.I0[c] / (4.0 * M_PI) * (id.mg == 0 ? 1.0 : 2.0) * om;
     const double* Y0 = d.Y0 + ((long)c * d.M + m) * P;
     double xe = 0.0, xo = 0.0, cmax = 0.0;  // X^e_j, X^o_j of this lane's stream
-    for (int ell = m; ell < P; ell += 2) {
+    for (int ell = id.mg; ell < P; ell += 2) {
       cmax = fmax(cmax, fabs(0.5 * om * wl[ell]));
       xe += fac * wl[ell] * Y0[ell] * Ym[(long)ell * NP + j];
       if (ell + 1 < P) {
@@ -616,7 +618,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : 1)) void rtd_eige
 #pragma unroll
   for (int i = 0; i < NP; ++i) acc_e[i] = acc_o[i] = 0.0;
   double cmax = 0.0;
-  for (int ell = m; ell < P; ell += 2) {
+  for (int ell = id.mg; ell < P; ell += 2) {
     {
       const double cl = 0.5 * om * wl[ell];
       cmax = fmax(cmax, fabs(cl));
@@ -728,10 +730,10 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : 1)) void rtd_eige
   //  T dd = mu0 [ T (x+ - x-) - Pm T s ],  Qm Pm = L^-T Z k^2 Z^T L^T
   if (d.beam) {
     const double mu0 = d.mu0[c];
-    const double fac = d.I0[c] * (0.25 / M_PI) * (m == 0 ? 1.0 : 2.0) * om;
+    const double fac = d.I0[c] * (0.25 / M_PI) * (id.mg == 0 ? 1.0 : 2.0) * om;
     const double* Y0 = d.Y0 + ((long)c * d.M + m) * P;
     double xe = 0.0, xo = 0.0, cmax = 0.0;  // X^e_j, X^o_j of this lane's stream
-    for (int ell = m; ell < P; ell += 2) {
+    for (int ell = id.mg; ell < P; ell += 2) {
       cmax = fmax(cmax, fabs(0.5 * om * wl[ell]));
       xe += fac * wl[ell] * Y0[ell] * Ym[(long)ell * NP + j];
       if (ell + 1 < P) {
@@ -813,7 +815,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : 1)) void rtd_eige
 
   // isotropic (thermal) source, Fourier mode 0 only (subroutines.py:746-862, _assemble.py:124).
   // A wave holds layers of ONE (c, m), so the branch is wave-uniform.
-  if (d.Ns > 0 && m == 0) {
+  if (d.Ns > 0 && id.mg == 0) {
     const bool act = true;
     // zneg_j = -k_j/2 [Z^T L^-1 (T/mu)]_j = -k_j/2 sum_i Y[i][j] T_i/mu_i   (Y = L^-T Z: no triangular solve)
     double zn = 0.0;
@@ -886,14 +888,14 @@ __global__ void rtd_tables_quad_kernel(RtdDev d) {
     for (int ell = 0; ell < d.P; ++ell) out[(long)ell * d.NP] = 0.0;
     return;
   }
-  ybar_column(m, d.P, d.mu[i], out, d.NP);
+  ybar_column(d.m0 + d.mstep * m, d.P, d.mu[i], out, d.NP);
 }
 
 __global__ void rtd_tables_mu0_kernel(RtdDev d) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (c, m)
   if (t >= (long)d.C * d.M) return;
   const int c = (int)(t / d.M), m = (int)(t % d.M);
-  ybar_column(m, d.P, -d.mu0[c], d.Y0 + t * d.P, 1);
+  ybar_column(d.m0 + d.mstep * m, d.P, -d.mu0[c], d.Y0 + t * d.P, 1);
   if (m == 0) {  // beam attenuation at the scaled layer boundaries, used by the boundary-condition kernel
     const double rmu0 = 1.0 / d.mu0[c];
     for (int l = 0; l <= d.L; ++l) d.att[(long)c * (d.L + 1) + l] = exp(-d.taus0[(long)c * (d.L + 1) + l] * rmu0);

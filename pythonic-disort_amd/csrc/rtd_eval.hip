@@ -105,7 +105,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
       vu += d.Bv[ml * Q + jj] * bfac;
       vd += d.Bv[ml * Q + NP + jj] * bfac;
     }
-    if (m == 0 && d.Ns > 0) {  // isotropic-source particular solution (subroutines.py:786-862)
+    if (d.m0 + d.mstep * m == 0 && d.Ns > 0) {  // isotropic-source particular solution (subroutines.py:786-862)
       const double* dq = d.dq + ((long)c * L + l) * d.Ns * Q;
       double tp = antider ? ts : 1.0;
       for (int q = 0; q < d.Ns; ++q) {
@@ -128,12 +128,13 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
       const int ir = idx / ev.nphi, p = idx % ev.nphi;
       const int i2 = ir < N ? ir : NP + (ir - N);
       const double dl = phi0 - ev.phi[p];
-      const double c1 = cos(dl);
-      double ckm1 = 1.0, ck = c1;  // cos(0), cos(dl); Chebyshev recurrence for cos(m dl)
-      double acc = um[i2];
-      for (int m = 1; m < M; ++m) {
+      // sum_k um[k] cos((m0 + k mstep) dl): Chebyshev recurrence in steps of mstep (m0 = 0, mstep = 1 without mode shards)
+      const double cs = cos(d.mstep * dl);
+      double ckm1 = cos((d.m0 - d.mstep) * dl), ck = cos(d.m0 * dl);
+      double acc = 0.0;
+      for (int m = 0; m < M; ++m) {
         acc += um[m * Q + i2] * ck;
-        const double cn = 2.0 * c1 * ck - ckm1;
+        const double cn = 2.0 * cs * ck - ckm1;
         ckm1 = ck;
         ck = cn;
       }
@@ -142,8 +143,10 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
   }
   if (tid < Qr) {
     const int i2 = tid < N ? tid : NP + (tid - N);
-    if (ev.u0 != nullptr) ev.u0[((long)c * Qr + tid) * ev.ntau + t] = rescale * um[i2];
-    if (ev.ulast != nullptr) ev.ulast[((long)c * Qr + tid) * ev.ntau + t] = rescale * um[(M - 1) * Q + i2];
+    // with mode shards the zeroth / last mode belongs to one shard only; the others contribute zeros to the sum
+    const bool own0 = d.m0 == 0, ownlast = d.m0 + d.mstep * (M - 1) == d.mtot - 1;
+    if (ev.u0 != nullptr) ev.u0[((long)c * Qr + tid) * ev.ntau + t] = own0 ? rescale * um[i2] : 0.0;
+    if (ev.ulast != nullptr) ev.ulast[((long)c * Qr + tid) * ev.ntau + t] = ownlast ? rescale * um[(M - 1) * Q + i2] : 0.0;
   }
   // fluxes from the zeroth mode (:519, :568-601)
   if (tid == 0 && (ev.fup != nullptr || ev.fdn != nullptr || ev.fdir != nullptr)) {
@@ -164,9 +167,10 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
       }
     }
     const long o = (long)c * ev.ntau + t;
-    if (ev.fup != nullptr) ev.fup[o] = rescale * 2.0 * M_PI * fu;
-    if (ev.fdn != nullptr) ev.fdn[o] = rescale * (2.0 * M_PI * fd + direct_s - direct);
-    if (ev.fdir != nullptr) ev.fdir[o] = rescale * direct;
+    const double own = (d.m0 == 0) ? 1.0 : 0.0;  // fluxes come from the zeroth mode (mode shards: its owner only)
+    if (ev.fup != nullptr) ev.fup[o] = own * rescale * 2.0 * M_PI * fu;
+    if (ev.fdn != nullptr) ev.fdn[o] = own * rescale * (2.0 * M_PI * fd + direct_s - direct);
+    if (ev.fdir != nullptr) ev.fdir[o] = own * rescale * direct;
   }
 }
 

@@ -27,6 +27,18 @@ class Plan:
         mu, w = _f64(prep["mu"]), _f64(prep["W"])
         _lib.check(lib.rtd_plan_set_quadrature(h, _lib.dptr(mu), _lib.dptr(w)))
         self.set_columns(prep)
+        if prep.get("mode_shard") is not None:
+            self.set_mode_shard(*prep["mode_shard"])
+
+    def set_mode_shard(self, first, stride, total):
+        """The plan's M local Fourier modes stand for the modes first, first + stride, ... of `total`
+        (include/rtd.h: rtd_plan_set_mode_shard); evaluators then return this shard's partial sums."""
+        _lib.check(self._lib.rtd_plan_set_mode_shard(self._h, int(first), int(stride), int(total)))
+        self.solved = False
+
+    def allreduce_results(self):
+        """RCCL all-reduce (sum) of the results of run() over the ranks of the communicator (mode shards)."""
+        _lib.check(self._lib.rtd_comm_allreduce_results(self._h))
 
     def set_columns(self, prep):
         """Upload the prepared per-column inputs (same dimensions as the plan): a plan can be reused for many batches."""

@@ -37,6 +37,7 @@ SIGNATURES = {
     "rtd_plan_set_quadrature": (C.c_int, [_vp, _dp, _dp]),
     "rtd_plan_set_columns": (C.c_int, [_vp] + [_dp] * 14),
     "rtd_plan_set_bdrf_samples": (C.c_int, [_vp, C.c_int32, _dp, _dp]),
+    "rtd_plan_set_mode_shard": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32]),
     "rtd_plan_solve": (C.c_int, [_vp]),
     "rtd_solve_batch": (C.c_int, [C.POINTER(rtd_dims), C.c_int32, C.POINTER(rtd_inputs), C.c_int32, _dp, C.c_int32, _dp]
                         + [_dp] * 5),
@@ -56,6 +57,7 @@ SIGNATURES = {
     "rtd_comm_unique_id": (C.c_int, [C.c_char_p]),
     "rtd_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int32, C.c_int32]),
     "rtd_comm_allgather_fluxes": (C.c_int, [_vp]),
+    "rtd_comm_allreduce_results": (C.c_int, [_vp]),
     "rtd_comm_fetch_gathered": (C.c_int, [_vp, _dp]),
     "rtd_comm_destroy": (C.c_int, [_vp]),
 }

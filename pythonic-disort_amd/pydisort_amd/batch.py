@@ -42,7 +42,7 @@ class BatchSolution:
 
 def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLeg=None, NFourier=None,
                    b_pos=0, b_neg=0, only_flux=False, f_arr=0, NT_cor=False, bdrf_q=None, bdrf_q0=None,
-                   s_poly_coeffs=None, device=0, bdrf_samples=None, NBDRF=None):
+                   s_poly_coeffs=None, device=0, bdrf_samples=None, NBDRF=None, mode_shard=None):
     """Like ``pydisort`` with a leading column axis on every atmospheric input:
     tau_arr, omega_arr, f_arr [C, L]; Leg_coeffs_all [C, L, NLeg_all]; mu0, I0, phi0 [C];
     b_pos / b_neg: scalar, [C], [C, N] or [C, N, NFourier]; s_poly_coeffs [C, L, Ns];
@@ -52,6 +52,9 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
     (``subroutines.sample_BDRF`` builds the samples from a function rho(mu, mu', dphi)).
     NT_cor=True adds the Nakajima-Tanaka corrections to ``u`` on the device (needs a beam in every column,
     f_arr > 0 and more Legendre coefficients than NLeg).
+    mode_shard=(r, G): solve only the Fourier modes r, r + G, r + 2G, ... (the partition for
+    fewer columns than GPUs); the evaluators then return this shard's partial sums -- the shards add up to the full
+    result (u0, fluxes and NT corrections come from shard 0 only; ``Plan.allreduce_results`` sums across RCCL ranks).
     All columns share NQuad, NLeg, NFourier and the layer count.  Returns (mu_arr, BatchSolution)."""
     tau_arr = np.atleast_2d(np.asarray(tau_arr, float))
     C, L = tau_arr.shape
@@ -103,6 +106,16 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
         bq, bq0 = np.zeros((C, nb, N, N)), np.zeros((C, nb, N))  # placeholders: the device fills the tables
     prep = prepare_columns(tau_arr, omega_arr, NQuad, Leg, mu0, I0, phi0, NLeg, NFourier, bc(b_pos), bc(b_neg),
                            f_arr, sp, bq, bq0)
+    if mode_shard is not None:
+        r, G = int(mode_shard[0]), int(mode_shard[1])
+        if not (0 <= r < G <= NFourier):
+            raise ValueError("mode_shard=(r, G) needs 0 <= r < G <= NFourier.")
+        modes = np.arange(r, NFourier, G)
+        prep["b_pos"] = np.ascontiguousarray(prep["b_pos"][:, modes, :])  # the source rescale above saw every mode
+        prep["b_neg"] = np.ascontiguousarray(prep["b_neg"][:, modes, :])
+        prep["M"] = len(modes)
+        prep["mode_shard"] = (r, G, NFourier)
+        NT_cor = NT_cor and r == 0
     plan = Plan(prep, device=device)
     if bdrf_samples is not None:
         plan.set_bdrf_samples(bdrf_samples[0], bdrf_samples[1] if np.any(I0 > 0) else None)

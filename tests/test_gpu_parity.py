@@ -216,6 +216,11 @@ def test_rccl_allgather_single_rank(amd):
     assert got.shape == (1, 3, 8, 6)
     assert np.array_equal(got[0, 0], res["flux_up"]) and np.array_equal(got[0, 1], res["flux_down_diffuse"])
     assert np.array_equal(got[0, 2], res["flux_down_direct"])
+    # the collective of the mode-shard partition (ncclAllReduce, sum) with the same 1-rank communicator: identity
+    plan.allreduce_results()
+    again = plan.fetch()
+    for k in ("u", "u0", "flux_up", "flux_down_diffuse", "flux_down_direct"):
+        assert np.array_equal(again[k], res[k]), k
 
 
 def test_batch_nt_corrections_match_single_column_reference_path(amd):
@@ -469,3 +474,37 @@ def test_one_call_entry_points_equal_the_plan_api(amd):
     for k in ("GC", "K", "B"):
         assert np.array_equal(t1[k], t2[k]), k
     sol.plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_fourier_mode_shards_add_up(amd, G):
+    """SURVEY section 8(e), secondary partition: G plans, each solving the Fourier modes r, r + G, ... of the same
+    columns (what G ranks would do), evaluated separately; the partial intensities, u0 and fluxes must add up to the
+    unsharded result.  cfg3 columns: beam + thermal + Dirichlet + BDRF sources, delta-M off; cfg4: delta-M on."""
+    from pydisort_amd import synthetic
+    for cfg in (synthetic.cfg3_columns(3, big=True), synthetic.cfg4_columns(2)):
+        tau = np.concatenate((np.zeros((cfg["tau_arr"].shape[0], 1)), cfg["tau_arr"]), axis=1)
+        phi = np.array([0.0, 0.9, 2.5, 4.0])
+        _, full = amd.pydisort_batch(**cfg)
+        want_u, want_u0 = full.u(tau, phi), full.u0(tau)
+        want_fu, want_fd = full.flux_up(tau), full.flux_down(tau)
+        full.plan.close()
+        got_u = np.zeros_like(want_u)
+        got_u0 = np.zeros_like(want_u0)
+        got_fu = np.zeros_like(want_fu)
+        got_fd = [np.zeros_like(want_fd[0]), np.zeros_like(want_fd[1])]
+        for r in range(G):
+            _, part = amd.pydisort_batch(mode_shard=(r, G), **cfg)
+            got_u += part.u(tau, phi)
+            got_u0 += part.u0(tau)
+            got_fu += part.flux_up(tau)
+            fd = part.flux_down(tau)
+            got_fd[0] += fd[0]
+            got_fd[1] += fd[1]
+            part.plan.close()
+        s = np.max(np.abs(want_u))
+        assert np.max(np.abs(got_u - want_u)) <= 1e-13 * s
+        assert np.max(np.abs(got_u0 - want_u0)) <= 1e-13 * s
+        assert np.array_equal(got_fu, want_fu)
+        assert np.array_equal(got_fd[0], want_fd[0]) and np.array_equal(got_fd[1], want_fd[1])
