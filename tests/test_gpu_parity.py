@@ -452,6 +452,12 @@ def test_high_precision_truth_m0(amd):
         tau = np.concatenate(([0.0], kw["tau_arr"]))
         truth = Z[name]
         assert np.max(np.abs(u0(tau) - truth)) <= 1e-12 * np.max(np.abs(truth)), name
+    # full intensities (8 Fourier modes, one omega = 1 - 1e-6 layer): u(tau, phi) against the 40-digit Fourier sum
+    kw = hp.intensity_case()
+    _, fu, fd, u0, u = amd.pydisort(**kw)
+    tau = np.concatenate(([0.0], kw["tau_arr"]))
+    truth = Z["intensity"]
+    assert np.max(np.abs(u(tau, hp.PHI) - truth)) <= 1e-12 * np.max(np.abs(truth))
 
 
 @pytest.mark.gpu

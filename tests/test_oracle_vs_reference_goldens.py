@@ -71,3 +71,9 @@ def test_oracle_against_high_precision_truth():
         err = np.max(np.abs(u0(tau) - truth)) / np.max(np.abs(truth))
         assert err <= tol, (name, err)
         assert np.allclose(u0(tau), Z[name + "_oracle"], rtol=0, atol=1e-11 * np.max(np.abs(truth)))
+    kw = hp.intensity_case()
+    u = O.pydisort(**kw)[4]
+    tau = np.concatenate(([0.0], kw["tau_arr"]))
+    truth = Z["intensity"]
+    err = np.max(np.abs(u(tau, hp.PHI) - truth)) / np.max(np.abs(truth))
+    assert err <= 1e-8, err   # 2e-10 observed: one omega = 1 - 1e-6 layer

@@ -16,3 +16,9 @@ for name, kw in (("benign", hp.benign_case()), ("harsh", hp.harsh_case())):
     truth, orc = Z[name], Z[name + "_oracle"]
     s = np.max(np.abs(truth))
     print(f"{name:7s} HIP vs truth {np.max(np.abs(got - truth)) / s:.2e}   oracle vs truth {np.max(np.abs(orc - truth)) / s:.2e}   HIP vs oracle {np.max(np.abs(got - orc)) / s:.2e}")
+kw = hp.intensity_case()
+_, fu, fd, u0, u = pydisort_amd.pydisort(**kw)
+tau = np.concatenate(([0.0], kw["tau_arr"]))
+got, truth, orc = u(tau, hp.PHI), Z["intensity"], Z["intensity_oracle"]
+s = np.max(np.abs(truth))
+print(f"intensity HIP vs truth {np.max(np.abs(got - truth)) / s:.2e}   oracle vs truth {np.max(np.abs(orc - truth)) / s:.2e}")

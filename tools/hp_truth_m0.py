@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""High-precision (mpmath, 40 digits) solution of the azimuthally averaged (m = 0) discrete-ordinate problem for a
+"""High-precision (mpmath, 40 digits) solution of the discrete-ordinate problem (every Fourier mode) for a
 beam + Dirichlet atmosphere, straight from the ODE system of SURVEY Appendix A.2-A.4 (full 2N x 2N eigenproblem per
 layer, dense boundary-condition system) -- no symmetrisation, no scaling tricks.  Used to decide who is right when the
 float64 oracle (the reference's algorithm) and the HIP path disagree at the 1e-7 level on near-conservative layers
@@ -14,20 +14,20 @@ from oracle import disort_oracle as O
 mp.mp.dps = 40
 
 
-from hp_cases import harsh_case, benign_case  # noqa: E402
+from hp_cases import harsh_case, benign_case, intensity_case, PHI  # noqa: E402
 
 
-def solve_hp(kw):
+def solve_hp(kw, m=0):
+    """-> u^m at the layer interfaces [Q, L+1] (times the rescale factor), Fourier mode m."""
     p = O.prepare(**kw)
     L, N, P = p["L"], p["N"], p["P"]
     mu = [mp.mpf(float(x)) for x in p["mu"]]
     w = [mp.mpf(float(x)) for x in p["W"]]
-    # Legendre polynomials at +mu_i and at -mu0 by the three-term recurrence in mp
+    # associated Legendre functions P_l^m at +mu_i and at -mu0, with the weight sqrt((l-m)!/(l+m)!) folded in (the
+    # reference's poch factor (:64-65) split evenly over the two factors of every product; signs cancel in pairs)
     def leg(x, n):
-        out = [mp.mpf(1), x]
-        for l in range(1, n - 1):
-            out.append(((2 * l + 1) * x * out[l] - l * out[l - 1]) / (l + 1))
-        return out[:n]
+        return [mp.mpf(0) if l < m else mp.legenp(l, m, x, type=2) * mp.sqrt(mp.factorial(l - m) / mp.factorial(l + m))
+                for l in range(n)]
     Y = [leg(m_, P) for m_ in mu]            # Y[i][l]
     mu0 = mp.mpf(p["mu0"])
     Y0 = leg(-mu0, P)
@@ -45,7 +45,7 @@ def solve_hp(kw):
                 for ell in range(P):
                     t = om / 2 * wl[ell] * Y[i][ell] * Y[j][ell]
                     sp += t
-                    sm += t * (-1) ** ell
+                    sm += t * (-1) ** (ell - m)
                 Dp[i, j], Dm[i, j] = sp, sm
         A = mp.zeros(Q)
         for i in range(N):
@@ -61,9 +61,9 @@ def solve_hp(kw):
         for i in range(N):
             xp = xm = mp.mpf(0)
             for ell in range(P):
-                t = mp.mpf(float(p["I0_4pi"])) * om * wl[ell] * Y0[ell] * Y[i][ell]
+                t = mp.mpf(float(p["I0_4pi"])) * (1 if m == 0 else 2) * om * wl[ell] * Y0[ell] * Y[i][ell]
                 xp += t
-                xm += t * (-1) ** ell
+                xm += t * (-1) ** (ell - m)
             X[i], X[N + i] = xp / mu[i], -xm / mu[i]
         Bv = mp.lu_solve(A + mp.eye(Q) / mu0, X)
         Gs.append(G); Ks.append(ev); Bs.append(Bv)
@@ -77,7 +77,7 @@ def solve_hp(kw):
     Amat = mp.zeros(n)
     rhs = mp.zeros(n, 1)
     row = 0
-    bneg = mp.mpf(float(p["b_neg"][0, 0])); bpos = mp.mpf(float(p["b_pos"][0, 0]))
+    bneg = mp.mpf(float(p["b_neg"][0, m])); bpos = mp.mpf(float(p["b_pos"][0, m]))
     for i in range(N):  # top: downward streams
         for j in range(Q):
             Amat[row, j] = Gs[0][N + i, j] * mode(0, j, ts[0])
@@ -118,7 +118,18 @@ if __name__ == "__main__":
         tau = np.concatenate(([0.0], kw["tau_arr"]))
         orc = u0(tau)
         scale = np.max(np.abs(hp))
-        print(name, "oracle vs high precision: max rel err %.2e" % (np.max(np.abs(orc - hp)) / scale))
+        print(name, "oracle vs high precision: max rel err %.2e" % (np.max(np.abs(orc - hp)) / scale), flush=True)
         res[name] = hp
         res[name + "_oracle"] = orc
+    # full intensity: u(tau, phi) = sum_m u^m cos(m (phi0 - phi))
+    kw = intensity_case()
+    M = kw["NQuad"]
+    um = [solve_hp(kw, m) for m in range(M)]
+    u = sum(um[m][:, :, None] * np.cos(m * (kw["phi0"] - PHI))[None, None, :] for m in range(M))
+    mu_arr, fu, fd, u0, uf = O.pydisort(**kw)
+    tau = np.concatenate(([0.0], kw["tau_arr"]))
+    orc = uf(tau, PHI)
+    print("intensity oracle vs high precision: max rel err %.2e" % (np.max(np.abs(orc - u)) / np.max(np.abs(u))), flush=True)
+    res["intensity"] = u
+    res["intensity_oracle"] = orc
     np.savez(os.path.join(ROOT, "tests", "golden", "hp_truth_m0.npz"), **res)
