@@ -5,15 +5,16 @@
 //   D+/D-, alpha, beta (:123-135), eig((alpha-beta)(alpha+beta)) (:179-183), G blocks (:186-198),
 //   beam particular solution (:143-152, :209-231), G^-1 [1/mu;-1/mu] (:203-205 + _assemble.py:124)
 //   and the isotropic-source particular solution coefficients (subroutines.py:746-862)
-//   -> rtd_eig_kernel<NP>.
+//   -> rtd_eigen_kernel<NP> (one fused kernel; rtd_asm / rtd_jacobi / rtd_post_kernel are its earlier three-kernel form,
+//      kept for NQuad > 32 behind RTD_EIG32_SPLIT).
 //
 // Algorithm (own design, not the reference's LAPACK calls): with T = diag(sqrt(mu w)) the matrices
 // -(T(alpha+beta)T^-1) = Pm and -(T(alpha-beta)T^-1) = Qm are symmetric positive definite, so with
 // the Cholesky factor Pm = L L^T the non-symmetric problem (alpha-beta)(alpha+beta) v = k^2 v becomes
-// the symmetric H z = k^2 z, H = L^T Qm L, solved by a parallel-order (XOR round-robin) cyclic
-// Jacobi iteration.  One problem occupies NP lanes of a wavefront (64/NP problems per wave); lane j
-// owns column j of every matrix in registers; columns are exchanged with cross-lane swizzles,
-// rotation parameters and small vectors through LDS.
+// the symmetric H z = k^2 z, H = L^T Qm L = F F^T with F = L^T R (Qm = R R^T), solved by a one-sided (Hestenes)
+// parallel-order (XOR round-robin) cyclic Jacobi iteration on the columns of F.  One problem occupies NP lanes of a
+// wavefront (64/NP problems per wave); lane j owns column j of every matrix in registers; columns are exchanged with
+// DPP / ds_swizzle cross-lane moves, small vectors and the Cholesky factor go through LDS.
 #include <cstdlib>
 #include <type_traits>
 
