@@ -18,9 +18,11 @@
 //   banded matrix to <= 5e-13 on every golden case and on thick/thin/near-conservative stress cases
 //   (tools/proto_device_algo.py: check_structured).
 //
-// Two kernels: rtd_iface_kernel (all (column, mode, interface) in parallel: Wp, Wq, rho) and
-// rtd_sweep_kernel (per (column, mode): forward carry recursion, bottom boundary, backward sweep).
-// NP lanes per problem, 64/NP problems per wavefront; lane i owns row i of the carry system.
+// Two implementations.  16 < NQuad <= 32: rtd_bc_mfma_kernel, one wavefront per (column, mode), everything in the
+// matrix-core register layout (see its comment below).  Other stream counts (or RTD_BC_SPLIT=1): rtd_iface_kernel (all
+// (column, mode, interface) in parallel: Wp, Wq, rho through HBM) and rtd_sweep_kernel (per (column, mode): forward carry
+// recursion, bottom boundary, backward sweep); NP lanes per problem, 64/NP problems per wavefront, lane i owns row i
+// of the carry system.
 #include <cstdlib>
 #include <type_traits>
 
