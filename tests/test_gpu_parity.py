@@ -284,6 +284,24 @@ EDGE_CASES = {
     "only_flux": dict(tau_arr=np.array([1.0, 2.0, 3.5]), omega_arr=np.array([0.5, 0.9, 0.7]), NQuad=16,
                       Leg_coeffs_all=np.tile(0.7 ** np.arange(17), (3, 1)), mu0=0.6, I0=1.5, phi0=0.3, only_flux=True,
                       BDRF_Fourier_modes=[0.3]),
+    # a deep chain for the fused boundary-condition kernel: 150 layers, 32 streams, alternating thick / thin layers,
+    # thermal + beam + Lambertian surface (the layer-sorted eigen stage sees 150 / 4 = 38 wavefronts per mode)
+    "deep_chain_32": dict(tau_arr=np.cumsum(np.where(np.arange(150) % 3 == 0, 2.0, 0.02)),
+                          omega_arr=0.3 + 0.65 * (np.arange(150) % 7) / 6.0, NQuad=32,
+                          Leg_coeffs_all=(0.2 + 0.6 * (np.arange(150) % 5) / 4.0)[:, None] ** np.arange(33)[None, :],
+                          mu0=0.35, I0=1.0, phi0=0.5, NFourier=6, b_neg=0.1,
+                          s_poly_coeffs=np.tile(np.array([[0.5, 0.01]]), (150, 1)), BDRF_Fourier_modes=[0.4]),
+    # 30 streams (N = 15 padded to 16 lanes in the MFMA layout), delta-M, two BDRF modes
+    "padded_30": dict(tau_arr=np.array([0.1, 1.1, 1.15, 6.0]), omega_arr=np.array([0.99, 0.3, 0.0, 0.9]), NQuad=30,
+                      Leg_coeffs_all=np.array([0.85, 0.5, 0.2, 0.7])[:, None] ** np.arange(34)[None, :], mu0=0.8, I0=2.0,
+                      phi0=0.0, f_arr=np.array([0.85, 0.5, 0.2, 0.7]) ** 30,
+                      BDRF_Fourier_modes=[lambda mu, nmup: 0.3 * (1 + 0.4 * np.outer(mu, nmup)),
+                                          lambda mu, nmup: 0.1 * np.outer(np.sqrt(1 - mu**2), np.sqrt(1 - np.asarray(nmup) ** 2))]),
+    # 64 streams (the largest accepted size): fused eigen kernel at 32 lanes per problem, row-per-lane BC kernels
+    "max_streams_64": dict(tau_arr=np.array([0.5, 2.5, 3.0]), omega_arr=np.array([0.9, 0.6, 0.95]), NQuad=64,
+                           Leg_coeffs_all=np.array([0.9, 0.4, 0.8])[:, None] ** np.arange(66)[None, :], mu0=0.45, I0=1.0,
+                           phi0=1.0, f_arr=np.array([0.9, 0.4, 0.8]) ** 64, NFourier=5, b_pos=0.3,
+                           s_poly_coeffs=np.array([[0.2, 0.1], [0.4, 0.0], [0.1, 0.05]])),
 }
 
 
