@@ -3,17 +3,29 @@
 (BASELINE.json configs[3], "cfg4" of SURVEY section 8(d)) on N GPUs of one node.
 
 A step = one pass of the whole hot path (Legendre tables, eigen stage, boundary-condition solve,
-evaluation of u at the 21 layer interfaces x 3 azimuths plus fluxes) over one batch of
-`--columns` synthetic columns per GPU, inputs already resident in HBM.  Columns are independent, so
-ranks shard them with no data-path exchange during the solve (weak scaling: per-GPU work fixed); one
-RCCL all-gather of the flux results per step stitches the outputs.
+evaluation of u at the 21 layer interfaces x 3 azimuths plus fluxes) over one batch of synthetic
+columns per GPU, inputs already resident in HBM.  Columns are independent (the reference's loops
+_solve_for_gen_and_part_sols.py:88-91 and _solve_for_coeffs.py:110-111 carry no state), so ranks shard
+them with no exchange during the solve; one RCCL all-gather of u and the fluxes per step stitches the
+outputs of all ranks, on its own stream so that it overlaps the next step.
+
+  weak scaling (default)  : every GPU solves --columns columns per step
+  strong scaling          : --total-columns T splits T columns over the GPUs (BASELINE's literal 10^5)
+
+Launch: `python bench.py --gpus N ...` starts N fresh rank processes itself (one per GPU, before anything in
+this process has touched a GPU) unless it already runs under torch.distributed.run (RANK / WORLD_SIZE set),
+in which case WORLD_SIZE must equal --gpus.  A rank that cannot join, or an RCCL failure, makes the whole
+run exit non-zero.
 
 Prints ONE JSON line on rank 0 (contract in the build prompt) with `roofline` and `cpu_baseline`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -23,6 +35,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "pythonic-disort_amd")]
 
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector = matrix peak (vendor figure)
 L, NQUAD, NTAU, NPHI = 20, 32, 21, 3
+EXIT_RANKS, EXIT_RCCL, EXIT_TIMEOUT = 2, 3, 124
 
 
 def algorithmic_flops():
@@ -38,19 +51,103 @@ def algorithmic_flops():
 
 
 def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json;
-    FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as read), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json, else
+    the round-1 file; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as read), or None."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (NumPy/SciPy restatement of the reference, same LAPACK calls) on the host cores
+# ---------------------------------------------------------------------------------------------------------
+def physical_cores():
+    """One logical CPU per physical core among the CPUs this process may run on (SMT siblings dropped)."""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, picked = set(), []
+    for cpu in allowed:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list") as f:
+                sib = f.read().strip()
+        except OSError:
+            sib = str(cpu)
+        if sib not in seen:
+            seen.add(sib)
+            picked.append(cpu)
+    return picked
+
+
+def _cpu_worker(args):
+    cpu, first, seconds, min_cols = args
     try:
-        with open(path) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+        os.sched_setaffinity(0, {cpu})
+    except OSError:
+        pass
+    from threadpoolctl import threadpool_limits
+    from oracle import disort_oracle as O
+    from pydisort_amd import synthetic
+    phi = np.array([0.0, np.pi / 2, np.pi])
+    keep = None
+    n = 0
+    with threadpool_limits(1):
+        t0 = time.perf_counter()
+        while n < min_cols or time.perf_counter() - t0 < seconds:
+            cfg = synthetic.cfg4_columns(1, first=first + n)
+            res = O.pydisort(**synthetic.column_kwargs(cfg, 0))
+            tau = np.concatenate(([0.0], cfg["tau_arr"][0]))
+            u = res[4](tau, phi)
+            res[1](tau), res[2](tau)
+            if n == 0:
+                keep = u
+            n += 1
+        dt = time.perf_counter() - t0
+    return n, dt, first, keep
+
+
+_ORACLE_SAMPLES = []
+
+
+def cpu_baseline(seconds=20.0, min_cols=16):
+    """Oracle on every physical host core: one process pinned to each, 1 BLAS thread, same synthetic inputs as the GPU
+    leg, every worker solving columns for `seconds` (at least `min_cols`).  value = sum of the workers' own rates.
+    Runs BEFORE the GPU is initialised (fork)."""
+    import multiprocessing as mp
+    cpus = physical_cores()
+    ctx = mp.get_context("fork")
+    with ctx.Pool(len(cpus)) as pool:
+        pool.map(_cpu_worker, [(c, 0, 0.0, 1) for c in cpus])  # warm imports
+        t0 = time.perf_counter()
+        results = pool.map(_cpu_worker, [(c, 10_000 + 1000 * k, seconds, min_cols) for k, c in enumerate(cpus)], chunksize=1)
+        wall = time.perf_counter() - t0
+    rates = [n / dt for n, dt, _, _ in results]
+    done = sum(r[0] for r in results)
+    global _ORACLE_SAMPLES  # (global column index, oracle u[Q, 21, 3]) of a few columns, for the parity field
+    _ORACLE_SAMPLES = [(r[2], r[3]) for r in results[:8]]
+    out = dict(value=float(sum(rates)), unit="column-solves/sec", cores=len(cpus), kind="port",
+               per_process=dict(mean=float(np.mean(rates)), min=float(min(rates)), max=float(max(rates))),
+               logical_cpus=os.cpu_count(),
+               sample=f"{done} cfg4 columns (L=20, NQuad=32, 32 Fourier modes, u at 21 tau x 3 phi + fluxes), "
+                      f"{len(cpus)} processes pinned one per physical core x 1 BLAS thread, {wall:.1f} s")
+    try:  # ratio oracle / reference on identical hardware and inputs, measured in the build container
+        with open(os.path.join(ROOT, "profiles", "r02_cpu_calibration.json")) as f:
+            cal = json.load(f)
+        out["calibration"] = dict(r=cal["r"], meaning="oracle rate / reference (PythonicDISORT) rate, same inputs, same core",
+                                  source="profiles/r02_cpu_calibration.json (tools/calibrate_cpu_baseline.py)")
     except Exception:
-        return None
+        pass
+    return out
 
 
+# ---------------------------------------------------------------------------------------------------------
+# secondary measurements on rank 0 at N = 1
+# ---------------------------------------------------------------------------------------------------------
 def extra_measurements(device):
-    """Secondary numbers of SURVEY section 8(d) on rank 0: max |dI| of the HIP path against the oracle on the sample
-    columns of the cpu_baseline leg, and the only_flux (one Fourier mode) throughput."""
+    """max |dI| of the HIP path against the oracle on the sample columns of the cpu_baseline leg, the only_flux
+    throughput, and the host-to-host rate on 10^5 columns."""
     import pydisort_amd
     from pydisort_amd import synthetic
     out = {}
@@ -84,11 +181,38 @@ def extra_measurements(device):
     out["only_flux"] = {"value": 5 * C / (time.perf_counter() - t0), "unit": "column-solves/sec",
                         "workload": "cfg4 with only_flux=True (one Fourier mode), 16384 columns per pass"}
     plan.close()
+    out["e2e"] = end_to_end(device)
     return out
 
 
-def shard_columns(rank, world, columns_per_gpu):
-    """Weak-scaling column shard of a rank: global column indices [first, first + count)."""
+def end_to_end(device, columns=100_000):
+    """Host arrays in -> host arrays out for BASELINE's literal cfg4 batch: preparation of the prepared arguments,
+    upload, windowed solve, evaluation, and the device-to-host copies overlapped with the next window's kernels."""
+    import pydisort_amd
+    from pydisort_amd import synthetic
+    cfg = synthetic.cfg4_columns_block(columns, first=200_000)
+    tau = np.concatenate((np.zeros((columns, 1)), cfg["tau_arr"]), axis=1)
+    phi = np.array([0.0, np.pi / 2, np.pi])
+    pydisort_amd.solve_columns_streamed({k: (v[:4096] if isinstance(v, np.ndarray) else v) for k, v in cfg.items()},
+                                        tau[:4096], phi, chunk_columns=2048, device=device)  # warm-up
+    t0 = time.perf_counter()
+    res = pydisort_amd.solve_columns_streamed(cfg, tau, phi, chunk_columns=2048, device=device)
+    dt = time.perf_counter() - t0
+    assert np.all(np.isfinite(res["flux_up"]))
+    return {"value": columns / dt, "unit": "column-solves/sec", "columns": columns, "seconds": dt,
+            "what": "host NumPy inputs -> host NumPy u [C,32,21,3], u0, fluxes: host preparation, H2D, windowed "
+                    "solve + evaluation (2048 columns per window), D2H overlapped with the next window; plan creation included"}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# rank layout
+# ---------------------------------------------------------------------------------------------------------
+def shard_columns(rank, world, columns_per_gpu, total_columns=0):
+    """Column shard of a rank: global column indices [first, first + count).  Weak scaling: every rank gets
+    columns_per_gpu; strong scaling (total_columns > 0): total_columns // world each (equal counts for the all-gather)."""
+    if total_columns > 0:
+        per = total_columns // world
+        return rank * per, per
     return rank * columns_per_gpu, columns_per_gpu
 
 
@@ -100,46 +224,260 @@ def reduce_max_seconds(dist, seconds):
     return float(t[0])
 
 
-def _cpu_worker(args):
-    first, n = args
-    from threadpoolctl import threadpool_limits
-    from oracle import disort_oracle as O
-    from pydisort_amd import synthetic
-    with threadpool_limits(1):
-        cfg = synthetic.cfg4_columns(n, first=first)
-        phi = np.array([0.0, np.pi / 2, np.pi])
-        keep = None
-        for i in range(n):
-            res = O.pydisort(**synthetic.column_kwargs(cfg, i))
-            tau = np.concatenate(([0.0], cfg["tau_arr"][i]))
-            u = res[4](tau, phi)
-            res[1](tau), res[2](tau)
-            if i == 0:
-                keep = u
-    return n, first, keep
+def all_ranks_ok(dist, ok):
+    """True iff every rank reports ok (MIN over the gloo control plane)."""
+    import torch
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t[0]) == 1
 
 
-_ORACLE_SAMPLES = []
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
-def cpu_baseline(cols_per_core=6):
-    """Oracle (NumPy/SciPy port of the reference, same LAPACK calls) on every host core, 1 BLAS thread
-    per process, same synthetic inputs; bounded sample.  Runs BEFORE the GPU is initialised (fork)."""
-    import multiprocessing as mp
-    cores = os.cpu_count() or 1
-    ctx = mp.get_context("fork")
-    jobs = [(10_000 + k * cols_per_core, cols_per_core) for k in range(cores)]
-    with ctx.Pool(cores) as pool:
-        pool.map(_cpu_worker, [(0, 1)] * cores)  # warm imports
-        t0 = time.perf_counter()
-        results = pool.map(_cpu_worker, jobs)
-        dt = time.perf_counter() - t0
-    done = sum(r[0] for r in results)
-    global _ORACLE_SAMPLES  # (global column index, oracle u[Q, 21, 3]) of a few columns, for the parity field
-    _ORACLE_SAMPLES = [(r[1], r[2]) for r in results[:8]]
-    return dict(value=done / dt, unit="column-solves/sec", cores=cores, kind="port",
-                sample=f"{done} cfg4 columns (L=20, NQuad=32, 32 Fourier modes, u at 21 tau x 3 phi + fluxes), "
-                       f"{cores} processes x 1 BLAS thread, {dt:.1f} s")
+def spawn_ranks(n, argv, timeout=None):
+    """Start n fresh rank processes of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, one GPU each), wait for
+    all of them, relay rank 0's JSON line.  Any rank failing (or the timeout) ends the others and the run with a
+    non-zero exit code.  The parent never touches a GPU."""
+    timeout = float(os.environ.get("RTD_BENCH_TIMEOUT", "3000")) if timeout is None else timeout
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    t0 = time.time()
+    code = 0
+    while True:
+        states = [p.poll() for p in procs]
+        bad = [s for s in states if s not in (None, 0)]
+        if bad:
+            code = bad[0] if bad[0] > 0 else 1
+            print(f"[bench] a rank exited with status {bad[0]}: stopping the run", file=sys.stderr)
+            break
+        if all(s == 0 for s in states):
+            break
+        if time.time() - t0 > timeout:
+            code = EXIT_TIMEOUT
+            print(f"[bench] ranks still running after {timeout:.0f} s: stopping the run", file=sys.stderr)
+            break
+        time.sleep(0.1)
+    for p in procs:  # exact PIDs only
+        if p.poll() is None:
+            p.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    reader.join(timeout=5)
+    if code:
+        return code
+    text = (out0[0] if out0 else b"").decode()
+    line = next((ln for ln in reversed(text.splitlines()) if ln.startswith("{")), None)
+    if line is None:
+        print("[bench] rank 0 printed no result line", file=sys.stderr)
+        return 1
+    res = json.loads(line)
+    if res.get("n_gpus") != n:
+        print(f"[bench] result line reports n_gpus = {res.get('n_gpus')}, expected {n}", file=sys.stderr)
+        return EXIT_RANKS
+    print(line)
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------
+def run_rank(a, rank, world, local):
+    stub = os.environ.get("RTD_BENCH_STUB") == "1"  # CPU test of the launch / control plane: no GPU, no librtd
+    if stub and os.environ.get("RTD_BENCH_STUB_FAIL_RANK") == str(rank):
+        sys.exit(7)  # test hook: a rank that dies before it joins
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not stub:
+        cpu = cpu_baseline()
+
+    first, C = shard_columns(rank, world, a.columns, a.total_columns)
+    strong = a.total_columns > 0
+    multi = world > 1 or a.force_dist
+    plan = None
+    if not stub:
+        from pydisort_amd import synthetic
+        from pydisort_amd._engine import Plan
+        from pydisort_amd._prepare import prepare_columns
+        cfg = synthetic.cfg4_columns_block(C, first=first) if strong else synthetic.cfg4_columns(C, first=first)
+        N = NQUAD // 2
+        prep = prepare_columns(cfg["tau_arr"], cfg["omega_arr"], NQUAD, cfg["Leg_coeffs_all"], cfg["mu0"], cfg["I0"],
+                               cfg["phi0"], NQUAD, NQUAD, np.zeros((C, N, NQUAD)), np.zeros((C, N, NQUAD)),
+                               cfg["f_arr"], np.zeros((C, L, 0)), np.zeros((C, 0, N, N)), np.zeros((C, 0, N)))
+        if multi:
+            Plan.comm_preload()  # bind RCCL to librtd's HIP runtime before torch (gloo control plane) is imported
+        plan = Plan(prep, device=local, work_columns=a.columns)  # uploads: inputs now resident in HBM
+        tau = np.concatenate((np.zeros((C, 1)), cfg["tau_arr"]), axis=1)
+        plan.set_eval_points(tau, np.array([0.0, np.pi / 2, np.pi]))
+
+    dist = None
+    gather = None
+    collective = "none (single rank)"
+    watchdog = None
+    if multi:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")  # control plane: barriers, status and the max-over-ranks of the time
+        if dist.get_world_size() != world:
+            print(f"[bench] rank {rank}: process group has {dist.get_world_size()} ranks, expected {world}", file=sys.stderr)
+            os._exit(EXIT_RANKS)
+        if not stub:
+            # data plane: RCCL all-gather of u + fluxes inside librtd.  A rank that cannot bootstrap or hangs ends the
+            # whole run: the plan is never touched again after a failure, and a watchdog ends a rank stuck in RCCL.
+            limit = float(os.environ.get("RTD_RCCL_TIMEOUT", "300"))
+
+            def expired():
+                print(f"[bench] rank {rank}: RCCL bootstrap / first gather still pending after {limit:.0f} s", file=sys.stderr)
+                sys.stderr.flush()
+                os._exit(EXIT_RCCL)
+
+            watchdog = threading.Timer(limit, expired)
+            watchdog.daemon = True
+            watchdog.start()
+            uid, err = [None], None
+            if rank == 0:
+                try:
+                    uid = [Plan.comm_unique_id()]
+                except Exception as e:
+                    err = e
+            dist.broadcast_object_list(uid, src=0)
+            ok = uid[0] is not None
+            if ok:
+                try:
+                    plan.comm_init(uid[0], rank, world)
+                    plan.run()
+                    plan.allgather_results()
+                    plan.synchronize()
+                except Exception as e:
+                    ok, err = False, e
+            if not ok:
+                print(f"[bench] rank {rank}: RCCL data plane failed: {err!r}", file=sys.stderr)
+            everyone = all_ranks_ok(dist, ok)
+            watchdog.cancel()
+            if not everyone:
+                sys.stderr.flush()
+                os._exit(EXIT_RCCL)  # no clean-up through a communicator that may be half-built
+            gather = plan.allgather_results
+            collective = f"rccl ncclAllGather of u + fluxes per step, nranks = {world}, on its own stream (overlaps the next step)"
+
+    def barrier():
+        if plan is not None:
+            plan.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def step():
+        if plan is not None:
+            plan.run()
+            if gather:
+                gather()
+        else:
+            time.sleep(0.001)
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    if plan is not None:
+        plan.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    joined = world
+    if dist is not None:
+        elapsed = reduce_max_seconds(dist, elapsed)
+        import torch
+        cnt = torch.tensor([C], dtype=torch.int64)
+        dist.all_reduce(cnt)
+        total_cols = int(cnt[0])
+        one = torch.tensor([1], dtype=torch.int64)
+        dist.all_reduce(one)
+        joined = int(one[0])
+    else:
+        total_cols = C
+    if joined != world:
+        print(f"[bench] only {joined} of {world} ranks took part", file=sys.stderr)
+        os._exit(EXIT_RANKS)
+
+    # per-kernel HIP-event times from a separate short pass (events + a stream sync per window would otherwise sit
+    # inside the timed region; the timed region above is the free-running pipeline)
+    stage, sweeps = None, None
+    if plan is not None and rank == 0:
+        plan.enable_timing(True)
+        plan.timing(reset=True)
+        for _ in range(max(2, min(a.steps, 5))):
+            plan.run()
+        stage = plan.timing(reset=True)
+        plan.enable_timing(False)
+        sweeps = plan.max_sweeps()
+
+    extras = {}
+    if rank == 0 and world == 1 and not a.no_extras and not stub:
+        extras = extra_measurements(local)
+    if rank == 0:
+        value = total_cols * a.steps / elapsed
+        out = {
+            "metric": "column-solves/sec (32 streams, 20 layers)", "value": value, "unit": "column-solves/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "cfg4: synthetic Henyey-Greenstein, 20 layers, 32 streams, 32 Fourier modes, "
+                                   "delta-M on, beam source, u at 21 interfaces x 3 azimuths + fluxes",
+                       "columns_per_gpu_per_step": C, "global_columns_per_step": total_cols,
+                       "columns_per_window": a.columns, "ranks_joined": joined,
+                       "parallelism": f"column-sharded x{world}", "collective": collective,
+                       "max_jacobi_sweeps": sweeps},
+        }
+        if stage is not None:
+            fl = algorithmic_flops()
+            nwin = max(1, -(-C // a.columns))
+            ms = {k: (v[0] / max(v[1], 1)) for k, v in stage.items()}  # per launch = per window of a.columns columns
+            ms["bc"] = ms["iface"] + ms["sweep"]
+            ms["eigen"] = ms["asm"] + ms["jacobi"] + ms["post"]  # one fused kernel at NQuad = 32 (timed in the jacobi slot)
+            dom = max(("eigen", "iface", "sweep"), key=lambda k: ms[k])
+            dom_flops = fl["bc"] if dom in ("iface", "sweep") else fl["asm"] + fl["jacobi"] + fl["post"]
+            dom_ms = ms["bc"] if dom in ("iface", "sweep") else ms["eigen"]
+            fused_bc = ms["iface"] < 0.05 * ms["sweep"]  # NQuad = 32: one fused kernel, timed in the sweep slot
+            kname = ("rtd_eigen_kernel<16>" if dom == "eigen" else
+                     "rtd_bc_mfma_kernel" if fused_bc else "rtd_iface_mfma_kernel+rtd_sweep_kernel<16>")
+            cols_per_launch = min(C, a.columns)
+            achieved = dom_flops * cols_per_launch / (dom_ms * 1e-3) / 1e12
+            traffic = measured_traffic(kname.split("+")[-1].split("<")[0]) if cols_per_launch == 2048 else None
+            out["roofline"] = {
+                "bound": "fp64-valu", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "kernel": kname,
+                "note": "FP64 path (SURVEY 8(d): compute-bound, not HBM-bound); the dominant kernel issues FP64 vector "
+                        "instructions (the matrix pipe has the same FP64 peak): peak = MI355X FP64 vector = matrix peak; "
+                        "achieved = algorithmic FLOPs of the kernel x columns per launch / its HIP-event duration (separate "
+                        "timing pass after the timed region); traffic = measured HBM bytes per launch of that kernel (profiles/)",
+                "kernel_ms_per_launch": ms, "columns_per_launch": cols_per_launch, "launches_per_step": nwin,
+                "whole_path_tflops": fl["total"] * value / world / 1e12,
+                "whole_path_frac": fl["total"] * value / world / 1e12 / FP64_PEAK_TFLOPS}
+        out["cpu_baseline"] = cpu
+        out.update(extras)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if plan is not None:
+        plan.close()
 
 
 def main():
@@ -147,153 +485,32 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--columns", type=int, default=2048, help="columns per GPU per step")
+    ap.add_argument("--columns", type=int, default=2048,
+                    help="columns per GPU per step (weak scaling); with --total-columns: columns per window")
+    ap.add_argument("--total-columns", type=int, default=0,
+                    help="strong scaling: this many columns in total, split over the GPUs (BASELINE: 100000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the parity and only_flux legs (profiling runs: every kernel launch is then the workload)")
+                    help="skip the parity, only_flux and end-to-end legs (profiling runs: every kernel launch is then the workload)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the multi-rank code path even with one rank")
     a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ:
+        if a.gpus > 1:
+            sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))
+        if a.force_dist:  # one rank, but through the same rendezvous as N ranks
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline()
-
-    from pydisort_amd import synthetic
-    from pydisort_amd._engine import Plan
-    from pydisort_amd._prepare import prepare_columns
-
-    first, C = shard_columns(rank, world, a.columns)
-    cfg = synthetic.cfg4_columns(C, first=first)
-    N = NQUAD // 2
-    prep = prepare_columns(cfg["tau_arr"], cfg["omega_arr"], NQUAD, cfg["Leg_coeffs_all"], cfg["mu0"], cfg["I0"],
-                           cfg["phi0"], NQUAD, NQUAD, np.zeros((C, N, NQUAD)), np.zeros((C, N, NQUAD)),
-                           cfg["f_arr"], np.zeros((C, L, 0)), np.zeros((C, 0, N, N)), np.zeros((C, 0, N)))
-    if world > 1 or a.force_dist:
-        Plan.comm_preload()  # bind RCCL to librtd's HIP runtime before torch (gloo control plane) is imported
-    plan = Plan(prep, device=local)  # uploads: inputs now resident in HBM
-    tau = np.concatenate((np.zeros((C, 1)), cfg["tau_arr"]), axis=1)
-    plan.set_eval_points(tau, np.array([0.0, np.pi / 2, np.pi]))
-
-    dist = None
-    gather = None
-    comm_thread = None
-    collective = "none (single rank)"
-    if world > 1 or a.force_dist:
-        import torch.distributed as dist
-        dist.init_process_group("gloo")  # control plane: barriers and the max-over-ranks of the time
-        collective = "none (nccl unavailable)"
-        # data plane: one RCCL all-gather of the flux results per step (ncclAllGather inside librtd)
-        uid = [None]
-        if rank == 0:
-            try:
-                uid = [Plan.comm_unique_id()]
-            except Exception as e:
-                print(f"[bench] RCCL unavailable: {e!r}", file=sys.stderr)
-        dist.broadcast_object_list(uid, src=0)
-        ok = 0
-        comm_thread = None
-        if uid[0] is not None:
-            # RCCL bootstrap in a watchdog thread: a rank that cannot reach its peers must not hang the benchmark
-            import threading
-            state = {}
-
-            def bootstrap():
-                try:
-                    plan.comm_init(uid[0], rank, world)
-                    plan.run()
-                    plan.allgather_fluxes()
-                    plan.synchronize()
-                    state["ok"] = True
-                except Exception as e:  # keep the benchmark alive on a misconfigured node
-                    state["err"] = e
-
-            comm_thread = threading.Thread(target=bootstrap, daemon=True)
-            comm_thread.start()
-            comm_thread.join(timeout=float(os.environ.get("RTD_RCCL_TIMEOUT", "120")))
-            if state.get("ok"):
-                ok = 1
-            else:
-                print(f"[bench] rank {rank}: RCCL data plane unavailable: {state.get('err', 'bootstrap timed out')!r}",
-                      file=sys.stderr)
-        import torch
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 1:
-            gather = plan.allgather_fluxes
-            collective = "rccl all_gather (fluxes)"
-
-    def barrier():
-        plan.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(a.warmup):
-        plan.run()
-        if gather:
-            gather()
-    plan.enable_timing(True)
-    plan.timing(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        plan.run()
-        if gather:
-            gather()
-    plan.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    if dist is not None:
-        elapsed = reduce_max_seconds(dist, elapsed)
-    stage = plan.timing(reset=True)
-    sweeps = plan.max_sweeps()
-
-    extras = {}
-    if rank == 0 and world == 1 and not a.no_extras:
-        extras = extra_measurements(local)
-    if rank == 0:
-        fl = algorithmic_flops()
-        ms = {k: (v[0] / max(v[1], 1)) for k, v in stage.items()}
-        ms["bc"] = ms["iface"] + ms["sweep"]
-        ms["eigen"] = ms["asm"] + ms["jacobi"] + ms["post"]  # one fused kernel at NQuad = 32 (timed in the jacobi slot)
-        dom = max(("eigen", "iface", "sweep"), key=lambda k: ms[k])
-        dom_flops = fl["bc"] if dom in ("iface", "sweep") else fl["asm"] + fl["jacobi"] + fl["post"]
-        dom_ms = ms["bc"] if dom in ("iface", "sweep") else ms["eigen"]
-        fused_bc = ms["iface"] < 0.05 * ms["sweep"]  # NQuad = 32: one fused kernel, timed in the sweep slot
-        kname = ("rtd_eigen_kernel<16>" if dom == "eigen" else
-                 "rtd_bc_mfma_kernel" if fused_bc else "rtd_iface_mfma_kernel+rtd_sweep_kernel<16>")
-        achieved = dom_flops * C / (dom_ms * 1e-3) / 1e12
-        value = world * C * a.steps / elapsed
-        traffic = measured_traffic(kname.split("+")[-1].split("<")[0]) if C == 2048 else None
-        out = {
-            "metric": "column-solves/sec (32 streams, 20 layers)", "value": value, "unit": "column-solves/sec",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "cfg4: synthetic Henyey-Greenstein, 20 layers, 32 streams, 32 Fourier modes, "
-                                   "delta-M on, beam source, u at 21 interfaces x 3 azimuths + fluxes",
-                       "columns_per_gpu_per_step": C, "global_columns_per_step": world * C,
-                       "parallelism": f"column-sharded x{world}", "collective": collective,
-                       "max_jacobi_sweeps": sweeps},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "kernel": kname,
-                         "note": "FP64 path (SURVEY 8(d): compute-bound, not HBM-bound): peak = MI355X FP64 vector = matrix "
-                                 "peak; achieved = algorithmic FLOPs of the kernel x columns / its HIP-event duration; "
-                                 "traffic = measured HBM bytes per launch of that kernel (profiles/r01_pmc_traffic.json)",
-                         "kernel_ms_per_step": ms,
-                         "whole_path_tflops": fl["total"] * C * a.steps / elapsed / 1e12,
-                         "whole_path_frac": fl["total"] * C * a.steps / elapsed / 1e12 / FP64_PEAK_TFLOPS},
-            "cpu_baseline": cpu,
-        }
-        out.update(extras)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
-        if comm_thread is not None and comm_thread.is_alive():
-            sys.stdout.flush()
-            os._exit(0)  # a rank stuck inside the RCCL bootstrap cannot be joined
+    if world != a.gpus:
+        print(f"[bench] --gpus {a.gpus} but WORLD_SIZE = {world}: launch one rank per GPU "
+              f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...) or let bench.py "
+              "start the ranks itself by running it without RANK/WORLD_SIZE in the environment", file=sys.stderr)
+        sys.exit(EXIT_RANKS)
+    run_rank(a, rank, world, local)
 
 
 if __name__ == "__main__":

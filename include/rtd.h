@@ -48,8 +48,16 @@ const char* rtd_last_error(void);
 int rtd_device_count(int32_t* count);
 
 /* --- plan life cycle ---------------------------------------------------------------------- */
-/* Allocates every device buffer the path needs for `dims` on HIP device `device`. */
+/* Allocates every device buffer the path needs for `dims` on HIP device `device`.
+ * Inputs and results are held for all `ncols` columns; the intermediates of the solve (eigenvector blocks, BC workspace:
+ * ~8 MB per 20-layer 32-stream column) are held for one *window* of columns at a time and the kernels run window after
+ * window on the plan's stream, so ncols is bounded by the inputs and results only (10^5 columns of BASELINE.json's
+ * configs[3] need 2.3 GB).  rtd_plan_create sizes the window itself (environment RTD_WORK_BYTES, default 24 GiB of
+ * intermediates); rtd_plan_create_windowed takes it from the caller (work_columns <= 0: automatic). */
 int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** plan);
+int rtd_plan_create_windowed(const rtd_dims* dims, int32_t device, int32_t work_columns, rtd_plan** plan);
+/* columns per window and number of windows of a plan */
+int rtd_plan_windows(rtd_plan* plan, int32_t* work_columns, int32_t* nwindows);
 int rtd_plan_destroy(rtd_plan* plan);
 int rtd_plan_synchronize(rtd_plan* plan);
 /* bytes of device memory held by the plan */
@@ -130,6 +138,10 @@ int rtd_plan_run(rtd_plan* plan);
 /* copy the results of the last rtd_plan_run to the host (any pointer may be NULL) */
 int rtd_plan_fetch(rtd_plan* plan, double* u, double* u0, double* flux_up, double* flux_down_diffuse,
                    double* flux_down_direct);
+/* rtd_plan_run + rtd_plan_fetch as one host-to-host pipeline: window w's results travel to the host (device -> pinned
+ * staging on a copy stream -> the caller's arrays) while window w+1 is being solved.  Synchronous; any pointer may be NULL. */
+int rtd_plan_run_fetch(rtd_plan* plan, double* u, double* u0, double* flux_up, double* flux_down_diffuse,
+                       double* flux_down_direct);
 /* device pointers of the result buffers of rtd_plan_run (for a device-side collective) */
 int rtd_plan_result_dev_ptrs(rtd_plan* plan, void** u_dev, int64_t* u_bytes, void** flux_dev, int64_t* flux_bytes);
 
@@ -172,16 +184,24 @@ int rtd_plan_get_timing(rtd_plan* plan, double ms[7], int64_t nlaunch[7], int32_
 int rtd_plan_max_sweeps(rtd_plan* plan, int32_t* sweeps);
 
 /* --- multi-GPU: RCCL over xGMI, one communicator rank per plan (one process per GPU) -------- */
-/* The path shards by atmospheric column with no exchange during the solve; the one
- * collective stitches the evaluated flux results [3][C][ntau] of every rank: ncclAllGather on the plan's
- * stream.  rank 0 creates the id (ncclGetUniqueId) and hands the 128 bytes to the other ranks by any
- * host channel. */
+/* The path shards by atmospheric column with no exchange during the solve (the reference's
+ * independent loops are _solve_for_gen_and_part_sols.py:88-91 and _solve_for_coeffs.py:110-111, the meeting point is
+ * the Fourier sum _assemble_intensity_and_fluxes.py:256-260); the one collective stitches the evaluated results of
+ * every rank -- u [C][NQuad][ntau][nphi] and the fluxes [3][C][ntau] -- with ncclAllGather.  rank 0 creates the id
+ * (ncclGetUniqueId) and hands the 128 bytes to the other ranks by any host channel. */
 /* Load RCCL now (call before anything else in the process loads another RCCL/HIP runtime, e.g. PyTorch). */
 int rtd_comm_preload(void);
 int rtd_comm_unique_id(char id[128]);
 int rtd_comm_init(rtd_plan* plan, const char id[128], int32_t rank, int32_t nranks);
 int rtd_comm_allgather_fluxes(rtd_plan* plan);               /* asynchronous on the plan's stream */
 int rtd_comm_fetch_gathered(rtd_plan* plan, double* out);    /* host [nranks][3][C][ntau] */
+/* u AND fluxes of the last rtd_plan_run: two ncclAllGather on the plan's communication stream, ordered after the run by
+ * an event, so that the next rtd_plan_run overlaps them (its evaluation kernel, which overwrites the results, waits for
+ * the gather).  rtd_plan_synchronize waits for both streams. */
+int rtd_comm_allgather_results(rtd_plan* plan);
+/* host copies of the gathered results: u [nranks][C][NQuad][ntau][nphi] (= all nranks * C columns in rank order),
+ * fluxes [nranks][3][C][ntau]; either may be NULL */
+int rtd_comm_fetch_gathered_results(rtd_plan* plan, double* u, double* fluxes);
 /* mode shards: ncclAllReduce(sum) of the u, u0 and flux results of rtd_plan_run over the ranks, in place, asynchronous
  * on the plan's stream (rtd_plan_fetch then returns the complete fields on every rank) */
 int rtd_comm_allreduce_results(rtd_plan* plan);
@@ -192,7 +212,11 @@ enum {
   RTD_ERR_ARG = 1,        /* bad argument / unsupported size */
   RTD_ERR_HIP = 2,        /* HIP runtime failure             */
   RTD_ERR_TAU_RANGE = 3,  /* tau outside [0, tau_arr[-1]]    */
-  RTD_ERR_STATE = 4       /* call order (e.g. evaluate before solve) */
+  RTD_ERR_STATE = 4,      /* call order (e.g. evaluate before solve) */
+  RTD_ERR_NUMERIC = 5     /* numerical failure on the device: non-positive Cholesky pivot (phase function not positive
+                             definite after delta-M scaling), Jacobi iteration not converged, singular boundary-condition
+                             system or 1/mu0 on an eigenvalue (non-finite result).  The reference raises LinAlgError from
+                             np.linalg.solve / returns NaN in these cases (_solve_for_gen_and_part_sols.py:186, :226-231) */
 };
 
 #ifdef __cplusplus

@@ -112,26 +112,42 @@ struct rtd_plan {
   int device = 0;
   int NP = 0;
   hipStream_t stream = nullptr;
+  // d.C = all columns.  The per-column INPUT pointers of d cover them all; the intermediates of the solve (Y0, att, Ym, Am,
+  // kk, Ek, Bv, dq, zneg, coef, Fws, Lw, Qw) cover one window of Cw columns: launch_windows runs window after window.
   RtdDev d{};
+  int Cw = 0, nwin = 1;
   std::vector<void*> allocs;
   std::vector<size_t> alloc_bytes;
   int64_t bytes = 0;
-  bool have_quad = false, have_cols = false, solved = false, tables_ready = false;
+  bool have_quad = false, have_cols = false, solved = false;
+  int numeric_status = 0;  // RTD_ST_* bits of the last solve other than the tau range: reported until the next solve
   // evaluation buffers (grown on demand)
   int ev_ntau = 0, ev_nphi = 0;
-  double *ev_tau = nullptr, *ev_phi = nullptr, *ev_u = nullptr, *ev_u0 = nullptr, *ev_fl = nullptr,
-         *ev_ulast = nullptr;
+  double *ev_tau = nullptr, *ev_phi = nullptr, *ev_u = nullptr, *ev_u0 = nullptr, *ev_fl = nullptr;
   int64_t cap_tau = 0, cap_phi = 0, cap_u = 0, cap_u0 = 0, cap_fl = 0;
   // export buffers
   double* ex_buf = nullptr;
   // Nakajima-Tanaka corrections (optional)
   RtdNt nt{};
+  double *nt_w = nullptr, *nt_f = nullptr, *nt_ic = nullptr, *nt_ip = nullptr, *nt_R = nullptr;
+  int64_t cap_nt_w = 0, cap_nt_f = 0, cap_nt_ic = 0, cap_nt_ip = 0, cap_nt_R = 0;
   bool have_nt = false, nt_tables_ready = false;
-  // RCCL communicator (one rank per GPU), gathered flux results [nranks][3][C][ntau]
+  // RCCL communicator (one rank per GPU)
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_size = 0;
-  double* gathered = nullptr;
+  double* gathered = nullptr;  // fluxes only [nranks][3][C][ntau] (rtd_comm_allgather_fluxes)
   int64_t cap_gathered = 0;
+  // gathered u [nranks][C][Q][ntau][nphi] and fluxes [nranks][3][C][ntau] (rtd_comm_allgather_results): the gather runs
+  // on comm_stream behind ev_results, and the next run's first evaluation kernel waits for ev_gathered
+  double *gathered_u = nullptr, *gathered_fl = nullptr;
+  int64_t cap_gathered_u = 0, cap_gathered_fl = 0;
+  hipStream_t comm_stream = nullptr, copy_stream = nullptr;
+  hipEvent_t ev_results = nullptr, ev_gathered = nullptr;
+  bool gather_inflight = false;
+  // host-to-host pipeline (rtd_plan_run_fetch): two pinned staging slabs, one per window in flight
+  char* stage[2] = {nullptr, nullptr};
+  size_t stage_bytes = 0;
+  hipEvent_t ev_win[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
   // timing
   bool timing = false;
   static constexpr int NT = 7;  // timed kernels: tables, asm, jacobi, post, iface, sweep, eval
@@ -146,7 +162,8 @@ struct rtd_plan {
     if (n <= 0) n = 1;
     size_t got = 0;
     hipError_t e = pooled_malloc(&q, (size_t)n * sizeof(T), device, &got);
-    if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (e != hipSuccess)
+      return fail(RTD_ERR_HIP, std::string("hipMalloc of ") + std::to_string((size_t)n * sizeof(T)) + " bytes: " + hipGetErrorString(e));
     allocs.push_back(q);
     alloc_bytes.push_back(got);
     bytes += (int64_t)got;
@@ -157,9 +174,14 @@ struct rtd_plan {
 
 namespace {
 
+// (Re)allocates *buf for `need` doubles.  The old block goes back to the process-wide pool, where another plan on
+// another stream may pick it up at once: this plan's streams are drained first (a plain hipFree would have
+// synchronised the device).
 int grow(rtd_plan* p, double** buf, int64_t* cap, int64_t need) {
   if (need <= *cap) return 0;
   if (*buf) {
+    (void)hipStreamSynchronize(p->stream);
+    if (p->comm_stream) (void)hipStreamSynchronize(p->comm_stream);
     for (size_t i = 0; i < p->allocs.size(); ++i)
       if (p->allocs[i] == *buf) {
         pooled_free(*buf, p->alloc_bytes[i], p->device);
@@ -188,42 +210,129 @@ void harvest(rtd_plan* p) {
   }
 }
 
-int launch_solve(rtd_plan* p, bool with_eval, const RtdEval* ev) {
+// the plan's device view restricted to the columns [c0, c0 + cnt): input pointers advanced, intermediates shared
+RtdDev window_dev(const rtd_plan* p, int64_t c0, int cnt) {
+  RtdDev w = p->d;
+  const int64_t L = w.L, M = w.M, P = w.P, NP = w.NP, Ns = w.Ns, NB = w.NBDRF;
+  w.C = cnt;
+  w.omega += c0 * L; w.tau += c0 * L; w.taus0 += c0 * (L + 1); w.scale += c0 * L; w.wleg += c0 * L * P;
+  w.mu0 += c0; w.I0 += c0; w.phi0 += c0; w.rescale += c0;
+  w.bpos += c0 * M * NP; w.bneg += c0 * M * NP; w.spoly += c0 * L * Ns;
+  w.bdrfq += c0 * NB * NP * NP; w.bdrfq0 += c0 * NB * NP; w.lperm += c0 * L;
+  return w;
+}
+RtdEval window_eval(const rtd_plan* p, const RtdEval& e, int64_t c0) {
+  RtdEval w = e;
+  const int64_t Qr = 2 * p->d.N, nt = e.ntau, np = e.nphi;
+  w.tau += c0 * nt;
+  if (w.u) w.u += c0 * Qr * nt * np;
+  if (w.u0) w.u0 += c0 * Qr * nt;
+  if (w.ulast) w.ulast += c0 * Qr * nt;
+  if (w.fup) w.fup += c0 * nt;
+  if (w.fdn) w.fdn += c0 * nt;
+  if (w.fdir) w.fdir += c0 * nt;
+  return w;
+}
+RtdNt window_nt(const rtd_plan* p, int64_t c0) {
+  RtdNt w = p->nt;
+  const int64_t L = p->d.L;
+  w.wfull += c0 * L * w.nleg_all; w.f += c0 * L; w.ims_coef += c0 * w.nleg_all; w.ims_par += c0 * 2;
+  w.R += c0 * 4 * p->d.NP * L;
+  return w;
+}
+
+// Solve (and optionally evaluate) every window.  after_window(w, c0, cnt) is called once window w's kernels are
+// queued (rtd_plan_run_fetch hangs its device-to-host copies there).
+template <typename F>
+int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt, F&& after_window) {
   hipStream_t s = p->stream;
-  if (p->timing) {
-    (void)hipStreamSynchronize(s);
-    harvest(p);
-  }
   const bool tm = p->timing;
   auto mark = [&](int k) {
     if (tm) (void)hipEventRecord(p->evt[k], s);
   };
-  mark(0);
-  (void)hipMemsetAsync(p->d.sweeps, 0, sizeof(int), s);
-  rtd_launch_tables(p->d, s);
-  mark(1);
-  rtd_launch_eig(p->d, s, 0);
-  mark(2);
-  rtd_launch_eig(p->d, s, 1);
-  mark(3);
-  rtd_launch_eig(p->d, s, 2);
-  mark(4);
-  rtd_launch_bc(p->d, s, 0);
-  mark(5);
-  rtd_launch_bc(p->d, s, 1);
-  mark(6);
-  if (with_eval) {
-    rtd_launch_eval(p->d, *ev, s);
-    mark(7);
+  bool nt_tables_done = false;
+  if (with_solve) {
+    hipError_t e = hipMemsetAsync(p->d.sweeps, 0, sizeof(int), s);
+    if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+    p->numeric_status = 0;  // a new solve starts clean
   }
-  if (tm) {
-    for (int k = 0; k < 6; ++k) p->pending[k] = true;
-    p->pending[6] = with_eval;
+  for (int w = 0; w < p->nwin; ++w) {
+    const int64_t c0 = (int64_t)w * p->Cw;
+    const int cnt = (int)std::min<int64_t>(p->Cw, p->d.C - c0);
+    const RtdDev d = window_dev(p, c0, cnt);
+    if (tm) {
+      (void)hipStreamSynchronize(s);
+      harvest(p);
+    }
+    if (with_solve) {
+      mark(0);
+      rtd_launch_tables(d, s, w == 0);
+      mark(1);
+      rtd_launch_eig(d, s, 0);
+      mark(2);
+      rtd_launch_eig(d, s, 1);
+      mark(3);
+      rtd_launch_eig(d, s, 2);
+      mark(4);
+      rtd_launch_bc(d, s, 0);
+      mark(5);
+      rtd_launch_bc(d, s, 1);
+    }
+    mark(6);
+    if (ev) {
+      if (w == 0 && p->gather_inflight) {  // the previous run's results are still being gathered from these buffers
+        (void)hipStreamWaitEvent(s, p->ev_gathered, 0);
+        p->gather_inflight = false;
+      }
+      const RtdEval e = window_eval(p, *ev, c0);
+      rtd_launch_eval(d, e, s);
+      if (with_nt && e.u != nullptr) {
+        const RtdNt nt = window_nt(p, c0);
+        if (!p->nt_tables_ready) {
+          rtd_launch_nt_tables(d, nt, s);
+          nt_tables_done = true;
+        }
+        rtd_launch_nt_apply(d, nt, e, s);
+      }
+      mark(7);
+    }
+    if (tm) {
+      for (int k = 0; k < 6; ++k) p->pending[k] = with_solve;
+      p->pending[6] = ev != nullptr;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    int rc = after_window(w, c0, cnt);
+    if (rc) return rc;
   }
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-  p->solved = true;
+  if (nt_tables_done) p->nt_tables_ready = true;  // every window's tables were made in this pass
+  if (with_solve) p->solved = true;
   return 0;
+}
+
+int launch_solve(rtd_plan* p, bool with_eval, const RtdEval* ev, bool with_nt = false) {
+  return launch_windows(p, true, with_eval ? ev : nullptr, with_nt, [](int, int64_t, int) { return 0; });
+}
+
+// read and clear the device status word after the stream has drained; maps it to an error code
+int check_status(rtd_plan* p) {
+  int st = 0;
+  HIP_TRY(hipMemcpyAsync(&st, p->d.status, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  if (st != 0) {
+    HIP_TRY(hipMemsetAsync(p->d.status, 0, sizeof(int), p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+  }
+  p->numeric_status |= st & ~RTD_ST_TAU;  // a failed solve stays failed for every later evaluation of it
+  if (st & RTD_ST_TAU) return fail(RTD_ERR_TAU_RANGE, "tau input outside the tau range specified for the atmosphere");
+  st = p->numeric_status;
+  if (st == 0) return 0;
+  std::string what;
+  if (st & RTD_ST_CHOL) what += " non-positive Cholesky pivot or non-finite eigenvalue (phase function not positive definite?);";
+  if (st & RTD_ST_JACOBI) what += " Jacobi eigen-iteration did not converge;";
+  if (st & RTD_ST_BEAM) what += " non-finite beam particular solution (1/mu0 coincides with an eigenvalue?);";
+  if (st & RTD_ST_BC) what += " singular boundary-condition system (non-finite coefficients);";
+  return fail(RTD_ERR_NUMERIC, "numerical failure on the device:" + what);
 }
 
 }  // namespace
@@ -232,7 +341,7 @@ extern "C" {
 
 int rtd_comm_destroy(rtd_plan* p);
 
-int rtd_version(void) { return 100; }
+int rtd_version(void) { return 200; }
 
 const char* rtd_last_error(void) { return g_err.c_str(); }
 
@@ -247,15 +356,8 @@ int rtd_device_count(int32_t* count) {
   return 0;
 }
 
-int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** out) {
-  if (!dims || !out) return fail(RTD_ERR_ARG, "null argument");
+static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t work_columns) {
   const int N = dims->nquad / 2;
-  if (dims->ncols < 1 || dims->nlayers < 1 || dims->nquad < 2 || (dims->nquad & 1) || dims->nleg < 1 ||
-      dims->nfourier < 1 || dims->nfourier > dims->nleg || dims->nscoeffs < 0 || dims->nbdrf < 0)
-    return fail(RTD_ERR_ARG, "invalid dimensions");
-  if (N > 32) return fail(RTD_ERR_ARG, "NQuad > 64 is not supported by this build (N = NQuad/2 <= 32)");
-  HIP_TRY(hipSetDevice(device));
-  rtd_plan* p = new rtd_plan();
   p->dims = *dims;
   p->device = device;
   p->NP = pad_pow2(N);
@@ -271,7 +373,22 @@ int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** out) {
   const bool split32 = NP == 32 && getenv("RTD_EIG32_SPLIT") != nullptr;
   d.Lw = nullptr;
   d.Qw = nullptr;
-  int rc = 0;
+  // window of columns whose intermediates are resident: bytes of intermediates per column
+  const int64_t per_col = 8 * (M * P + (L + 1) + 2 * M * L * NP * NP + 2 * M * L * NP + 2 * M * L * Q2 + L * Ns * Q2 + L * NP +
+                               (split32 ? 2 * M * L * NP * NP : 0) + M * (L - 1) * Q2 * Q2);
+  int64_t Cw = C;
+  if (work_columns > 0) {
+    Cw = std::min<int64_t>(C, work_columns);
+  } else {
+    const char* env = getenv("RTD_WORK_BYTES");
+    const double budget = env ? atof(env) : 24.0 * (double)(1ull << 30);
+    int64_t fit = (int64_t)(budget / (double)per_col);
+    if (fit < 1) fit = 1;
+    if (fit > 256) fit -= fit % 256;
+    Cw = std::min<int64_t>(C, fit);
+  }
+  p->Cw = (int)Cw;
+  p->nwin = (int)((C + Cw - 1) / Cw);
   double *mu = nullptr, *w = nullptr, *invmu = nullptr, *S = nullptr, *T = nullptr, *omega = nullptr, *tau = nullptr,
          *taus0 = nullptr, *scale = nullptr, *wleg = nullptr, *mu0 = nullptr, *I0 = nullptr, *phi0 = nullptr,
          *rescale = nullptr, *bpos = nullptr, *bneg = nullptr, *spoly = nullptr, *bq = nullptr, *bq0 = nullptr;
@@ -291,41 +408,78 @@ int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** out) {
     };
 #define A(ptr, n) carve(&ptr, (n));
     A(mu, NP) A(w, NP) A(invmu, NP) A(S, NP) A(T, NP)
-    A(d.Y, M * P * NP) A(d.Y0, C * M * P) A(d.att, C * (L + 1)) A(lperm, C * L)
-    A(omega, C * L) A(tau, C * L) A(taus0, C * (L + 1)) A(scale, C * L) A(wleg, C * L * P)
+    A(d.Y, M * P * NP)
+    // inputs: all C columns
+    A(lperm, C * L) A(omega, C * L) A(tau, C * L) A(taus0, C * (L + 1)) A(scale, C * L) A(wleg, C * L * P)
     A(mu0, C) A(I0, C) A(phi0, C) A(rescale, C)
     A(bpos, C * M * NP) A(bneg, C * M * NP) A(spoly, C * L * Ns) A(bq, C * NB * NP * NP) A(bq0, C * NB * NP)
-    A(d.Ym, C * M * L * NP * NP) A(d.Am, C * M * L * NP * NP) A(d.kk, C * M * L * NP) A(d.Bv, C * M * L * Q2)
-    A(d.dq, C * L * Ns * Q2) A(d.zneg, C * L * NP) A(d.coef, C * M * L * Q2)
-    if (split32) { A(d.Lw, C * M * L * NP * NP) A(d.Qw, C * M * L * NP * NP) }  // three-kernel eigen path only (RTD_EIG32_SPLIT)
-    A(d.Fws, C * M * (L - 1) * Q2 * Q2) A(d.Ek, C * M * L * NP)
+    // intermediates: one window of Cw columns
+    A(d.Y0, Cw * M * P) A(d.att, Cw * (L + 1))
+    A(d.Ym, Cw * M * L * NP * NP) A(d.Am, Cw * M * L * NP * NP) A(d.kk, Cw * M * L * NP) A(d.Bv, Cw * M * L * Q2)
+    A(d.dq, Cw * L * Ns * Q2) A(d.zneg, Cw * L * NP) A(d.coef, Cw * M * L * Q2)
+    if (split32) { A(d.Lw, Cw * M * L * NP * NP) A(d.Qw, Cw * M * L * NP * NP) }  // three-kernel eigen path only (RTD_EIG32_SPLIT)
+    A(d.Fws, Cw * M * (L - 1) * Q2 * Q2) A(d.Ek, Cw * M * L * NP)
     A(d.sweeps, 1) A(d.status, 1)
 #undef A
     if (pass == 0) {
       void* q = nullptr;
       size_t got = 0;
       hipError_t e = pooled_malloc(&q, (size_t)off, device, &got);
-      if (e != hipSuccess) {
-        rtd_plan_destroy(p);
+      if (e != hipSuccess)
         return fail(RTD_ERR_HIP, std::string("hipMalloc of ") + std::to_string(off) + " bytes: " + hipGetErrorString(e));
-      }
       p->allocs.push_back(q);
       p->alloc_bytes.push_back(got);
       p->bytes += (int64_t)got;
       arena = static_cast<char*>(q);
     }
   }
-  (void)rc;
   d.mu = mu; d.w = w; d.invmu = invmu; d.S = S; d.T = T;
   d.omega = omega; d.tau = tau; d.taus0 = taus0; d.scale = scale; d.wleg = wleg;
   d.mu0 = mu0; d.I0 = I0; d.phi0 = phi0; d.rescale = rescale; d.bpos = bpos; d.bneg = bneg;
   d.spoly = spoly; d.bdrfq = bq; d.bdrfq0 = bq0; d.lperm = lperm;
   HIP_TRY(hipMemsetAsync(d.status, 0, sizeof(int), p->stream));
   HIP_TRY(hipMemsetAsync(d.sweeps, 0, sizeof(int), p->stream));
-  HIP_TRY(hipMemsetAsync(d.Bv, 0, (size_t)(C * M * L * Q2) * 8, p->stream));
-  if (Ns > 0) HIP_TRY(hipMemsetAsync(d.dq, 0, (size_t)(C * L * Ns * Q2) * 8, p->stream));
+  HIP_TRY(hipMemsetAsync(d.Bv, 0, (size_t)(Cw * M * L * Q2) * 8, p->stream));
+  if (Ns > 0) HIP_TRY(hipMemsetAsync(d.dq, 0, (size_t)(Cw * L * Ns * Q2) * 8, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+int rtd_plan_create_windowed(const rtd_dims* dims, int32_t device, int32_t work_columns, rtd_plan** out) {
+  if (!dims || !out) return fail(RTD_ERR_ARG, "null argument");
+  *out = nullptr;
+  const int N = dims->nquad / 2;
+  if (dims->ncols < 1 || dims->nlayers < 1 || dims->nquad < 2 || (dims->nquad & 1) || dims->nleg < 1 ||
+      dims->nfourier < 1 || dims->nfourier > dims->nleg || dims->nscoeffs < 0 || dims->nbdrf < 0)
+    return fail(RTD_ERR_ARG, "invalid dimensions");
+  if (N > 32) return fail(RTD_ERR_ARG, "NQuad > 64 is not supported by this build (N = NQuad/2 <= 32)");
+  HIP_TRY(hipSetDevice(device));
+  {  // the evaluation kernel keeps 2 M 2 NP doubles of a point in LDS: refuse sizes a gfx950 workgroup cannot hold
+    constexpr size_t kLdsPerWorkgroup = 160u << 10;  // gfx950: a workgroup may use the CU's whole 160 KiB
+    const size_t need = (size_t)2 * dims->nfourier * 2 * pad_pow2(N) * sizeof(double) + 64;
+    if (need > kLdsPerWorkgroup)
+      return fail(RTD_ERR_ARG, "nfourier x nquad needs " + std::to_string(need) + " bytes of LDS per workgroup (limit 163840)");
+  }
+  rtd_plan* p = new rtd_plan();
+  const int rc = plan_build(p, dims, device, work_columns);
+  if (rc) {
+    const std::string keep = g_err;  // rtd_plan_destroy must not lose the message
+    rtd_plan_destroy(p);
+    g_err = keep;
+    return rc;
+  }
   *out = p;
+  return 0;
+}
+
+int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** out) {
+  return rtd_plan_create_windowed(dims, device, 0, out);
+}
+
+int rtd_plan_windows(rtd_plan* p, int32_t* work_columns, int32_t* nwindows) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  if (work_columns) *work_columns = p->Cw;
+  if (nwindows) *nwindows = p->nwin;
   return 0;
 }
 
@@ -333,11 +487,19 @@ int rtd_plan_destroy(rtd_plan* p) {
   if (!p) return 0;
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
+  if (p->comm_stream) (void)hipStreamSynchronize(p->comm_stream);
+  if (p->copy_stream) (void)hipStreamSynchronize(p->copy_stream);
   rtd_comm_destroy(p);
   for (size_t i = 0; i < p->allocs.size(); ++i)
     if (p->allocs[i]) pooled_free(p->allocs[i], p->alloc_bytes[i], p->device);
   for (auto& e : p->evt)
     if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {p->ev_results, p->ev_gathered, p->ev_win[0], p->ev_win[1], p->ev_copied[0], p->ev_copied[1]})
+    if (e) (void)hipEventDestroy(e);
+  for (char* st : p->stage)
+    if (st) (void)hipHostFree(st);
+  if (p->comm_stream) (void)hipStreamDestroy(p->comm_stream);
+  if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
   if (p->stream) pool().put_stream(p->stream, p->device);
   delete p;
   return 0;
@@ -346,6 +508,7 @@ int rtd_plan_destroy(rtd_plan* p) {
 int rtd_plan_synchronize(rtd_plan* p) {
   if (!p) return fail(RTD_ERR_ARG, "null plan");
   HIP_TRY(hipStreamSynchronize(p->stream));
+  if (p->comm_stream) HIP_TRY(hipStreamSynchronize(p->comm_stream));
   return 0;
 }
 
@@ -393,6 +556,10 @@ int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* 
   if (d.NBDRF > 0 && (!bdrf_q || !bdrf_q0)) return fail(RTD_ERR_ARG, "BDRF tables are required when nbdrf > 0");
   HIP_TRY(hipSetDevice(p->device));
   const int64_t C = d.C, L = d.L, M = d.M, P = d.P, N = d.N, NP = d.NP, Ns = d.Ns, NB = d.NBDRF;
+  // a plan created without a beam skips the beam terms on the device: refuse inputs that have one
+  if (!d.beam)
+    for (int64_t c = 0; c < C; ++c)
+      if (I0[c] > 0.0) return fail(RTD_ERR_ARG, "the plan was created with beam = 0 but a column has I0 > 0");
   hipStream_t s = p->stream;
 #define UP(dst, src, n) HIP_TRY(hipMemcpyAsync((void*)(dst), (src), (size_t)(n) * 8, hipMemcpyHostToDevice, s))
   UP(d.omega, scaled_omega, C * L);
@@ -423,14 +590,23 @@ int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* 
   UP(d.rescale, rescale, C);
   if (Ns > 0) UP(d.spoly, s_poly, C * L * Ns);
   // pad the per-stream arrays from N to NP
-  std::vector<double> bp((size_t)(C * M * NP), 0.0), bn((size_t)(C * M * NP), 0.0);
-  for (int64_t cm = 0; cm < C * M; ++cm)
-    for (int64_t i = 0; i < N; ++i) {
-      if (b_pos) bp[cm * NP + i] = b_pos[cm * N + i];
-      if (b_neg) bn[cm * NP + i] = b_neg[cm * N + i];
-    }
-  UP(d.bpos, bp.data(), C * M * NP);
-  UP(d.bneg, bn.data(), C * M * NP);
+  std::vector<double> bp, bn;
+  if (N == NP) {
+    if (b_pos) UP(d.bpos, b_pos, C * M * NP);
+    else HIP_TRY(hipMemsetAsync((void*)d.bpos, 0, (size_t)(C * M * NP) * 8, s));
+    if (b_neg) UP(d.bneg, b_neg, C * M * NP);
+    else HIP_TRY(hipMemsetAsync((void*)d.bneg, 0, (size_t)(C * M * NP) * 8, s));
+  } else {
+    bp.assign((size_t)(C * M * NP), 0.0);
+    bn.assign((size_t)(C * M * NP), 0.0);
+    for (int64_t cm = 0; cm < C * M; ++cm)
+      for (int64_t i = 0; i < N; ++i) {
+        if (b_pos) bp[cm * NP + i] = b_pos[cm * N + i];
+        if (b_neg) bn[cm * NP + i] = b_neg[cm * N + i];
+      }
+    UP(d.bpos, bp.data(), C * M * NP);
+    UP(d.bneg, bn.data(), C * M * NP);
+  }
   std::vector<double> q, q0;
   if (NB > 0) {
     q.assign((size_t)(C * NB * NP * NP), 0.0);
@@ -487,7 +663,6 @@ int rtd_plan_set_mode_shard(rtd_plan* p, int32_t first, int32_t stride, int32_t 
   d.m0 = first;
   d.mstep = stride;
   d.mtot = total;
-  p->tables_ready = false;
   p->solved = false;
   return 0;
 }
@@ -539,7 +714,7 @@ int rtd_plan_run(rtd_plan* p) {
   if (!p->have_quad || !p->have_cols || p->ev_ntau < 1) return fail(RTD_ERR_STATE, "inputs or evaluation points missing");
   HIP_TRY(hipSetDevice(p->device));
   RtdEval e = make_eval(p, 0, true);
-  return launch_solve(p, true, &e);
+  return launch_solve(p, true, &e, p->have_nt);
 }
 
 int rtd_plan_fetch(rtd_plan* p, double* u, double* u0, double* flux_up, double* fdn, double* fdir) {
@@ -553,14 +728,67 @@ int rtd_plan_fetch(rtd_plan* p, double* u, double* u0, double* flux_up, double* 
   if (flux_up) HIP_TRY(hipMemcpyAsync(flux_up, p->ev_fl, (size_t)(C * nt) * 8, hipMemcpyDeviceToHost, s));
   if (fdn) HIP_TRY(hipMemcpyAsync(fdn, p->ev_fl + C * nt, (size_t)(C * nt) * 8, hipMemcpyDeviceToHost, s));
   if (fdir) HIP_TRY(hipMemcpyAsync(fdir, p->ev_fl + 2 * C * nt, (size_t)(C * nt) * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  int st = 0;
-  HIP_TRY(hipMemcpy(&st, p->d.status, sizeof(int), hipMemcpyDeviceToHost));
-  if (st & 1) {
-    HIP_TRY(hipMemset(p->d.status, 0, sizeof(int)));
-    return fail(RTD_ERR_TAU_RANGE, "tau input outside the tau range specified for the atmosphere");
+  return check_status(p);
+}
+
+// solve + evaluate + copy out, window by window: the device-to-host copy of window w (copy stream, pinned staging)
+// and the host memcpy into the caller's arrays overlap the kernels of window w + 1
+int rtd_plan_run_fetch(rtd_plan* p, double* u, double* u0, double* flux_up, double* fdn, double* fdir) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  if (!p->have_quad || !p->have_cols || p->ev_ntau < 1) return fail(RTD_ERR_STATE, "inputs or evaluation points missing");
+  HIP_TRY(hipSetDevice(p->device));
+  const int64_t C = p->d.C, Qr = 2 * p->d.N, nt = p->ev_ntau, np = p->ev_nphi;
+  const int64_t per_u = (u && np > 0) ? Qr * nt * np : 0, per_u0 = u0 ? Qr * nt : 0, per_fl = nt;
+  const int nfl = (flux_up ? 1 : 0) + (fdn ? 1 : 0) + (fdir ? 1 : 0);
+  const size_t slab = (size_t)p->Cw * (size_t)(per_u + per_u0 + nfl * per_fl) * 8;
+  if (!p->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+  for (int k = 0; k < 2; ++k) {
+    if (!p->ev_win[k]) HIP_TRY(hipEventCreateWithFlags(&p->ev_win[k], hipEventDisableTiming));
+    if (!p->ev_copied[k]) HIP_TRY(hipEventCreateWithFlags(&p->ev_copied[k], hipEventDisableTiming));
   }
-  return 0;
+  if (slab > p->stage_bytes) {
+    for (char*& st : p->stage) {
+      if (st) (void)hipHostFree(st);
+      st = nullptr;
+      HIP_TRY(hipHostMalloc((void**)&st, slab, hipHostMallocDefault));
+    }
+    p->stage_bytes = slab;
+  }
+  double* fls[3] = {flux_up, fdn, fdir};
+  // host side of window w: wait for its copy, scatter the staging slab into the caller's arrays
+  auto drain = [&](int w) -> int {
+    const int k = w & 1;
+    const int64_t c0 = (int64_t)w * p->Cw, cnt = std::min<int64_t>(p->Cw, C - c0);
+    HIP_TRY(hipEventSynchronize(p->ev_copied[k]));
+    const char* src = p->stage[k];
+    if (per_u) { std::memcpy(u + c0 * per_u, src, (size_t)(cnt * per_u) * 8); src += cnt * per_u * 8; }
+    if (per_u0) { std::memcpy(u0 + c0 * per_u0, src, (size_t)(cnt * per_u0) * 8); src += cnt * per_u0 * 8; }
+    for (int f = 0; f < 3; ++f)
+      if (fls[f]) { std::memcpy(fls[f] + c0 * nt, src, (size_t)(cnt * nt) * 8); src += cnt * nt * 8; }
+    return 0;
+  };
+  RtdEval e = make_eval(p, 0, true);
+  int rc = launch_windows(p, true, &e, p->have_nt, [&](int w, int64_t c0, int cnt) -> int {
+    const int k = w & 1;
+    if (w >= 2) {  // the slab of window w - 2 must have been drained before it is overwritten
+      int r = drain(w - 2);
+      if (r) return r;
+    }
+    HIP_TRY(hipEventRecord(p->ev_win[k], p->stream));
+    HIP_TRY(hipStreamWaitEvent(p->copy_stream, p->ev_win[k], 0));
+    char* dst = p->stage[k];
+    hipStream_t cs = p->copy_stream;
+    if (per_u) { HIP_TRY(hipMemcpyAsync(dst, p->ev_u + c0 * per_u, (size_t)(cnt * per_u) * 8, hipMemcpyDeviceToHost, cs)); dst += (int64_t)cnt * per_u * 8; }
+    if (per_u0) { HIP_TRY(hipMemcpyAsync(dst, p->ev_u0 + c0 * per_u0, (size_t)(cnt * per_u0) * 8, hipMemcpyDeviceToHost, cs)); dst += (int64_t)cnt * per_u0 * 8; }
+    for (int f = 0; f < 3; ++f)
+      if (fls[f]) { HIP_TRY(hipMemcpyAsync(dst, p->ev_fl + f * C * nt + c0 * nt, (size_t)((int64_t)cnt * nt) * 8, hipMemcpyDeviceToHost, cs)); dst += (int64_t)cnt * nt * 8; }
+    HIP_TRY(hipEventRecord(p->ev_copied[k], cs));
+    return 0;
+  });
+  if (rc) return rc;
+  for (int w = std::max(0, p->nwin - 2); w < p->nwin; ++w)
+    if ((rc = drain(w))) return rc;
+  return check_status(p);
 }
 
 int rtd_plan_result_dev_ptrs(rtd_plan* p, void** u_dev, int64_t* u_bytes, void** flux_dev, int64_t* flux_bytes) {
@@ -582,25 +810,11 @@ int rtd_plan_evaluate(rtd_plan* p, int32_t ntau, const double* tau, int32_t nphi
   if (rc) return rc;
   const bool skip_nt = (antiderivative & 2) != 0;
   RtdEval e = make_eval(p, antiderivative & 1, u != nullptr);
-  if (p->timing) {
-    (void)hipStreamSynchronize(p->stream);
-    harvest(p);
-    (void)hipEventRecord(p->evt[6], p->stream);
-  }
-  rtd_launch_eval(p->d, e, p->stream);
-  if (p->have_nt && !skip_nt && e.u != nullptr) {
-    if (!p->nt_tables_ready) {
-      rtd_launch_nt_tables(p->d, p->nt, p->stream);
-      p->nt_tables_ready = true;
-    }
-    rtd_launch_nt_apply(p->d, p->nt, e, p->stream);
-  }
-  if (p->timing) {
-    (void)hipEventRecord(p->evt[7], p->stream);
-    p->pending[6] = true;
-  }
-  hipError_t er = hipGetLastError();
-  if (er != hipSuccess) return fail(RTD_ERR_HIP, std::string("eval launch: ") + hipGetErrorString(er));
+  // one window: the intermediates of the solve are resident, only the evaluation kernels run.  Several windows: they
+  // are solved again, window by window, with the evaluation behind each (the throughput form rtd_plan_run is the
+  // intended entry point for such batches).
+  rc = launch_windows(p, p->nwin > 1, &e, p->have_nt && !skip_nt, [](int, int64_t, int) { return 0; });
+  if (rc) return rc;
   rc = rtd_plan_fetch(p, u, u0, flux_up, fdn, fdir);
   if (rc) return rc;
   if (ulast) {
@@ -621,19 +835,19 @@ int rtd_plan_set_nt(rtd_plan* p, int32_t nleg_all, const double* weighted_leg_al
   if (!p->d.beam) return fail(RTD_ERR_ARG, "NT corrections need a beam source");
   HIP_TRY(hipSetDevice(p->device));
   const int64_t C = p->d.C, L = p->d.L;
-  double *w, *f, *ic, *ip, *R;
-  int rc;
-  if ((rc = p->alloc(&w, C * L * nleg_all)) || (rc = p->alloc(&f, C * L)) || (rc = p->alloc(&ic, C * nleg_all)) ||
-      (rc = p->alloc(&ip, C * 2)) || (rc = p->alloc(&R, C * 4 * p->d.NP * L)))
+  int rc;  // buffers are reused (or grown) on repeated calls, not leaked
+  if ((rc = grow(p, &p->nt_w, &p->cap_nt_w, C * L * nleg_all)) || (rc = grow(p, &p->nt_f, &p->cap_nt_f, C * L)) ||
+      (rc = grow(p, &p->nt_ic, &p->cap_nt_ic, C * nleg_all)) || (rc = grow(p, &p->nt_ip, &p->cap_nt_ip, C * 2)) ||
+      (rc = grow(p, &p->nt_R, &p->cap_nt_R, C * 4 * p->d.NP * L)))
     return rc;
   hipStream_t s = p->stream;
-  HIP_TRY(hipMemcpyAsync(w, weighted_leg_all, (size_t)(C * L * nleg_all) * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(f, f_arr, (size_t)(C * L) * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(ic, ims_coef, (size_t)(C * nleg_all) * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(ip, ims_par, (size_t)(C * 2) * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(p->nt_w, weighted_leg_all, (size_t)(C * L * nleg_all) * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(p->nt_f, f_arr, (size_t)(C * L) * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(p->nt_ic, ims_coef, (size_t)(C * nleg_all) * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(p->nt_ip, ims_par, (size_t)(C * 2) * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));
   p->nt.nleg_all = nleg_all;
-  p->nt.wfull = w; p->nt.f = f; p->nt.ims_coef = ic; p->nt.ims_par = ip; p->nt.R = R;
+  p->nt.wfull = p->nt_w; p->nt.f = p->nt_f; p->nt.ims_coef = p->nt_ic; p->nt.ims_par = p->nt_ip; p->nt.R = p->nt_R;
   p->have_nt = true;
   p->nt_tables_ready = false;
   return 0;
@@ -650,16 +864,26 @@ int rtd_plan_get_tensors(rtd_plan* p, int32_t column, double* GC, double* K, dou
     int rc = p->alloc(&p->ex_buf, 2 * nG + 2 * nK + nZ);
     if (rc) return rc;
   }
+  hipStream_t s = p->stream;
+  RtdDev d = p->d;
+  int local = column;
+  if (p->nwin > 1) {  // the column is solved again on its own (its window's intermediates may have been overwritten)
+    d = window_dev(p, column, 1);
+    local = 0;
+    rtd_launch_tables(d, s, false);
+    for (int part = 0; part < 3; ++part) rtd_launch_eig(d, s, part);
+    for (int part = 0; part < 2; ++part) rtd_launch_bc(d, s, part);
+  }
   double *dGC = p->ex_buf, *dG = dGC + nG, *dK = dG + nG, *dB = dK + nK, *dZ = dB + nK;
-  HIP_TRY(hipMemsetAsync(dZ, 0, (size_t)nZ * 8, p->stream));
-  rtd_launch_export(p->d, column, dGC, dK, dB, dZ, dG, p->stream);
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  HIP_TRY(hipMemsetAsync(dZ, 0, (size_t)nZ * 8, s));
+  rtd_launch_export(d, local, dGC, dK, dB, dZ, dG, s);
+  HIP_TRY(hipStreamSynchronize(s));
   if (GC) HIP_TRY(hipMemcpy(GC, dGC, (size_t)nG * 8, hipMemcpyDeviceToHost));
   if (G) HIP_TRY(hipMemcpy(G, dG, (size_t)nG * 8, hipMemcpyDeviceToHost));
   if (K) HIP_TRY(hipMemcpy(K, dK, (size_t)nK * 8, hipMemcpyDeviceToHost));
   if (B) HIP_TRY(hipMemcpy(B, dB, (size_t)nK * 8, hipMemcpyDeviceToHost));
   if (Gim) HIP_TRY(hipMemcpy(Gim, dZ, (size_t)nZ * 8, hipMemcpyDeviceToHost));
-  return 0;
+  return check_status(p);
 }
 
 static int solve_once(const rtd_dims* dims, int32_t device, const rtd_inputs* in, rtd_plan** out) {
@@ -673,7 +897,9 @@ static int solve_once(const rtd_dims* dims, int32_t device, const rtd_inputs* in
                               in->I0, in->phi0, in->rescale, in->b_pos, in->b_neg, in->s_poly, in->bdrf_q, in->bdrf_q0);
   if (!rc) rc = rtd_plan_solve(p);
   if (rc) {
+    const std::string keep = g_err;
     rtd_plan_destroy(p);
+    g_err = keep;
     return rc;
   }
   *out = p;
@@ -686,7 +912,9 @@ int rtd_solve_batch(const rtd_dims* dims, int32_t device, const rtd_inputs* in, 
   int rc = solve_once(dims, device, in, &p);
   if (rc) return rc;
   rc = rtd_plan_evaluate(p, ntau, tau, nphi, phi, 0, u, u0, flux_up, fdn, fdir, nullptr);
+  const std::string keep = g_err;
   rtd_plan_destroy(p);
+  g_err = keep;
   return rc;
 }
 
@@ -696,7 +924,9 @@ int rtd_solve_tensors(const rtd_dims* dims, int32_t device, const rtd_inputs* in
   int rc = solve_once(dims, device, in, &p);
   if (rc) return rc;
   rc = rtd_plan_get_tensors(p, column, GC, K, B, Gim, G);
+  const std::string keep = g_err;
   rtd_plan_destroy(p);
+  g_err = keep;
   return rc;
 }
 
@@ -705,6 +935,10 @@ int rtd_plan_enable_timing(rtd_plan* p, int32_t enable) {
   if (enable && !p->evt[0]) {
     HIP_TRY(hipSetDevice(p->device));
     for (auto& e : p->evt) HIP_TRY(hipEventCreate(&e));
+  }
+  if (!enable && p->timing) {
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    harvest(p);
   }
   p->timing = enable != 0;
   return 0;
@@ -727,9 +961,9 @@ int rtd_plan_get_timing(rtd_plan* p, double ms[7], int64_t nlaunch[7], int32_t r
 
 int rtd_plan_max_sweeps(rtd_plan* p, int32_t* sweeps) {
   if (!p || !sweeps) return fail(RTD_ERR_ARG, "null argument");
-  HIP_TRY(hipStreamSynchronize(p->stream));
   int v = 0;
-  HIP_TRY(hipMemcpy(&v, p->d.sweeps, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(&v, p->d.sweeps, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
   *sweeps = v;
   return 0;
 }
@@ -747,9 +981,8 @@ struct RcclApi {
 };
 RcclApi* rccl() {
   static RcclApi api;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  static std::once_flag once;  // plans may be used from different host threads (one thread per plan)
+  std::call_once(once, [] {
     // The ROCm install's RCCL first, by absolute path: a process that also imports PyTorch carries a second,
     // bundled RCCL/HIP pair under the same SONAMEs, and RCCL must bind to the HIP runtime librtd itself uses.
     for (const char* name : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) {
@@ -763,9 +996,9 @@ RcclApi* rccl() {
       api.AllReduce = (decltype(api.AllReduce))dlsym(api.h, "ncclAllReduce");
       api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
       api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
-      if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) api.h = nullptr;
+      if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy || !api.GetErrorString) api.h = nullptr;
     }
-  }
+  });
   return api.h ? &api : nullptr;
 }
 }  // namespace
@@ -813,6 +1046,43 @@ int rtd_comm_allgather_fluxes(rtd_plan* p) {
   return 0;
 }
 
+int rtd_comm_allgather_results(rtd_plan* p) {
+  if (!p || !p->comm) return fail(RTD_ERR_STATE, "communicator not initialised");
+  if (p->ev_ntau < 1 || !p->solved) return fail(RTD_ERR_STATE, "no evaluation results to gather");
+  HIP_TRY(hipSetDevice(p->device));
+  const int64_t C = p->d.C, Qr = 2 * p->d.N, nt = p->ev_ntau, np = p->ev_nphi;
+  const int64_t nu = np > 0 ? C * Qr * nt * np : 0, nfl = 3 * C * nt;
+  int rc;
+  if ((rc = grow(p, &p->gathered_u, &p->cap_gathered_u, std::max<int64_t>(nu, 1) * p->comm_size))) return rc;
+  if ((rc = grow(p, &p->gathered_fl, &p->cap_gathered_fl, nfl * p->comm_size))) return rc;
+  if (!p->comm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking));
+  if (!p->ev_results) HIP_TRY(hipEventCreateWithFlags(&p->ev_results, hipEventDisableTiming));
+  if (!p->ev_gathered) HIP_TRY(hipEventCreateWithFlags(&p->ev_gathered, hipEventDisableTiming));
+  // the gather starts when the run that produced the results is done, and runs beside the next run's kernels
+  HIP_TRY(hipEventRecord(p->ev_results, p->stream));
+  HIP_TRY(hipStreamWaitEvent(p->comm_stream, p->ev_results, 0));
+  RcclApi* r = rccl();
+  ncclResult_t nr = ncclSuccess;
+  if (nu > 0) nr = r->AllGather(p->ev_u, p->gathered_u, (size_t)nu, ncclDouble, p->comm, p->comm_stream);
+  if (nr == ncclSuccess) nr = r->AllGather(p->ev_fl, p->gathered_fl, (size_t)nfl, ncclDouble, p->comm, p->comm_stream);
+  if (nr != ncclSuccess) return fail(RTD_ERR_HIP, std::string("ncclAllGather: ") + r->GetErrorString(nr));
+  HIP_TRY(hipEventRecord(p->ev_gathered, p->comm_stream));
+  p->gather_inflight = true;
+  return 0;
+}
+
+int rtd_comm_fetch_gathered_results(rtd_plan* p, double* u, double* fluxes) {
+  if (!p || !p->gathered_fl) return fail(RTD_ERR_STATE, "nothing gathered");
+  HIP_TRY(hipSetDevice(p->device));
+  const int64_t C = p->d.C, Qr = 2 * p->d.N, nt = p->ev_ntau, np = p->ev_nphi;
+  const int64_t nu = np > 0 ? C * Qr * nt * np : 0, nfl = 3 * C * nt;
+  hipStream_t s = p->comm_stream;
+  if (u && nu > 0) HIP_TRY(hipMemcpyAsync(u, p->gathered_u, (size_t)(nu * p->comm_size) * 8, hipMemcpyDeviceToHost, s));
+  if (fluxes) HIP_TRY(hipMemcpyAsync(fluxes, p->gathered_fl, (size_t)(nfl * p->comm_size) * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
 int rtd_comm_allreduce_results(rtd_plan* p) {
   if (!p || !p->comm) return fail(RTD_ERR_STATE, "communicator not initialised");
   if (p->ev_ntau < 1) return fail(RTD_ERR_STATE, "no evaluation results to reduce");
@@ -842,9 +1112,11 @@ int rtd_comm_destroy(rtd_plan* p) {
   if (!p) return 0;
   if (p->comm && rccl()) {
     (void)hipStreamSynchronize(p->stream);
+    if (p->comm_stream) (void)hipStreamSynchronize(p->comm_stream);
     rccl()->CommDestroy(p->comm);
   }
   p->comm = nullptr;
+  p->gather_inflight = false;
   return 0;
 }
 

@@ -575,6 +575,8 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
     if (valid) {
       coef[(long)l * Q + j] = v2[j];
       coef[(long)l * Q + NP + j] = v1[j];
+      // singular system (the reference's solve_banded / solve raises LinAlgError, :326-333, :383)
+      if (!(fabs(v2[j]) + fabs(v1[j]) < 1e300)) atomicOr(d.status, RTD_ST_BC);
     }
   }
   // ---- backward sweep: C+_l = Wq C-' + Wp E' C+' + rho_b ;  C-_l = s - S C+_l
@@ -1142,13 +1144,18 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       coef[(long)l * Q + col] = cminus;
       coef[(long)l * Q + NP + col] = cplus;
     }
+    // a singular system (the reference's solve_banded / solve raises LinAlgError, :326-333, :383) leaves inf / nan here,
+    // and they propagate through the whole backward sweep: one test at its end is enough
   }
   // ---- backward sweep: C+_l = Wq C-' + Wp E' C+' + rho_b ;  C-_l = s_l - S_l C+_l, with W applied through its
   //      factors.  The loads of layer l-1 are issued while layer l is processed.
   a1 = a0;
   y1 = y0;
   double k1b = kk[Lm1 * NP + col], e1b = Ek[Lm1 * NP + col];
-  if (Lm1 == 0) return;  // single layer: no interface, no workspace
+  if (Lm1 == 0) {  // single layer: no interface, no workspace
+    if (!(fabs(cminus) + fabs(cplus) < 1e300)) atomicOr(d.status, RTD_ST_BC);
+    return;
+  }
   int lp = Lm1 - 1;
   v4f64 pa = load_d(Am + (long)lp * NN, kq, col), py = load_d(Ym + (long)lp * NN, kq, col), ph = load_d(wsb + (long)lp * Ws<NP>::SLOT + Ws<NP>::S, kq, col);
   double psl = wsb[(long)lp * Ws<NP>::SLOT + Ws<NP>::SV + col], prb = wsb[(long)lp * Ws<NP>::SLOT + Ws<NP>::RB + col];
@@ -1199,6 +1206,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     k1b = k0b;
     e1b = e0b;
   }
+  if (!(fabs(cminus) + fabs(cplus) < 1e300)) atomicOr(d.status, RTD_ST_BC);
 }
 
 }  // namespace

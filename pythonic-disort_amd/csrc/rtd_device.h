@@ -41,7 +41,16 @@ struct RtdDev {
   double* Ek;         // [C][M][L][NP]  exp(-k dtau*_l): the Stamnes-Conklin scaling factors
   double* Fws;  // BC workspace: [C][M][L-1][4 NP^2]: Wp, Wq, S, rho_t, rho_b, s per interface (rtd_bc.hip)
   int* sweeps;        // [1] max Jacobi sweeps (diagnostic)
-  int* status;        // [1] device-side status flags (bit 0: tau out of range)
+  int* status;        // [1] device-side status flags (RTD_ST_*)
+};
+
+// device-side status bits (rtd_api.hip maps bit 0 to RTD_ERR_TAU_RANGE, the others to RTD_ERR_NUMERIC)
+enum : int {
+  RTD_ST_TAU = 1,     // an evaluation point lies outside [0, tau_arr[-1]] of its column
+  RTD_ST_JACOBI = 2,  // the Jacobi iteration of some eigenproblem hit its sweep limit
+  RTD_ST_CHOL = 4,    // non-positive pivot in a Cholesky factorisation / non-finite eigenvalue
+  RTD_ST_BC = 8,      // non-finite boundary-condition coefficients (singular system)
+  RTD_ST_BEAM = 16    // non-finite beam particular solution (1/mu0 on an eigenvalue)
 };
 
 struct RtdEval {
@@ -62,7 +71,7 @@ struct RtdNt {
 };
 
 // launchers (one per translation unit)
-void rtd_launch_tables(const RtdDev& d, hipStream_t s);
+void rtd_launch_tables(const RtdDev& d, hipStream_t s, bool with_quad = true);  // with_quad: also the column-independent Y table
 void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part);  // 0 asm, 1 jacobi, 2 post
 void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part);   // 0 iface, 1 sweep
 void rtd_launch_eval(const RtdDev& d, const RtdEval& e, hipStream_t s);

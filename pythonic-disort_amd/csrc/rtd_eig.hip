@@ -667,6 +667,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : 1)) void rtd_eige
   }
   // one-sided Jacobi on the columns of F
   int nsweep = 0;
+  bool converged = false;
   for (int sweep = 0; sweep < 40; ++sweep) {
     int notconv = 0;
     double alpha = 0.0;
@@ -674,9 +675,13 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : 1)) void rtd_eige
     for (int i = 0; i < NP; ++i) alpha += w[i] * w[i];
     JacobiStep<NP, 1>::run(w, alpha, j, notconv);
     ++nsweep;
-    if (!__any(notconv)) break;
+    if (!__any(notconv)) {
+      converged = true;
+      break;
+    }
   }
   if (threadIdx.x == 0 && nsweep > *(volatile int*)d.sweeps) atomicMax(d.sweeps, nsweep);
+  if (!converged && threadIdx.x == 0) atomicOr(d.status, RTD_ST_JACOBI);  // NaN input (failed Cholesky) also ends here
   }
   // ---- stage 2: eigenvector blocks and particular solutions.  The lane's identifiers are rebuilt from an opaque copy
   //      of the lane index, so that none of them is kept (and spilled) across the Jacobi loop.
@@ -700,6 +705,9 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : 1)) void rtd_eige
 #pragma unroll
   for (int i = 0; i < NP; ++i) k2 += w[i] * w[i];
   const double rk0 = fast_rsqrt(k2), kj = k2 * rk0;
+  // a non-positive Cholesky pivot (phase function not positive definite after delta-M scaling) or an overflow shows up
+  // as a non-finite or non-positive eigenvalue: the reference's eig / sqrt would return NaN here (:186)
+  if (valid && !(k2 > 0.0 && k2 < 1e300)) atomicOr(d.status, RTD_ST_CHOL);
   double zc[NP];
   {
 #pragma unroll
@@ -795,6 +803,8 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : 1)) void rtd_eige
     if (valid) {
       d.Bv[base * 2 * NP + j] = 0.5 * (s_j + d_j);
       d.Bv[base * 2 * NP + NP + j] = 0.5 * (s_j - d_j);
+      // 1/mu0 on an eigenvalue: the reference's solve (:226-231) meets a singular matrix
+      if (!(fabs(s_j) + fabs(d_j) < 1e300)) atomicOr(d.status, RTD_ST_BEAM);
     }
   }
   __syncthreads();
@@ -905,8 +915,8 @@ __global__ void rtd_tables_mu0_kernel(RtdDev d) {
 
 }  // namespace
 
-void rtd_launch_tables(const RtdDev& d, hipStream_t s) {
-  {
+void rtd_launch_tables(const RtdDev& d, hipStream_t s, bool with_quad) {
+  if (with_quad) {
     const int n = d.M * d.NP;
     hipLaunchKernelGGL(rtd_tables_quad_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d);
   }

@@ -12,8 +12,9 @@ def _f64(a):
 
 
 class Plan:
-    def __init__(self, prep, device=0):
-        """prep: dict from _prepare.prepare_columns."""
+    def __init__(self, prep, device=0, work_columns=0):
+        """prep: dict from _prepare.prepare_columns.  work_columns: columns whose intermediates are resident at a time
+        (0: sized by the library, include/rtd.h: rtd_plan_create_windowed)."""
         lib = _lib.load()
         self._lib = lib
         self.prep = prep
@@ -22,7 +23,7 @@ class Plan:
         dims = _lib.rtd_dims(prep["C"], prep["L"], 2 * prep["N"], prep["P"], prep["M"], prep["Ns"],
                              prep["NBDRF"], int(prep["beam"]))
         h = C.c_void_p()
-        _lib.check(lib.rtd_plan_create(C.byref(dims), device, C.byref(h)))
+        _lib.check(lib.rtd_plan_create_windowed(C.byref(dims), device, int(work_columns), C.byref(h)))
         self._h = h
         mu, w = _f64(prep["mu"]), _f64(prep["W"])
         _lib.check(lib.rtd_plan_set_quadrature(h, _lib.dptr(mu), _lib.dptr(w)))
@@ -41,10 +42,14 @@ class Plan:
         _lib.check(self._lib.rtd_comm_allreduce_results(self._h))
 
     def set_columns(self, prep):
-        """Upload the prepared per-column inputs (same dimensions as the plan): a plan can be reused for many batches."""
+        """Upload the prepared per-column inputs (same dimensions as the plan): a plan can be reused for many batches.
+        A plan created without a beam source skips the beam terms on the device, so a batch that has one is refused
+        (and a batch without one for a plan with one is fine: its beam terms are zero)."""
         for k in ("C", "L", "N", "P", "M", "Ns", "NBDRF"):
             if prep[k] != self.prep[k]:
                 raise ValueError(f"prepared batch does not match the plan: {k} = {prep[k]} vs {self.prep[k]}")
+        if prep["beam"] and not self.prep["beam"]:
+            raise ValueError("prepared batch has a beam source but the plan was created without one")
         keys = ["omega_s", "tau", "tau_s0", "scale_tau", "wleg", "mu0", "I0", "phi0", "rescale",
                 "b_pos", "b_neg", "s_s", "bdrf_q", "bdrf_q0"]
         arrs = [_f64(prep[k]) for k in keys]
@@ -133,6 +138,26 @@ class Plan:
         _lib.check(self._lib.rtd_plan_run(self._h))
         self.solved = True
 
+    def windows(self):
+        """(columns per window, number of windows) of the plan's work arena."""
+        a, b = C.c_int32(), C.c_int32()
+        _lib.check(self._lib.rtd_plan_windows(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def run_fetch(self, out=None):
+        """run() and fetch() as one host-to-host pipeline (device-to-host copies of a window overlap the next window's
+        kernels; include/rtd.h: rtd_plan_run_fetch).  `out`: dict of preallocated arrays to fill (u, u0, flux_up,
+        flux_down_diffuse, flux_down_direct; missing keys are not fetched), default: all of them, freshly allocated."""
+        ntau, nphi = self._ev_shape
+        if out is None:
+            out = dict(u=np.empty((self.C, self.Q, ntau, nphi)), u0=np.empty((self.C, self.Q, ntau)),
+                       flux_up=np.empty((self.C, ntau)), flux_down_diffuse=np.empty((self.C, ntau)),
+                       flux_down_direct=np.empty((self.C, ntau)))
+        keys = ("u", "u0", "flux_up", "flux_down_diffuse", "flux_down_direct")
+        _lib.check(self._lib.rtd_plan_run_fetch(self._h, *[_lib.dptr(out.get(k)) for k in keys]))
+        self.solved = True
+        return out
+
     def fetch(self):
         ntau, nphi = self._ev_shape
         u = np.empty((self.C, self.Q, ntau, nphi))
@@ -173,6 +198,19 @@ class Plan:
 
     def allgather_fluxes(self):
         _lib.check(self._lib.rtd_comm_allgather_fluxes(self._h))
+
+    def allgather_results(self):
+        """RCCL all-gather of u and the fluxes of the last run() over the ranks, on the plan's communication stream
+        (overlaps the next run(); include/rtd.h: rtd_comm_allgather_results)."""
+        _lib.check(self._lib.rtd_comm_allgather_results(self._h))
+
+    def fetch_gathered_results(self, want_u=True):
+        """-> (u [nranks * C, Q, ntau, nphi] or None, fluxes [nranks, 3, C, ntau]) of the last allgather_results()."""
+        ntau, nphi = self._ev_shape
+        u = np.empty((self._nranks * self.C, self.Q, ntau, nphi)) if want_u else None
+        fl = np.empty((self._nranks, 3, self.C, ntau))
+        _lib.check(self._lib.rtd_comm_fetch_gathered_results(self._h, _lib.dptr(u), _lib.dptr(fl)))
+        return u, fl
 
     def fetch_gathered(self):
         out = np.empty((self._nranks, 3, self.C, self._ev_shape[0]))

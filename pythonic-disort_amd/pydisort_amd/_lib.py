@@ -31,6 +31,8 @@ SIGNATURES = {
     "rtd_last_error": (C.c_char_p, []),
     "rtd_device_count": (C.c_int, [C.POINTER(C.c_int32)]),
     "rtd_plan_create": (C.c_int, [C.POINTER(rtd_dims), C.c_int32, C.POINTER(_vp)]),
+    "rtd_plan_create_windowed": (C.c_int, [C.POINTER(rtd_dims), C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "rtd_plan_windows": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rtd_plan_destroy": (C.c_int, [_vp]),
     "rtd_plan_synchronize": (C.c_int, [_vp]),
     "rtd_plan_device_bytes": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
@@ -47,6 +49,7 @@ SIGNATURES = {
     "rtd_plan_set_eval_points": (C.c_int, [_vp, C.c_int32, _dp, C.c_int32, _dp]),
     "rtd_plan_run": (C.c_int, [_vp]),
     "rtd_plan_fetch": (C.c_int, [_vp] + [_dp] * 5),
+    "rtd_plan_run_fetch": (C.c_int, [_vp] + [_dp] * 5),
     "rtd_plan_result_dev_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_int64), C.POINTER(_vp),
                                            C.POINTER(C.c_int64)]),
     "rtd_plan_get_tensors": (C.c_int, [_vp, C.c_int32] + [_dp] * 5),
@@ -58,10 +61,21 @@ SIGNATURES = {
     "rtd_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int32, C.c_int32]),
     "rtd_comm_allgather_fluxes": (C.c_int, [_vp]),
     "rtd_comm_allreduce_results": (C.c_int, [_vp]),
+    "rtd_comm_allgather_results": (C.c_int, [_vp]),
+    "rtd_comm_fetch_gathered_results": (C.c_int, [_vp, _dp, _dp]),
     "rtd_comm_fetch_gathered": (C.c_int, [_vp, _dp]),
     "rtd_comm_destroy": (C.c_int, [_vp]),
 }
 RTD_ERR_TAU_RANGE = 3
+RTD_ERR_NUMERIC = 5
+
+
+class NumericalError(RuntimeError, np.linalg.LinAlgError):
+    """Numerical failure reported by the device (RTD_ERR_NUMERIC): singular boundary-condition system, non-positive
+    Cholesky pivot, unconverged eigen-iteration or 1/mu0 on an eigenvalue.  The reference raises
+    ``numpy.linalg.LinAlgError`` from ``np.linalg.solve`` / ``eig`` in these situations
+    (_solve_for_gen_and_part_sols.py:179-183, :226-231; _solve_for_coeffs.py:326-333, :383)."""
+
 
 _lib = None
 
@@ -95,4 +109,6 @@ def check(rc):
         msg = load().rtd_last_error().decode()
         if rc == RTD_ERR_TAU_RANGE:
             raise ValueError("tau input outside the tau range specified for the atmosphere (check `tau_arr`).")
+        if rc == RTD_ERR_NUMERIC:
+            raise NumericalError(msg)
         raise RuntimeError(f"librtd error {rc}: {msg}")

@@ -42,7 +42,8 @@ class BatchSolution:
 
 def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLeg=None, NFourier=None,
                    b_pos=0, b_neg=0, only_flux=False, f_arr=0, NT_cor=False, bdrf_q=None, bdrf_q0=None,
-                   s_poly_coeffs=None, device=0, bdrf_samples=None, NBDRF=None, mode_shard=None):
+                   s_poly_coeffs=None, device=0, bdrf_samples=None, NBDRF=None, mode_shard=None, work_columns=0,
+                   _defer_solve=False):
     """Like ``pydisort`` with a leading column axis on every atmospheric input:
     tau_arr, omega_arr, f_arr [C, L]; Leg_coeffs_all [C, L, NLeg_all]; mu0, I0, phi0 [C];
     b_pos / b_neg: scalar, [C], [C, N] or [C, N, NFourier]; s_poly_coeffs [C, L, Ns];
@@ -55,6 +56,8 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
     mode_shard=(r, G): solve only the Fourier modes r, r + G, r + 2G, ... (the partition for
     fewer columns than GPUs); the evaluators then return this shard's partial sums -- the shards add up to the full
     result (u0, fluxes and NT corrections come from shard 0 only; ``Plan.allreduce_results`` sums across RCCL ranks).
+    work_columns: columns whose intermediates are resident on the device at a time (0: sized by the library); batches
+    larger than that are solved window by window (include/rtd.h: rtd_plan_create_windowed).
     All columns share NQuad, NLeg, NFourier and the layer count.  Returns (mu_arr, BatchSolution)."""
     tau_arr = np.atleast_2d(np.asarray(tau_arr, float))
     C, L = tau_arr.shape
@@ -116,10 +119,11 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
         prep["M"] = len(modes)
         prep["mode_shard"] = (r, G, NFourier)
         NT_cor = NT_cor and r == 0
-    plan = Plan(prep, device=device)
+    plan = Plan(prep, device=device, work_columns=work_columns)
     if bdrf_samples is not None:
         plan.set_bdrf_samples(bdrf_samples[0], bdrf_samples[1] if np.any(I0 > 0) else None)
-    plan.solve()
+    if not _defer_solve:
+        plan.solve()
     if NT_cor and not only_flux:
         if not (np.all(I0 > 0) and np.any(f_arr > 0) and NLeg < Leg.shape[2]):
             raise ValueError("NT_cor needs a beam source in every column, f_arr > 0 and NLeg < number of Legendre coefficients.")
@@ -130,77 +134,30 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
     return sol.mu_arr, sol
 
 
-def solve_columns_streamed(cfg, tau, phi, chunk_columns=4096, device=0, only_flux=False):
-    """Throughput form for column counts that do not fit one plan (a cfg4 column needs ~8 MB of HBM): the columns
-    are solved chunk by chunk through ONE reused plan (same device buffers, new inputs per chunk) and only the
-    evaluated results come back.
+def solve_columns_streamed(cfg, tau, phi, chunk_columns=0, device=0, only_flux=False):
+    """Throughput form for large column counts: ONE plan holds the inputs and the results of all columns, the
+    intermediates of the solve (~8 MB per cfg4 column) live for `chunk_columns` columns at a time (0: sized by the
+    library) and the device-to-host copies of a window overlap the kernels of the next (``Plan.run_fetch``).
+    Source terms are taken from the whole batch (a beam or a thermal source in any column switches it on for all).
 
     cfg : dict of ``pydisort_batch`` keyword arguments with a leading column axis (tau_arr, omega_arr, Leg_coeffs_all,
           mu0, I0, phi0, optional f_arr, b_pos, b_neg, s_poly_coeffs, bdrf_q, bdrf_q0, NLeg, NFourier); NQuad scalar.
     tau : [C, ntau] evaluation depths; phi : [nphi].
     Returns dict(u [C, NQuad, ntau, nphi] (absent when only_flux), u0, flux_up, flux_down_diffuse, flux_down_direct)."""
-    tau = np.asarray(tau, float)
-    C = tau.shape[0]
-    per_col = ("tau_arr", "omega_arr", "Leg_coeffs_all", "mu0", "I0", "phi0", "f_arr", "b_pos", "b_neg",
-               "s_poly_coeffs", "bdrf_q", "bdrf_q0")
-    out = {}
-    plan = None
-    for c0 in range(0, C, chunk_columns):
-        c1 = min(c0 + chunk_columns, C)
-        sub = {k: (v[c0:c1] if (k in per_col and isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == C) else v)
-               for k, v in cfg.items()}
-        if plan is not None and c1 - c0 != plan.C:  # last, shorter chunk: new plan
-            plan.close()
-            plan = None
-        if plan is None:
-            _, sol = pydisort_batch(only_flux=only_flux, device=device, **sub)
-            plan = sol.plan
-        else:
-            prep = _prepared_like(plan.prep, sub, only_flux)
-            plan.set_columns(prep)
-            plan.solve()
-        res = plan.evaluate(np.ascontiguousarray(tau[c0:c1]), None if only_flux else phi,
-                            want=("u0", "flux") if only_flux else ("u", "u0", "flux"))
-        for k, v in res.items():
-            if v is None:
-                continue
-            if k not in out:
-                out[k] = np.empty((C,) + v.shape[1:])
-            out[k][c0:c1] = v
-    if plan is not None:
+    tau = np.ascontiguousarray(np.asarray(tau, float))
+    C, ntau = tau.shape
+    _, sol = pydisort_batch(only_flux=only_flux, device=device, work_columns=chunk_columns, _defer_solve=True, **cfg)
+    plan = sol.plan
+    try:
+        sol._tau(tau)  # range check on the host, with the reference's message
+        phi = np.array([0.0]) if only_flux else np.atleast_1d(np.asarray(phi, float))
+        plan.set_eval_points(tau, phi)
+        Q = plan.Q
+        out = dict(u0=np.empty((C, Q, ntau)), flux_up=np.empty((C, ntau)), flux_down_diffuse=np.empty((C, ntau)),
+                   flux_down_direct=np.empty((C, ntau)))
+        if not only_flux:
+            out["u"] = np.empty((C, Q, ntau, len(phi)))
+        plan.run_fetch(out)
+    finally:
         plan.close()
     return out
-
-
-def _prepared_like(prep0, sub, only_flux):
-    """Host preparation of another chunk with the dimensions of an existing plan."""
-    tau_arr = np.atleast_2d(np.asarray(sub["tau_arr"], float))
-    C, L = tau_arr.shape
-    NQuad = sub["NQuad"]
-    N = NQuad // 2
-    NLeg, NFourier = prep0["P"], prep0["M"]
-    Leg = np.asarray(sub["Leg_coeffs_all"], float)
-    if Leg.ndim == 2:
-        Leg = np.broadcast_to(Leg[None], (C,) + Leg.shape)
-
-    def bc(b):
-        b = np.asarray(b, float)
-        out = np.zeros((C, N, NFourier))
-        if b.ndim == 0 or b.shape == (C,):
-            out[:, :, 0] = np.broadcast_to(b, (C,))[:, None]
-        elif b.shape == (C, N):
-            out[:, :, 0] = b
-        else:
-            out[:] = b
-        return out
-
-    sp = sub.get("s_poly_coeffs")
-    sp = np.zeros((C, L, 0)) if sp is None or prep0["Ns"] == 0 else np.asarray(sp, float).reshape(C, L, -1)
-    bq = sub.get("bdrf_q")
-    bq = np.zeros((C, 0, N, N)) if bq is None else np.asarray(bq, float)
-    bq0 = sub.get("bdrf_q0")
-    bq0 = np.zeros((C, 0, N)) if bq0 is None else np.asarray(bq0, float)
-    return prepare_columns(tau_arr, np.broadcast_to(np.asarray(sub["omega_arr"], float), (C, L)), NQuad, Leg,
-                           np.broadcast_to(np.asarray(sub["mu0"], float), (C,)), np.broadcast_to(np.asarray(sub["I0"], float), (C,)),
-                           np.broadcast_to(np.asarray(sub["phi0"], float), (C,)), NLeg, NFourier, bc(sub.get("b_pos", 0)),
-                           bc(sub.get("b_neg", 0)), np.broadcast_to(np.asarray(sub.get("f_arr", 0), float), (C, L)), sp, bq, bq0)

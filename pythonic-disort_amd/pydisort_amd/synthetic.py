@@ -23,6 +23,21 @@ def cfg4_columns(C, first=0, L=20, NQuad=32, seed=4):
                 phi0=np.zeros(C), f_arr=g**NQuad)
 
 
+def cfg4_columns_block(C, first=0, L=20, NQuad=32, seed=4):
+    """The distributions of ``cfg4_columns`` drawn from ONE generator for the whole block (vectorised: 10^5 columns in
+    a fraction of a second instead of a Python loop over per-column generators).  Deterministic in (seed, first, C);
+    NOT the same atmospheres as ``cfg4_columns`` -- used where only the workload's shape matters (throughput legs)."""
+    rng = np.random.default_rng([seed, 77, first, C])
+    tau = np.cumsum(rng.uniform(0.05, 0.5, (C, L)), axis=1)
+    omega = rng.uniform(0.5, 0.99, (C, L))
+    g = rng.uniform(0.6, 0.85, (C, L))
+    mu0 = rng.uniform(0.2, 1.0, C)
+    k = np.arange(NQuad + 1)
+    Leg = g[:, :, None] ** k[None, None, :]
+    return dict(tau_arr=tau, omega_arr=omega, NQuad=NQuad, Leg_coeffs_all=Leg, mu0=mu0, I0=np.full(C, np.pi),
+                phi0=np.zeros(C), f_arr=g**NQuad)
+
+
 def cfg3_columns(C, first=0, big=True, seed=9):
     """Test-Problem-9-like multi-layer atmospheres with every layer different, replicated with a
     per-column perturbation of omega.  big=True: L=8, NQuad=16 (BASELINE wording); False: L=6, NQuad=8."""

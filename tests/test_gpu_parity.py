@@ -532,3 +532,127 @@ def test_fourier_mode_shards_add_up(amd, G):
         assert np.max(np.abs(got_u0 - want_u0)) <= 1e-13 * s
         assert np.array_equal(got_fu, want_fu)
         assert np.array_equal(got_fd[0], want_fd[0]) and np.array_equal(got_fd[1], want_fd[1])
+
+
+# ---- round 2: windowed plans, the u + flux collective, device status --------------------------------------------
+@pytest.mark.gpu
+def test_rccl_allgather_results_single_rank(amd):
+    """The collective of SURVEY 8(e) -- ncclAllGather of u AND the fluxes, on the plan's communication stream, overlapped
+    with the next run -- with a 1-rank communicator; two pipelined steps, the gather of the second is checked."""
+    from pydisort_amd import synthetic
+    from pydisort_amd._engine import Plan
+    Plan.comm_preload()
+    cfg = synthetic.cfg4_columns(8, L=5, NQuad=8)
+    _, sol = amd.pydisort_batch(**cfg)
+    plan = sol.plan
+    tau = np.concatenate((np.zeros((8, 1)), cfg["tau_arr"]), axis=1)
+    plan.set_eval_points(tau, np.array([0.0, 1.0]))
+    plan.comm_init(Plan.comm_unique_id(), 0, 1)
+    for _ in range(3):  # the evaluation kernel of step i + 1 waits for the gather of step i
+        plan.run()
+        plan.allgather_results()
+    plan.synchronize()
+    gu, gf = plan.fetch_gathered_results()
+    res = plan.fetch()
+    assert gu.shape == (8, 8, 6, 2) and gf.shape == (1, 3, 8, 6)
+    assert np.array_equal(gu, res["u"])
+    assert np.array_equal(gf[0, 0], res["flux_up"]) and np.array_equal(gf[0, 1], res["flux_down_diffuse"])
+    assert np.array_equal(gf[0, 2], res["flux_down_direct"])
+    plan.close()
+
+
+@pytest.mark.gpu
+def test_windowed_plan_equals_single_window(amd):
+    """A plan whose intermediates cover 16 columns at a time (4 windows, the last one short) gives the results of the
+    one-window plan bit for bit through every entry point: closures (re-solve per window), run/fetch, run_fetch, tensors."""
+    from pydisort_amd import synthetic
+    C = 50
+    cfg = synthetic.cfg3_columns(C, big=True)   # thermal source, BDRF, beam, b_pos/b_neg: every input array is windowed
+    tau = np.tile(np.linspace(0.0, cfg["tau_arr"][0, -1], 7), (C, 1))
+    phi = np.array([0.0, 2.0])
+    _, one = amd.pydisort_batch(**cfg)
+    _, win = amd.pydisort_batch(work_columns=16, **cfg)
+    assert win.plan.windows() == (16, 4) and one.plan.windows() == (50, 1)
+    assert np.array_equal(win.u(tau, phi), one.u(tau, phi))
+    assert np.array_equal(win.flux_up(tau), one.flux_up(tau))
+    assert np.array_equal(win.flux_down(tau, True)[0], one.flux_down(tau, True)[0])   # antiderivative branch
+    for col in (0, 17, 49):
+        a, b = win.plan.tensors(col), one.plan.tensors(col)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (col, k)
+    win.plan.set_eval_points(tau, phi)
+    got = win.plan.run_fetch()
+    one.plan.set_eval_points(tau, phi)
+    one.plan.run()
+    want = one.plan.fetch()
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    win.plan.run()
+    again = win.plan.fetch()
+    for k in want:
+        assert np.array_equal(again[k], want[k]), k
+
+
+@pytest.mark.gpu
+def test_streamed_batch_takes_its_sources_from_every_column(amd):
+    """Regression (round-1 advisor finding): columns 0..15 have no beam and no thermal source, later columns have both.
+    The streamed solver must not drop the sources of the later windows."""
+    from pydisort_amd import synthetic
+    C = 40
+    cfg = synthetic.cfg3_columns(C, big=False)
+    cfg["I0"] = cfg["I0"].copy()
+    cfg["I0"][:16] = 0.0
+    cfg["s_poly_coeffs"] = cfg["s_poly_coeffs"].copy()
+    cfg["s_poly_coeffs"][:16] = 0.0
+    tau = np.tile(np.linspace(0.0, cfg["tau_arr"][0, -1], 5), (C, 1))
+    phi = np.array([0.3])
+    got = amd.solve_columns_streamed(cfg, tau, phi, chunk_columns=16)
+    _, sol = amd.pydisort_batch(**cfg)
+    assert np.array_equal(got["u"], sol.u(tau, phi))
+    # and against single-column solves of a sourced column and of a source-free column
+    for i in (3, 30):
+        kw = synthetic.column_kwargs(cfg, i)
+        kw["BDRF_Fourier_modes"] = [0.5]
+        res = amd.pydisort(**kw)
+        want = res[4](tau[i], phi)
+        assert np.max(np.abs(got["u"][i][:, :, 0] - want)) <= 1e-12 * max(1.0, np.max(np.abs(want)))
+
+
+@pytest.mark.gpu
+def test_numerical_failure_is_reported_not_returned(amd):
+    """A phase function that is not positive definite after delta-M scaling (moments > 1) breaks the Cholesky
+    factorisation on the device: the C ABI returns RTD_ERR_NUMERIC and the host raises (the reference raises
+    LinAlgError / returns NaN, _solve_for_gen_and_part_sols.py:186, :226-231)."""
+    from pydisort_amd import _lib
+    from pydisort_amd._engine import Plan
+    from pydisort_amd._prepare import prepare_columns
+    C, Lr, NQ = 2, 3, 16
+    N = NQ // 2
+    Leg = np.tile(np.array([1.0] + [3.0] * NQ), (C, Lr, 1))   # impossible moments: Pm loses positive definiteness
+    prep = prepare_columns(np.tile([0.5, 1.0, 2.0], (C, 1)), np.full((C, Lr), 0.99), NQ, Leg, np.full(C, 0.6),
+                           np.full(C, np.pi), np.zeros(C), NQ, NQ, np.zeros((C, N, NQ)), np.zeros((C, N, NQ)),
+                           np.zeros((C, Lr)), np.zeros((C, Lr, 0)), np.zeros((C, 0, N, N)), np.zeros((C, 0, N)))
+    plan = Plan(prep)
+    plan.solve()
+    with pytest.raises(_lib.NumericalError):
+        plan.evaluate(np.tile([0.0, 1.0], (C, 1)), np.array([0.0]))
+    with pytest.raises(np.linalg.LinAlgError):   # the reference's exception type is a base class of ours
+        plan.evaluate(np.tile([0.0, 1.0], (C, 1)), np.array([0.0]))
+    plan.close()
+
+
+@pytest.mark.gpu
+def test_default_fourier_count_at_64_streams(amd):
+    """pydisort(NQuad=64) with its default NFourier = 64 (the evaluation kernel's largest LDS footprint, 64 KB + change)
+    against the oracle on a small atmosphere."""
+    from oracle import disort_oracle as O
+    k = np.arange(65)
+    kw = dict(tau_arr=np.array([0.4, 1.1]), omega_arr=np.array([0.9, 0.7]), NQuad=64,
+              Leg_coeffs_all=np.stack((0.7**k, 0.5**k)), mu0=0.55, I0=np.pi, phi0=0.3)
+    tau, phi = np.array([0.0, 0.4, 0.9, 1.1]), np.array([0.0, 1.0, 3.0])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got, ref = amd.pydisort(**kw), O.pydisort(**kw)
+    want = ref[4](tau, phi)
+    assert np.max(np.abs(got[4](tau, phi) - want)) < 1e-9 * np.max(np.abs(want))
+    assert np.allclose(got[1](tau), ref[1](tau), rtol=1e-9)
