@@ -113,7 +113,7 @@ struct rtd_plan {
   int NP = 0;
   hipStream_t stream = nullptr;
   // d.C = all columns.  The per-column INPUT pointers of d cover them all; the intermediates of the solve (Y0, att, Ym, Am,
-  // kk, Ek, Bv, dq, zneg, coef, Fws, Lw, Qw) cover one window of Cw columns: launch_windows runs window after window.
+  // kk, Ek, Bv, dq, zneg, coef, Fws) cover one window of Cw columns: launch_windows runs window after window.
   RtdDev d{};
   int Cw = 0, nwin = 1;
   std::vector<void*> allocs;
@@ -370,12 +370,9 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   d.NBDRF = (int)NB; d.beam = dims->beam ? 1 : 0;
   d.flags = getenv("RTD_BC_FORCE_PIVOT") ? 1 : 0;
   d.m0 = 0; d.mstep = 1; d.mtot = (int)M;
-  const bool split32 = NP == 32 && getenv("RTD_EIG32_SPLIT") != nullptr;
-  d.Lw = nullptr;
-  d.Qw = nullptr;
   // window of columns whose intermediates are resident: bytes of intermediates per column
   const int64_t per_col = 8 * (M * P + (L + 1) + 2 * M * L * NP * NP + 2 * M * L * NP + 2 * M * L * Q2 + L * Ns * Q2 + L * NP +
-                               (split32 ? 2 * M * L * NP * NP : 0) + M * (L - 1) * Q2 * Q2);
+                               M * (L - 1) * Q2 * Q2);
   int64_t Cw = C;
   if (work_columns > 0) {
     Cw = std::min<int64_t>(C, work_columns);
@@ -417,7 +414,6 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
     A(d.Y0, Cw * M * P) A(d.att, Cw * (L + 1))
     A(d.Ym, Cw * M * L * NP * NP) A(d.Am, Cw * M * L * NP * NP) A(d.kk, Cw * M * L * NP) A(d.Bv, Cw * M * L * Q2)
     A(d.dq, Cw * L * Ns * Q2) A(d.zneg, Cw * L * NP) A(d.coef, Cw * M * L * Q2)
-    if (split32) { A(d.Lw, Cw * M * L * NP * NP) A(d.Qw, Cw * M * L * NP * NP) }  // three-kernel eigen path only (RTD_EIG32_SPLIT)
     A(d.Fws, Cw * M * (L - 1) * Q2 * Q2) A(d.Ek, Cw * M * L * NP)
     A(d.sweeps, 1) A(d.status, 1)
 #undef A

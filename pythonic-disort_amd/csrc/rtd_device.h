@@ -37,7 +37,6 @@ struct RtdDev {
   const double *bdrfq, *bdrfq0;  // [C][NBDRF][NP][NP], [C][NBDRF][NP]
   // intermediates
   double *Ym, *Am, *kk, *Bv, *dq, *zneg, *coef;
-  double *Lw, *Qw;    // eigen-stage workspace [C][M][L][NP][NP]: Cholesky factor L, symmetrised Qm
   double* Ek;         // [C][M][L][NP]  exp(-k dtau*_l): the Stamnes-Conklin scaling factors
   double* Fws;  // BC workspace: [C][M][L-1][4 NP^2]: Wp, Wq, S, rho_t, rho_b, s per interface (rtd_bc.hip)
   int* sweeps;        // [1] max Jacobi sweeps (diagnostic)
@@ -72,7 +71,7 @@ struct RtdNt {
 
 // launchers (one per translation unit)
 void rtd_launch_tables(const RtdDev& d, hipStream_t s, bool with_quad = true);  // with_quad: also the column-independent Y table
-void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part);  // 0 asm, 1 jacobi, 2 post
+void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part);  // the fused eigen kernel runs as part 1 (0, 2: empty timing slots)
 void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part);   // 0 iface, 1 sweep
 void rtd_launch_eval(const RtdDev& d, const RtdEval& e, hipStream_t s);
 void rtd_launch_nt_tables(const RtdDev& d, const RtdNt& nt, hipStream_t s);

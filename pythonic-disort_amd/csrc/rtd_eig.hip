@@ -5,8 +5,8 @@
 //   D+/D-, alpha, beta (:123-135), eig((alpha-beta)(alpha+beta)) (:179-183), G blocks (:186-198),
 //   beam particular solution (:143-152, :209-231), G^-1 [1/mu;-1/mu] (:203-205 + _assemble.py:124)
 //   and the isotropic-source particular solution coefficients (subroutines.py:746-862)
-//   -> rtd_eigen_kernel<NP> (one fused kernel; rtd_asm / rtd_jacobi / rtd_post_kernel are its earlier three-kernel form,
-//      kept for NQuad > 32 behind RTD_EIG32_SPLIT).
+//   -> rtd_eigen_kernel<NP, JV> (one fused kernel; JV = 2: Jacobi sweeps in the pair layout, JV = 1: one column per lane,
+//      kept behind RTD_EIG_V1 for A/B runs and as a regression test).
 //
 // Algorithm (own design, not the reference's LAPACK calls): with T = diag(sqrt(mu w)) the matrices
 // -(T(alpha+beta)T^-1) = Pm and -(T(alpha-beta)T^-1) = Qm are symmetric positive definite, so with
@@ -82,16 +82,26 @@ __device__ __forceinline__ double approx_rcp(double x) {
   return y * (2.0 - x * y);
 }
 
+#ifndef RTD_JAC_F32_ANGLE
+#define RTD_JAC_F32_ANGLE 1  /* rotation angle of the pair-layout sweeps from float arithmetic (see PairStep) */
+#endif
+#ifndef RTD_CHOL_FMAC_DPP
+#define RTD_CHOL_FMAC_DPP 1  /* Cholesky trailing updates as ONE v_fmac_f64_dpp (row_newbcast) per element, NP = 16 */
+#endif
+
 #ifndef RTD_EIGEN_WAVES
 #define RTD_EIGEN_WAVES 3  /* waves per SIMD the fused eigen kernel is compiled for (LDS: 10 KB per wave) */
 #endif
 
-// a sweep is the last one when every pair it met had cos^2(angle) <= RTD_JAC_TOL before its rotation (quadratic
-// convergence squares the residual angle during that sweep).  Measured on the benchmark columns against the CPU
-// oracle: 1e-16 .. 1e-11 give the same max |dI| (1.6e-11 abs, 4.1e-10 rel: other roundoff dominates), 1e-9 gives
-// 1.4e-8 rel, 1e-7 gives 5e-7; 1e-11 saves a third of a sweep on average.
+// A sweep is the last one when every pair it met had cos^2(angle) <= RTD_JAC_TOL before its rotation.  Quadratic
+// convergence leaves about that much (not its square) of non-orthogonality behind: eigenvalues are then good to
+// rounding, eigenvectors to ~RTD_JAC_TOL.  The eigenvector error matters where the beam source is nearly resonant with
+// an eigenvalue (1/mu0 ~ k: the particular solution's 1/(1/mu0^2 - k^2) and the homogeneous part cancel): on the 64
+// golden columns of cfg4 the worst column (mu0 = 0.912) is 1.8e-9 of the field scale off the reference at 1e-11 and
+// 1e-13, 7.3e-11 at 1e-14 and 1e-16 (all other columns 2-3e-11 throughout); kernel time 4.86 / 4.94 / 5.06 ms at
+// 1e-11 / 1e-14 / 1e-16.
 #ifndef RTD_JAC_TOL
-#define RTD_JAC_TOL 1e-11
+#define RTD_JAC_TOL 1e-14
 #endif
 
 // One parallel step of the one-sided (Hestenes) Jacobi iteration on the columns of W (H = W W^T at the
@@ -213,18 +223,43 @@ __device__ __forceinline__ double bcast_lane_lds(double v) {
   return __hiloint2double(hi, lo);
 }
 
+template <int NP, int K, int I>
+struct CholRowDpp {  // col[i] -= bcast_K(col[i]) * f for i = I .. NP - 1, one v_fmac_f64_dpp each
+  static __device__ __forceinline__ void run(double (&col)[NP], const double f) {
+    // The compiler's hazard recogniser does not see a VALU write inside inline asm, and the next step broadcasts
+    // col[K + 1] (its pivot) with a DPP move of its own: the two wait states a DPP read needs after a VALU write of the
+    // same VGPR are spent here, behind the rows that DPP reads next (the first and the last of the step).
+    if constexpr (I == K + 1 || I == NP - 1)
+      asm("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(col[I]) : "v"(f), "n"(K));
+    else
+      asm("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(col[I]) : "v"(f), "n"(K));
+    CholRowDpp<NP, K, I + 1>::run(col, f);
+  }
+};
+template <int NP, int K>
+struct CholRowDpp<NP, K, NP> {
+  static __device__ __forceinline__ void run(double (&)[NP], const double) {}
+};
+
 template <int NP, int K>
 struct CholStep {
   static __device__ __forceinline__ void run(double (&col)[NP], double& diag, const int j) {
     const double akk = bcast_lane<NP, K>(col[K]);
     const double f = (j > K) ? col[K] * fast_rcp(akk) : 0.0;
     diag = (j == K) ? akk : diag;
+    if constexpr (RTD_CHOL_FMAC_DPP && NP == 16) {
+      // col[i] -= bcast_K(col[i]) * f in one instruction: the DP-ALU DPP form exists for row_newbcast only (the DPP
+      // source is the accumulator itself).  A VALU write of a VGPR needs two wait states before a DPP read of it: the
+      // elements were last written by step K - 1's updates, at least NP - K instructions back; `f` is not a DPP operand.
+      CholRowDpp<NP, K, K + 1>::run(col, f);
+    } else {
 #pragma unroll
-    for (int i = K + 1; i < NP; ++i) {
-      if constexpr (RTD_CHOL_SWZ && NP <= 16)
-        col[i] = fma(-bcast_lane_lds<NP, K>(col[i]), f, col[i]);
-      else
-        col[i] = fma(-bcast_lane<NP, K>(col[i]), f, col[i]);
+      for (int i = K + 1; i < NP; ++i) {
+        if constexpr (RTD_CHOL_SWZ && NP <= 16)
+          col[i] = fma(-bcast_lane_lds<NP, K>(col[i]), f, col[i]);
+        else
+          col[i] = fma(-bcast_lane<NP, K>(col[i]), f, col[i]);
+      }
     }
     CholStep<NP, K + 1>::run(col, diag, j);
   }
@@ -270,326 +305,128 @@ __device__ __forceinline__ ProbId locate(const RtdDev& d, const int tx = threadI
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stage 1: assemble Pm, Qm (symmetrised alpha+-beta), Cholesky Pm = L L^T, Qm = R R^T, F = L^T R (H = F F^T).
-// Workspace written: Lw [prob][NP][NP] (row-major L), Qw [prob][NP][NP] (Qm),
-//                    F (aliases Ym) [prob][i][j].
+// Jacobi sweeps in the "pair" layout (the default): the NP lanes of a problem are NP/2 pair slots x 2 halves; lane
+// (p, u) holds the elements [u NP/2, (u + 1) NP/2) of BOTH columns of the pair in slot p.  Against the column-per-lane
+// form (JacobiStep): the dot product of a pair is NP/2 FMAs and one cross-lane add (not NP FMAs after NP column moves),
+// and after the rotation only ONE of the two columns moves on, as a half column: NP/2 doubles per lane (not NP) to
+// lane ^ mask with mask in {1, 2, 3, 7, 8, 15} -- a single DPP move per dword.  Per step a wavefront issues
+// ~NP/2 + 25 + 2 NP FP64 instructions and NP + 6 moves instead of NP + 34 + 2 NP and 2 NP + 2.
+//
+// Ordering: a butterfly on the NP/2 pair slots.  Level g (g = NP/2, NP/4, ..., 1) pairs the kept column X of a slot
+// with the g columns Y that circulate inside its group of g slots (g steps, Gray-code walk with the masks above); at
+// the end of a level the slots of the upper half of each group hand on their X instead of their Y, which splits the
+// group into two independent halves.  Which of the two columns a slot hands on is folded into the rotation itself
+// (the lanes write the rotated pair into (X, Y) or into (Y, X): four coefficient selects, no column selects).  Every one
+// of the NP (NP - 1) / 2 pairs meets exactly once per sweep whatever the arrangement the sweep starts from, so sweeps
+// simply follow each other (tools/jacobi_schedule.py replays the schedule and checks this).  The columns wander; each
+// carries the index it started with, and the lanes put them back in that order after the last sweep (the
+// boundary-condition kernel's speculative diagonal pivoting relies on eigen-columns that stay next to their diagonal).
 // ------------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_asm_kernel(RtdDev d) {
-  constexpr int GPW = 64 / NP;
-  constexpr int LD = NP + 1;
-  __shared__ double sL[GPW][NP * LD];
-  const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
-  const ProbId id = locate<NP>(d);
-  const int P = d.P, m = id.m;
-  double* L_ = sL[grp];
-  const double* wl = d.wleg + ((long)id.c * d.L + id.l) * P;
-  const double om = d.omega[(long)id.c * d.L + id.l];
-  const double* Ym = d.Y + (long)m * P * NP;
+struct JSched {  // after the rotation of step s: slots with (p & sw[s]) hand on X instead of Y; the move is slot ^ mk[s]
+  int sw[NP - 1], mk[NP - 1];
+  constexpr JSched() : sw{}, mk{} {
+    constexpr int LPP = NP / 2;
+    int s = 0;
+    for (int g = LPP; g >= 1; g >>= 1) {
+      for (int b = 0; b < g; ++b, ++s) {
+        if (b < g - 1) {  // walk inside the level: Gray code with 4 replaced by 7 (row_half_mirror)
+          const int low = (b + 1) & -(b + 1);
+          sw[s] = 0;
+          mk[s] = low == 4 ? 7 : low;
+        } else if (g > 1) {  // split the groups of g slots into halves
+          const int h = g >> 1;
+          sw[s] = h;
+          mk[s] = h == 4 ? 7 : h;
+        } else {  // into the next sweep
+          sw[s] = 0;
+          mk[s] = LPP > 1 ? LPP - 1 : 0;
+        }
+      }
+    }
+  }
+};
 
-  // D+/D- split by parity of (l - m): Ae = 2 sum_even c_l Y_l Y_l^T, Ao likewise (:123-125)
-  double acc_e[NP], acc_o[NP];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) acc_e[i] = acc_o[i] = 0.0;
-  double cmax = 0.0;
-  for (int ell = id.mg; ell < P; ell += 2) {
-    {
-      const double cl = 0.5 * om * wl[ell];
-      cmax = fmax(cmax, fabs(cl));
-      const double* Yr = Ym + (long)ell * NP;
-      const double coef = 2.0 * cl * Yr[j];
-#pragma unroll
-      for (int i = 0; i < NP; ++i) acc_e[i] += coef * Yr[i];
-    }
-    if (ell + 1 < P) {
-      const double cl = 0.5 * om * wl[ell + 1];
-      cmax = fmax(cmax, fabs(cl));
-      const double* Yr = Ym + (long)(ell + 1) * NP;
-      const double coef = 2.0 * cl * Yr[j];
-#pragma unroll
-      for (int i = 0; i < NP; ++i) acc_o[i] += coef * Yr[i];
-    }
-  }
-  // "shortcut" of the reference when multiple scattering is insignificant (:119, :162-168): the layer
-  // is treated as non-scattering; the general path then gives G = [[0,D],[D,0]], k = 1/mu, B = 0.
-  if (!(cmax > 1e-8)) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) acc_e[i] = acc_o[i] = 0.0;
-  }
-  const double invmu_j = d.invmu[j], S_j = d.S[j];
-  double pcol[NP], qcol[NP];
-  double* Qw = d.Qw + id.pid * NP * NP;
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const double Si = d.S[i];
-    pcol[i] = (i == j ? invmu_j : 0.0) - Si * acc_e[i] * S_j;  // Pm = M^-1 - S Ae S
-    qcol[i] = (i == j ? invmu_j : 0.0) - Si * acc_o[i] * S_j;  // Qm = M^-1 - S Ao S
-    if (id.valid) Qw[i * NP + j] = qcol[i];
-  }
-  cholesky_columns<NP>(pcol, j);  // Pm = L L^T
-  cholesky_columns<NP>(qcol, j);  // Qm = R R^T
-  double* Lw = d.Lw + id.pid * NP * NP;
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    L_[i * LD + j] = pcol[i];
-    if (id.valid) Lw[i * NP + j] = pcol[i];
-  }
-  __syncthreads();
-  // H = L^T Qm L = F F^T with F = L^T R;  lane j: F[i][j] = sum_r L[r][i] R[r][j]
-  double* Fw = d.Ym + id.pid * NP * NP;
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    double a = 0.0;
-#pragma unroll
-    for (int r = i; r < NP; ++r) a += L_[r * LD + i] * qcol[r];
-    if (id.valid) Fw[i * NP + j] = a;
-  }
+template <int MASK>
+__device__ __forceinline__ int xor_lane_i(int v) {
+  constexpr int ctrl = dpp_xor_ctrl(MASK);
+  if constexpr (ctrl >= 0) return __builtin_amdgcn_update_dpp(0, v, ctrl, 0xF, 0xF, true);
+  else return __builtin_amdgcn_ds_swizzle(v, (MASK << 10) | 0x1F);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Stage 2: one-sided cyclic Jacobi (XOR round-robin ordering) on the columns of F; k^2 -> kk (fixed up in
-// stage 3), k_j z_j -> Zw (aliases Am) [prob][i][j].  Registers and cross-lane swizzles only.
-// ------------------------------------------------------------------------------------------------
-#ifndef RTD_JAC_WAVES
-#define RTD_JAC_WAVES 2
+template <int NP, int S>
+struct PairStep {
+  static constexpr int H = NP / 2;
+  static __device__ __forceinline__ void run(double (&xh)[H], double (&yh)[H], double& ax, double& ay, int& ix, int& iy,
+                                             const int p, int& notconv) {
+    constexpr JSched<NP> sched{};
+    constexpr int SW = sched.sw[S], MK = sched.mk[S];
+    double g0 = 0.0, g1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < H; i += 2) {
+      g0 = fma(xh[i], yh[i], g0);
+      if (i + 1 < H) g1 = fma(xh[i + 1], yh[i + 1], g1);
+    }
+    const double gp = g0 + g1;
+    const double gamma = gp + xor_lane<H>(gp);  // both halves of the pair: the same bits in both lanes
+    // tan(2 theta) = 2 gamma / (|y|^2 - |x|^2);  t = tan(theta) without cancellation.  Branch-free: the tiny term keeps
+    // gamma = 0 (decoupled or already orthogonal columns, also with equal norms) at t = 0, c = 1 without a 0/0.
+    const double delta = ay - ax;
+    const double g2 = 2.0 * gamma;
+#if RTD_JAC_F32_ANGLE
+    // The angle only steers the iteration: a t that is 1e-7 off leaves 1e-7 of the pair's inner product behind, far below
+    // what the sweep test asks for (the test is made BEFORE the rotation).  So t comes from float arithmetic with the
+    // hardware's rsq / rcp and no Newton step (eigenvalues here lie between 1e-3 and 1e5: no float range issue; a
+    // product that underflows belongs to a pair that has converged).  c and s below are double, from that t: the
+    // rotation itself stays orthogonal to double accuracy.
+    const float df = (float)delta, gf = (float)g2;
+    const float r2f = fmaf(df, df, fmaf(gf, gf, 1e-36f));
+    const float rhof = r2f * __builtin_amdgcn_rsqf(r2f);
+    const float denf = df + copysignf(rhof, df);
+    const double tt = (double)(gf * __builtin_amdgcn_rcpf(denf));
+#else
+    const double r2 = fma(delta, delta, fma(g2, g2, 1e-280));
+    const double rho = r2 * approx_rsqrt(r2);
+    const double den = delta + copysign(rho, delta);
+    const double tt = g2 * approx_rcp(den);
 #endif
+    // c from ONE Newton step (4e-15): the error scales BOTH columns of the pair by the same 1 + eps, so orthogonality and
+    // the directions z are untouched; only the norms k drift, by ~50 rotations x 4e-15 (parity unchanged)
+    const double c = approx_rsqrt(fma(tt, tt, 1.0));
+    const double sn = tt * c;
+    notconv |= (gamma * gamma > RTD_JAC_TOL * ax * ay) ? 1 : 0;
+    const double nax = fma(-tt, gamma, ax), nay = fma(tt, gamma, ay);  // |c x - s y|^2, |s x + c y|^2
+    // (x, y) <- (c x - s y, s x + c y), written the other way round in the slots that hand on their x
+    double cxx = c, cxy = -sn, cyx = sn, cyy = c;
+    double oax = nax, oay = nay;
+    if constexpr (SW != 0) {
+      const bool swp = (p & SW) != 0;
+      cxx = swp ? sn : c;
+      cxy = swp ? c : -sn;
+      cyx = swp ? c : sn;
+      cyy = swp ? -sn : c;
+      oax = swp ? nay : nax;
+      oay = swp ? nax : nay;
+      const int t = swp ? iy : ix;
+      iy = swp ? ix : iy;
+      ix = t;
+    }
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      const double xi = xh[i], yi = yh[i];
+      xh[i] = fma(cxy, yi, cxx * xi);
+      yh[i] = xor_lane<MK>(fma(cyy, yi, cyx * xi));
+    }
+    ax = oax;
+    ay = xor_lane<MK>(oay);
+    iy = xor_lane_i<MK>(iy);
+    PairStep<NP, S + 1>::run(xh, yh, ax, ay, ix, iy, p, notconv);
+  }
+};
 template <int NP>
-__global__ __launch_bounds__(64, (NP <= 8 ? 4 : (NP == 16 ? RTD_JAC_WAVES : 1))) void rtd_jacobi_kernel(RtdDev d) {
-  const int j = threadIdx.x % NP;
-  const ProbId id = locate<NP>(d);
-  const double* Fw = d.Ym + id.pid * NP * NP;
-  double w[NP];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) w[i] = Fw[i * NP + j];
-  int nsweep = 0;
-  for (int sweep = 0; sweep < 40; ++sweep) {
-    int notconv = 0;
-    double alpha = 0.0;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) alpha += w[i] * w[i];
-    JacobiStep<NP, 1>::run(w, alpha, j, notconv);
-    ++nsweep;
-    // every pair met during this sweep was already orthogonal to ~1e-10: the sweep just done finished the job
-    if (!__any(notconv)) break;
-  }
-  if (threadIdx.x == 0 && nsweep > *(volatile int*)d.sweeps) atomicMax(d.sweeps, nsweep);
-  if (id.valid) {
-    double n2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) n2 += w[i] * w[i];
-    d.kk[id.pid * NP + j] = n2;  // k^2 (the post kernel takes the root and normalises the column)
-    double* Zw = d.Am + id.pid * NP * NP;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) Zw[i * NP + j] = w[i];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Stage 3: eigenvector blocks Gp/Gm, k, isotropic-source coefficients, beam particular solution.
-// ------------------------------------------------------------------------------------------------
-template <int NP>
-__global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev d) {
-  constexpr int GPW = 64 / NP;
-  constexpr int LD = NP + 1;
-  __shared__ double sL[GPW][NP * LD];
-  __shared__ double sQ[GPW][NP * LD];
-  __shared__ double sR[GPW][NP * LD];  // scratch for cross-lane reductions (Qm must survive until the beam stage)
-  __shared__ double sV[GPW][3][NP];
-  const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
-  const ProbId id = locate<NP>(d);
-  const int P = d.P, m = id.m, c = id.c, l = id.l;
-  const bool valid = id.valid;
-  double* L_ = sL[grp];
-  double* Q_ = sQ[grp];
-  double* R_ = sR[grp];
-  double* v0 = sV[grp][0];
-  double* v1 = sV[grp][1];
-  double* v2 = sV[grp][2];
-  const long base = id.pid;
-  double zc[NP];
-  {
-    const double* Lw = d.Lw + base * NP * NP;
-    const double* Qw = d.Qw + base * NP * NP;
-    const double* Zw = d.Am + base * NP * NP;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      L_[i * LD + j] = Lw[i * NP + j];
-      Q_[i * LD + j] = Qw[i * NP + j];
-      zc[i] = Zw[i * NP + j];
-    }
-  }
-  const double k2 = d.kk[base * NP + j];
-  const double kj = sqrt(k2);
-  {
-    const double rk0 = 1.0 / kj;  // columns arrive as k_j z_j
-#pragma unroll
-    for (int i = 0; i < NP; ++i) zc[i] *= rk0;
-  }
-  const double invmu_j = d.invmu[j], T_j = d.T[j];
-  __syncthreads();
-
-  // eigenvector blocks (:190-198): V = T^-1 L^-T Z, U = (alpha+beta) V / k = -T^-1 L Z / k; stored as
-  // Y = L^-T Z and A = L Z, from which Gp = (Y - A/k)/T, Gm = (Y + A/k)/T, V^-1 = A^T T, U^-1 = -k Y^T T
-  double ya[NP], aa[NP];
-#pragma unroll
-  for (int i = NP - 1; i >= 0; --i) {
-    double a = zc[i];
-#pragma unroll
-    for (int r = i + 1; r < NP; ++r) a -= L_[r * LD + i] * ya[r];
-    ya[i] = a / L_[i * LD + i];
-    RTD_FENCE();
-  }
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    double a = 0.0;
-#pragma unroll
-    for (int r = 0; r <= i; ++r) a += L_[i * LD + r] * zc[r];
-    aa[i] = a;
-    RTD_FENCE();
-  }
-  if (valid) {
-    double* Ym = d.Ym + base * NP * NP;
-    double* Am = d.Am + base * NP * NP;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      Ym[i * NP + j] = ya[i];
-      Am[i * NP + j] = aa[i];
-    }
-    d.kk[base * NP + j] = kj;
-    const double* ts0 = d.taus0 + (long)c * (d.L + 1);
-    d.Ek[base * NP + j] = exp(-kj * (ts0[l + 1] - ts0[l]));
-  }
-
-  // isotropic (thermal) source, Fourier mode 0 only (subroutines.py:746-862, _assemble.py:124).
-  // Every group runs the barriers below; only groups with m == 0 store.
-  if (d.Ns > 0) {
-    const bool act = (id.mg == 0);
-    // q = L^-1 (T / mu) by forward substitution distributed over the lanes
-    double cur = T_j * invmu_j, q_j = 0.0;
-    static_for<0, NP>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      const double qi = bcast_lane<NP, i>(cur) / L_[i * LD + i];
-      q_j = (j == i) ? qi : q_j;
-      cur -= (j > i) ? L_[j * LD + i] * qi : 0.0;
-    });
-    v0[j] = q_j;
-    __syncthreads();
-    double zn = 0.0;  // zneg_j = -k_j/2 sum_i Z[i][j] q[i]
-#pragma unroll
-    for (int i = 0; i < NP; ++i) zn += zc[i] * v0[i];
-    zn *= -0.5 * kj;
-    if (valid && act) d.zneg[((long)c * d.L + l) * NP + j] = zn;
-    const double* sp = d.spoly + ((long)c * d.L + l) * d.Ns;
-    const double rk = 1.0 / kj;
-    for (int q = 0; q < d.Ns; ++q) {
-      // b_q(K) = sum_{jj>=q} jj!/q! a_jj K^-(jj-q+1), K = -k (first N eigen-columns) and +k
-      double bneg = 0.0, bpos = 0.0, ratio = 1.0, pw_pos = rk, pw_neg = -rk;
-      for (int jj = q; jj < d.Ns; ++jj) {
-        bpos += ratio * sp[jj] * pw_pos;
-        bneg += ratio * sp[jj] * pw_neg;
-        ratio *= (double)(jj + 1);
-        pw_pos *= rk;
-        pw_neg *= -rk;
-      }
-      const double a = zn * bneg, b = -zn * bpos;
-      // up-streams: Gp a + Gm b ; down-streams: Gm a + Gp b  (sum over eigen-index = lanes), with
-      // Gp = (Y - A/k)/T, Gm = (Y + A/k)/T:  up = [Y (a+b) - A (a-b)/k]/T, down = [Y (a+b) + A (a-b)/k]/T
-      const double sab = a + b, dab = (a - b) * rk;
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < NP; ++i) R_[i * LD + j] = (ya[i] * sab - aa[i] * dab) / d.T[i];
-      __syncthreads();
-      double up = 0.0;
-#pragma unroll
-      for (int r = 0; r < NP; ++r) up += R_[j * LD + r];
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < NP; ++i) R_[i * LD + j] = (ya[i] * sab + aa[i] * dab) / d.T[i];
-      __syncthreads();
-      double dn = 0.0;
-#pragma unroll
-      for (int r = 0; r < NP; ++r) dn += R_[j * LD + r];
-      if (valid && act) {
-        double* dq = d.dq + (((long)c * d.L + l) * d.Ns + q) * 2 * NP;
-        dq[j] = up;
-        dq[NP + j] = dn;
-      }
-    }
-    __syncthreads();
-  }
-
-  // beam particular solution (:143-152, :226-231) through the spectral decomposition:
-  //  s = B+ + B-, dd = B+ - B- ;  (I/mu0^2 - Qm Pm) T s = T(x+ + x-)/mu0 - Qm T (x+ - x-)
-  //  T dd = mu0 [ T (x+ - x-) - Pm T s ],  Qm Pm = L^-T Z k^2 Z^T L^T
-  if (d.beam) {
-    const double mu0 = d.mu0[c];
-    const double om = d.omega[(long)c * d.L + l];
-    const double* wl = d.wleg + ((long)c * d.L + l) * P;
-    const double* Ym = d.Y + (long)m * P * NP;
-    const double fac = d.I0[c] / (4.0 * M_PI) * (id.mg == 0 ? 1.0 : 2.0) * om;
-    const double* Y0 = d.Y0 + ((long)c * d.M + m) * P;
-    double xe = 0.0, xo = 0.0, cmax = 0.0;  // X^e_j, X^o_j of this lane's stream
-    for (int ell = id.mg; ell < P; ell += 2) {
-      cmax = fmax(cmax, fabs(0.5 * om * wl[ell]));
-      xe += fac * wl[ell] * Y0[ell] * Ym[(long)ell * NP + j];
-      if (ell + 1 < P) {
-        cmax = fmax(cmax, fabs(0.5 * om * wl[ell + 1]));
-        xo += fac * wl[ell + 1] * Y0[ell + 1] * Ym[(long)(ell + 1) * NP + j];
-      }
-    }
-    if (!(cmax > 1e-8)) xe = xo = 0.0;
-    const double txd = 2.0 * T_j * xe * invmu_j;  // T (x+ - x-)
-    v0[j] = txd;
-    __syncthreads();
-    double qv = 0.0;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) qv += Q_[i * LD + j] * v0[i];
-    const double rhat = 2.0 * T_j * xo * invmu_j / mu0 - qv;
-    v1[j] = rhat;
-    __syncthreads();
-    double g = 0.0;  // g = L^T rhat
-#pragma unroll
-    for (int r = 0; r < NP; ++r) g += L_[r * LD + j] * v1[r];
-    v2[j] = g;
-    __syncthreads();
-    double h = 0.0;  // h = Z^T g / (1/mu0^2 - k^2)
-#pragma unroll
-    for (int i = 0; i < NP; ++i) h += zc[i] * v2[i];
-    h /= (1.0 / (mu0 * mu0) - k2);
-    // e = Z h (cross-lane sum through LDS)
-#pragma unroll
-    for (int i = 0; i < NP; ++i) R_[i * LD + j] = zc[i] * h;
-    __syncthreads();
-    double e = 0.0;
-#pragma unroll
-    for (int r = 0; r < NP; ++r) e += R_[j * LD + r];
-    // shat = L^-T e by back substitution distributed over the lanes
-    double sh = 0.0;
-    static_for<0, NP>([&](auto ic) {
-      constexpr int i = NP - 1 - decltype(ic)::value;
-      const double si = bcast_lane<NP, i>(e) / L_[i * LD + i];
-      sh = (j == i) ? si : sh;
-      e -= (j < i) ? L_[i * LD + j] * si : 0.0;
-    });
-    v1[j] = sh;
-    __syncthreads();
-    double tv = 0.0;  // t = L^T shat
-#pragma unroll
-    for (int r = 0; r < NP; ++r) tv += L_[r * LD + j] * v1[r];
-    v2[j] = tv;
-    __syncthreads();
-    double ps = 0.0;  // Pm shat = L t
-#pragma unroll
-    for (int r = 0; r < NP; ++r) ps += L_[j * LD + r] * v2[r];
-    const double rT = 1.0 / T_j;
-    const double s_j = sh * rT;
-    const double d_j = mu0 * (txd - ps) * rT;
-    if (valid) {
-      d.Bv[base * 2 * NP + j] = 0.5 * (s_j + d_j);
-      d.Bv[base * 2 * NP + NP + j] = 0.5 * (s_j - d_j);
-    }
-  }
-}
+struct PairStep<NP, NP - 1> {  // the last step of a sweep is step NP - 2
+  static __device__ __forceinline__ void run(double (&)[NP / 2], double (&)[NP / 2], double&, double&, int&, int&, const int, int&) {}
+};
 
 // ------------------------------------------------------------------------------------------------
 // Fused eigen stage: assembly, Cholesky factors, one-sided Jacobi and the eigenvector /
@@ -597,7 +434,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? 3 : 1)) void rtd_post_kernel(RtdDev
 // compared with the three-kernel pipeline this removes 10.6 KB of HBM traffic per problem (a third of the path's
 // total) and the Lw / Qw workspaces.
 // ------------------------------------------------------------------------------------------------
-template <int NP>
+template <int NP, int JV>  // JV: 2 = Jacobi sweeps in the pair layout (default), 1 = one column per lane (RTD_EIG_V1)
 __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : 1)) void rtd_eigen_kernel(RtdDev d) {
   constexpr int GPW = 64 / NP;
   constexpr int LD = NP + 1;
@@ -668,17 +505,62 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : 1)) void rtd_eige
   // one-sided Jacobi on the columns of F
   int nsweep = 0;
   bool converged = false;
-  for (int sweep = 0; sweep < 40; ++sweep) {
-    int notconv = 0;
-    double alpha = 0.0;
+  if constexpr (JV == 1) {
+    for (int sweep = 0; sweep < 40; ++sweep) {
+      int notconv = 0;
+      double alpha = 0.0;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) alpha += w[i] * w[i];
-    JacobiStep<NP, 1>::run(w, alpha, j, notconv);
-    ++nsweep;
-    if (!__any(notconv)) {
-      converged = true;
-      break;
+      for (int i = 0; i < NP; ++i) alpha += w[i] * w[i];
+      JacobiStep<NP, 1>::run(w, alpha, j, notconv);
+      ++nsweep;
+      if (!__any(notconv)) {
+        converged = true;
+        break;
+      }
     }
+  } else {
+    constexpr int H = NP / 2;
+    const int u = j / H, p = j % H;  // lane (p, u): half u of the two columns of pair slot p
+    double xh[H], yh[H];
+#pragma unroll
+    for (int i = 0; i < H; ++i) {  // columns p and p + H start in slot p: trade the halves with lane ^ H
+      const double recv = xor_lane<H>(u ? w[i] : w[H + i]);
+      xh[i] = u ? recv : w[i];
+      yh[i] = u ? w[H + i] : recv;
+    }
+    int ix = p, iy = p + H;  // the columns' starting indices travel with them
+    for (int sweep = 0; sweep < 40; ++sweep) {
+      int notconv = 0;
+      double ax = 0.0, ay = 0.0;
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
+        ax = fma(xh[i], xh[i], ax);
+        ay = fma(yh[i], yh[i], ay);
+      }
+      ax += xor_lane<H>(ax);
+      ay += xor_lane<H>(ay);
+      PairStep<NP, 0>::run(xh, yh, ax, ay, ix, iy, p, notconv);
+      ++nsweep;
+      if (!__any(notconv)) {
+        converged = true;
+        break;
+      }
+    }
+    // back to one column per lane: lane (p, 0) takes column X of its slot, lane (p, 1) column Y ...
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      const double recv = xor_lane<H>(u ? xh[i] : yh[i]);
+      w[i] = u ? recv : xh[i];
+      w[H + i] = u ? yh[i] : recv;
+    }
+    // ... and every column returns to the lane it started in (its index j): the source lane of lane j through LDS
+    int* where = reinterpret_cast<int*>(sV[grp][0]);
+    where[u ? iy : ix] = j;
+    __syncthreads();
+    const int src = where[j];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) w[i] = __shfl(w[i], src, NP);
+    __syncthreads();
   }
   if (threadIdx.x == 0 && nsweep > *(volatile int*)d.sweeps) atomicMax(d.sweeps, nsweep);
   if (!converged && threadIdx.x == 0) atomicOr(d.status, RTD_ST_JACOBI);  // NaN input (failed Cholesky) also ends here
@@ -927,29 +809,23 @@ void rtd_launch_tables(const RtdDev& d, hipStream_t s, bool with_quad) {
 }
 
 void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part) {
-  // part 0: assembly + Cholesky + F, 1: Jacobi, 2: eigenvector blocks / particular solutions
+  // One fused kernel (launched as part 1; parts 0 and 2 are the empty timing slots of the earlier three-kernel form).
+  if (part != 1) return;
   const int gpw = 64 / d.NP;
   const dim3 grid((unsigned)((long)d.C * d.M * ((d.L + gpw - 1) / gpw)));
-  // One fused kernel (launched as part 1).  RTD_EIG32_SPLIT=1 selects, for NP = 32, the earlier three-kernel pipeline
-  // that exchanges F, L, Qm, k Z through the Ym / Am / Lw / Qw buffers (A/B: 25.6 ms against 17.1 ms fused on cfg5).
-#define RTD_EIG_FUSED(NPV)                                                                      \
-  case NPV:                                                                                     \
-    if (part == 1) hipLaunchKernelGGL(rtd_eigen_kernel<NPV>, grid, dim3(64), 0, s, d);          \
+  // RTD_EIG_V1=1: the one-column-per-lane form of the sweeps (A/B runs and a regression test)
+  static const bool v1 = getenv("RTD_EIG_V1") != nullptr;
+#define RTD_EIG_CASE(NPV)                                                                        \
+  case NPV:                                                                                      \
+    if (v1) hipLaunchKernelGGL((rtd_eigen_kernel<NPV, 1>), grid, dim3(64), 0, s, d);             \
+    else hipLaunchKernelGGL((rtd_eigen_kernel<NPV, 2>), grid, dim3(64), 0, s, d);                \
     break;
   switch (d.NP) {
-    RTD_EIG_FUSED(4)
-    RTD_EIG_FUSED(8)
-    RTD_EIG_FUSED(16)
-    case 32:
-      if (d.Lw == nullptr) {  // default: fused (the plan did not allocate the exchange buffers)
-        if (part == 1) hipLaunchKernelGGL(rtd_eigen_kernel<32>, grid, dim3(64), 0, s, d);
-        break;
-      }
-      if (part == 0) hipLaunchKernelGGL(rtd_asm_kernel<32>, grid, dim3(64), 0, s, d);
-      if (part == 1) hipLaunchKernelGGL(rtd_jacobi_kernel<32>, grid, dim3(64), 0, s, d);
-      if (part == 2) hipLaunchKernelGGL(rtd_post_kernel<32>, grid, dim3(64), 0, s, d);
-      break;
+    RTD_EIG_CASE(4)
+    RTD_EIG_CASE(8)
+    RTD_EIG_CASE(16)
+    RTD_EIG_CASE(32)
     default: break;
   }
-#undef RTD_EIG_FUSED
+#undef RTD_EIG_CASE
 }

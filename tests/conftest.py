@@ -18,3 +18,27 @@ def pytest_sessionstart(session):
     if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
         import subprocess
         subprocess.run([sys.executable, os.path.join(ROOT, "pythonic-disort_amd", "build.py")], check=True)
+
+
+# ---- parity report: every GPU parity test records (scale-relative, pointwise-relative) errors; the session writes them to
+#      gpurun_out/parity_report.json (copied to profiles/ as the measured parity evidence of the round)
+PARITY = {}
+
+
+def record_parity(name, scale_err, pointwise_err, tol_scale=None, tol_pointwise=None):
+    PARITY[name] = dict(scale_rel=float(scale_err), pointwise_rel=float(pointwise_err), tol_scale_rel=tol_scale,
+                        tol_pointwise_rel=tol_pointwise)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not PARITY:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.json"), "w") as f:
+            json.dump(dict(metric="scale_rel = max|d| / max|ref| over a call; pointwise_rel = max |d| / |ref| over points "
+                                  "with |ref| > 1e-8 max|ref| (SURVEY 8(d))", cases=PARITY), f, indent=1, sort_keys=True)
+    except OSError:
+        pass

@@ -70,10 +70,41 @@ def run_single(name, kw, tau_pts):
     print(name, "done", flush=True)
 
 
+def cloud_c1_cases():
+    """BASELINE.json configs[1] as literally worded -- Test Problem 5 (Cloud C.1, one layer of optical depth 64, beam
+    source) at 32 streams, delta-M with f = the 32nd moment, Nakajima-Tanaka corrections on -- for both single-scattering
+    albedos of the reference's 5a / 5b.  The 300 Cloud C.1 moments are data: they are read from the keyword arguments
+    captured in tests/golden/ref/5a.npz (make_reference_goldens.py) and stored in the fixture next to the outputs."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import goldens
+    leg = np.atleast_2d(goldens.load("5a")[0]["kwargs"]["Leg_coeffs_all"])
+    cases = {}
+    for tag, omega in (("a", 1 - 1e-6), ("b", 0.9)):
+        kw = dict(tau_arr=np.array([64.0]), omega_arr=np.array([omega]), NQuad=32, Leg_coeffs_all=leg, mu0=1.0, I0=np.pi,
+                  phi0=np.pi, f_arr=np.array([leg[0, 32]]), NT_cor=True)
+        cases["cfg2_q32_cloud_" + tag] = (kw, np.array([0.0, 3.2, 6.4, 12.8, 32.0, 48.0, 64.0]))
+    return cases
+
+
+def run_cloud(name, kw, tau_pts):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mu_arr, Fp, Fm, u0, u = PythonicDISORT.pydisort(**{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+    out = {"tau_pts": tau_pts, "phi": PHI, "u": u(tau_pts, PHI), "u0": u0(tau_pts), "flux_up": Fp(tau_pts),
+           "Leg_coeffs_all": kw["Leg_coeffs_all"], "omega": kw["omega_arr"]}
+    out["flux_down_diffuse"], out["flux_down_direct"] = Fm(tau_pts)
+    np.savez_compressed(os.path.join(HERE, "synth", name + ".npz"), **out)
+    print(name, "done", flush=True)
+
+
 if __name__ == "__main__":
+    os.makedirs(os.path.join(HERE, "synth"), exist_ok=True)
     for name, (kw, tau_pts) in synthetic.literal_cases().items():
         run_single(name, kw, tau_pts)
-    run("cfg4", synthetic.cfg4_columns(16), 16)
+    for name, (kw, tau_pts) in cloud_c1_cases().items():
+        run_cloud(name, kw, tau_pts)
+    # column counts of SURVEY section 8(d): cfg4 64, cfg5 4
+    run("cfg4", synthetic.cfg4_columns(64), 64)
     run("cfg3_big", synthetic.cfg3_columns(4, big=True), 4)
     run("cfg3_small", synthetic.cfg3_columns(4, big=False), 4)
-    run("cfg5", synthetic.cfg5_columns(2), 2)
+    run("cfg5", synthetic.cfg5_columns(4), 4)

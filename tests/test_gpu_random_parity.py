@@ -145,10 +145,18 @@ def test_random_many_stream_case_matches_oracle(seed):
     scale = max(float(np.max(np.abs(want))), 1e-300)
     if not np.isfinite(scale) or np.max(np.abs(ref[1](tau))) > 1e8 * scale:
         pytest.skip("oracle result is not finite / ill-conditioned")
-    # Layers with omega = 1 - 1e-6 limit the ORACLE, not the HIP path: against a 40-digit solution the reference's
-    # algorithm in float64 is off by 6e-9 on such a mix while the HIP path is at 2e-14 (tools/hp_truth_m0.py,
-    # test_high_precision_truth_m0); random mixes reach 3e-7.  Everything else agrees to rounding.
+    # Layers with omega = 1 - 1e-6 limit the ORACLE, not the HIP path: against a 40-digit solution of a 20-layer,
+    # 32-stream atmosphere with four such layers the reference's algorithm in float64 is off by 6.4e-8 (Fourier mode 0;
+    # 1e-12 for the other modes) while the HIP path is below 1e-11 (tools/hp_truth_q32.py,
+    # test_high_precision_truth_32_streams); random mixes reach 3e-7.  So: the north star's 1e-6 for those, and what two
+    # float64 implementations reach (1e-9 of the field scale) for everything else.  Both metrics of SURVEY 8(d).
+    from conftest import record_parity
+    import goldens
     near_conservative = bool(np.any(kw["omega_arr"] > 1 - 1e-5))
-    tol = 1e-5 if near_conservative else 1e-9
-    assert np.max(np.abs(got[4](tau, phi) - want)) / scale < tol
+    tol = 1e-6 if near_conservative else 1e-9
+    a, b = goldens.max_rel_err(got[4](tau, phi), want)
+    record_parity("random32/%d" % seed, a, b, tol, 1e-6 if near_conservative else 1e-6)
+    assert a < tol
+    if not near_conservative:
+        assert b < 1e-6  # pointwise relative over |I| > 1e-8 max |I|
     assert np.allclose(got[1](tau), ref[1](tau), rtol=10 * tol, atol=tol * scale)

@@ -126,3 +126,20 @@ def test_oracle_on_synthetic_config_is_self_consistent():
     b = O.pydisort(use_banded_solver_NLayers=100, **kw)
     tau = np.linspace(0, kw["tau_arr"][-1], 7)
     assert np.allclose(a[4](tau, 0.3), b[4](tau, 0.3), rtol=1e-10)
+
+
+def test_pair_layout_jacobi_schedule_meets_every_pair_once():
+    """The butterfly ordering of the device's Jacobi sweeps (csrc/rtd_eig.hip: JSched), replayed on the host."""
+    import importlib.util
+    import random
+    spec = importlib.util.spec_from_file_location("jacobi_schedule", os.path.join(ROOT, "tools", "jacobi_schedule.py"))
+    js = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(js)
+    rng = random.Random(7)
+    for NP in (4, 8, 16, 32):
+        sw, mk = js.build(NP)
+        assert len(sw) == NP - 1 and set(mk) <= js.DPP_XOR_MASKS
+        js.replay(NP, 3)
+        perm = list(range(NP))
+        rng.shuffle(perm)
+        js.replay(NP, 3, (perm[: NP // 2], perm[NP // 2:]))

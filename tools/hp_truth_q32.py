@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""High-precision (mpmath, 40 digits) solution of ONE 32-stream, 20-layer atmosphere with near-conservative layers --
+the regime of the benchmark's fused boundary-condition kernel (speculative diagonal pivoting, growth threshold 64) -- for
+several Fourier modes, straight from the equations of SURVEY Appendix A:
+
+  * per layer the reference's eigenproblem (alpha - beta)(alpha + beta) V = V k^2 (_solve_for_gen_and_part_sols.py:
+    179-198) with mpmath's general eigensolver, G = [[V+U, V-U],[V-U, V+U]], U = (alpha + beta) V / k;
+  * the beam particular solution from the 2N x 2N system (A + I/mu0) B = X (:226-231);
+  * the reference's banded boundary-condition system with the Stamnes-Conklin scaling (_solve_for_coeffs.py:276-323),
+    solved by Gaussian elimination with partial pivoting inside the band, in 40-digit arithmetic.
+
+Nothing of the device's algorithm (symmetrisation, Cholesky, Jacobi, structured block elimination) is used.  The
+fixture tests/golden/hp_truth_q32.npz holds the inputs and u^m at the 21 layer interfaces for the modes MODES; tests
+compare the HIP path (ulast of a solve with NFourier = m + 1) and the float64 oracle against it: the oracle's distance
+to the truth is the error budget of every oracle-based tolerance in tests/.
+
+Usage (build container, ~15 minutes):  python3 tools/hp_truth_q32.py
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import mpmath as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT]
+from oracle import disort_oracle as O  # noqa: E402  (host-side preparation: delta-M scaling, quadrature)
+
+mp.mp.dps = 40
+MODES = (0, 1, 2, 9, 31)
+
+
+def case():
+    """20 layers, 32 streams, Henyey-Greenstein layers with delta-M scaling as in BASELINE's cfg4, four layers with
+    omega = 1 - 1e-6 (two of them adjacent, one optically thick), a grazing beam."""
+    rng = np.random.default_rng(3220)
+    L, NQuad = 20, 32
+    dtau = rng.uniform(0.05, 0.5, L)
+    dtau[11] = 6.0
+    omega = rng.uniform(0.5, 0.99, L)
+    omega[[3, 4, 11, 17]] = 1 - 1e-6
+    g = rng.uniform(0.6, 0.85, L)
+    Leg = g[:, None] ** np.arange(NQuad + 1)[None, :]
+    return dict(tau_arr=np.cumsum(dtau), omega_arr=omega, NQuad=NQuad, Leg_coeffs_all=Leg, mu0=0.35, I0=np.pi, phi0=0.0,
+                f_arr=g**NQuad)
+
+
+def banded_solve(rows, rhs, kl):
+    """Gaussian elimination with partial pivoting on a banded system in mpmath numbers.  rows[i] is a dict
+    {column: value} of row i; fill stays inside [i - kl, i + 2 kl] as in LAPACK's dgbsv."""
+    n = len(rows)
+    for c in range(n):
+        piv, best = c, abs(rows[c].get(c, mp.mpf(0)))
+        for r in range(c + 1, min(n, c + kl + 1)):
+            v = abs(rows[r].get(c, mp.mpf(0)))
+            if v > best:
+                piv, best = r, v
+        if piv != c:
+            rows[c], rows[piv] = rows[piv], rows[c]
+            rhs[c], rhs[piv] = rhs[piv], rhs[c]
+        prow, pv = rows[c], rows[c][c]
+        for r in range(c + 1, min(n, c + kl + 1)):
+            v = rows[r].pop(c, None)
+            if v is None or v == 0:
+                continue
+            f = v / pv
+            rr = rows[r]
+            for k, a in prow.items():
+                if k > c:
+                    rr[k] = rr.get(k, mp.mpf(0)) - f * a
+            rhs[r] -= f * rhs[c]
+    x = [mp.mpf(0)] * n
+    for c in range(n - 1, -1, -1):
+        s = rhs[c]
+        for k, a in rows[c].items():
+            if k > c:
+                s -= a * x[k]
+        x[c] = s / rows[c][c]
+    return x
+
+
+def solve_mode(p, m):
+    """u^m at the layer interfaces [Q, L + 1] (times the rescale factor) for Fourier mode m."""
+    L, N, P = p["L"], p["N"], p["P"]
+    Q = 2 * N
+    mu = [mp.mpf(float(x)) for x in p["mu"]]
+    w = [mp.mpf(float(x)) for x in p["W"]]
+
+    def leg(x):  # P_l^m(x) with sqrt((l-m)!/(l+m)!) folded in (the reference's poch factor split over both factors)
+        return [mp.mpf(0) if l < m else mp.legenp(l, m, x, type=2) * mp.sqrt(mp.factorial(l - m) / mp.factorial(l + m))
+                for l in range(P)]
+    Y = [leg(x) for x in mu]
+    mu0 = mp.mpf(float(p["mu0"]))
+    Y0 = leg(-mu0)
+    ts = [mp.mpf(float(x)) for x in p["tau_s0"]]
+    Gs, Ks, Bs = [], [], []
+    for l in range(L):
+        om = mp.mpf(float(p["omega_s"][l]))
+        wl = [mp.mpf(float(x)) for x in p["wleg"][l]]
+        sgn = [(-1) ** (ell - m) for ell in range(P)]
+        al, be = mp.zeros(N), mp.zeros(N)
+        for i in range(N):
+            for j in range(N):
+                sp = sm = mp.mpf(0)
+                for ell in range(m, P):
+                    t = om / 2 * wl[ell] * Y[i][ell] * Y[j][ell]
+                    sp += t
+                    sm += t * sgn[ell]
+                al[i, j] = (sp * w[j] - (1 if i == j else 0)) / mu[i]
+                be[i, j] = sm * w[j] / mu[i]
+        ev, V = mp.eig((al - be) * (al + be))
+        k = [mp.sqrt(mp.re(e)) for e in ev]
+        V = V.apply(mp.re)
+        U = (al + be) * V
+        for j in range(N):
+            for i in range(N):
+                U[i, j] /= k[j]
+        G = mp.zeros(Q)
+        for i in range(N):
+            for j in range(N):
+                G[i, j] = G[N + i, N + j] = V[i, j] + U[i, j]
+                G[i, N + j] = G[N + i, j] = V[i, j] - U[i, j]
+        A = mp.zeros(Q)
+        for i in range(N):
+            for j in range(N):
+                A[i, j], A[i, N + j], A[N + i, j], A[N + i, N + j] = -al[i, j], -be[i, j], be[i, j], al[i, j]
+        X = mp.zeros(Q, 1)
+        for i in range(N):
+            xp = xm = mp.mpf(0)
+            for ell in range(m, P):
+                t = mp.mpf(float(p["I0_4pi"])) * (1 if m == 0 else 2) * om * wl[ell] * Y0[ell] * Y[i][ell]
+                xp += t
+                xm += t * sgn[ell]
+            X[i], X[N + i] = xp / mu[i], -xm / mu[i]
+        Gs.append(G)
+        Ks.append([-x for x in k] + k)
+        Bs.append(mp.lu_solve(A + mp.eye(Q) / mu0, X))
+
+    def expo(l, j, t):  # every exponential referenced to the boundary of its layer where it is <= 1
+        kk = Ks[l][j]
+        return mp.e ** (kk * (t - (ts[l + 1] if kk > 0 else ts[l])))
+    n = Q * L
+    rows, rhs = [dict() for _ in range(n)], [mp.mpf(0)] * n
+    r = 0
+    bneg, bpos = mp.mpf(float(p["b_neg"][0, m])), mp.mpf(float(p["b_pos"][0, m]))
+    for i in range(N):  # top boundary: downward streams
+        for j in range(Q):
+            rows[r][j] = Gs[0][N + i, j] * expo(0, j, ts[0])
+        rhs[r] = bneg - Bs[0][N + i] * mp.e ** (-ts[0] / mu0)
+        r += 1
+    for l in range(L - 1):
+        t = ts[l + 1]
+        for i in range(Q):
+            for j in range(Q):
+                rows[r][l * Q + j] = Gs[l][i, j] * expo(l, j, t)
+                rows[r][(l + 1) * Q + j] = -Gs[l + 1][i, j] * expo(l + 1, j, t)
+            rhs[r] = (Bs[l + 1][i] - Bs[l][i]) * mp.e ** (-t / mu0)
+            r += 1
+    for i in range(N):  # bottom boundary: upward streams (black surface)
+        for j in range(Q):
+            rows[r][(L - 1) * Q + j] = Gs[L - 1][i, j] * expo(L - 1, j, ts[L])
+        rhs[r] = bpos - Bs[L - 1][i] * mp.e ** (-ts[L] / mu0)
+        r += 1
+    Cc = banded_solve(rows, rhs, 3 * N - 1)
+    out = np.zeros((Q, L + 1))
+    for ti in range(L + 1):
+        l = 0 if ti == 0 else ti - 1
+        t = ts[ti]
+        for i in range(Q):
+            v = Bs[l][i] * mp.e ** (-t / mu0)
+            for j in range(Q):
+                v += Gs[l][i, j] * expo(l, j, t) * Cc[l * Q + j]
+            out[i, ti] = float(v * mp.mpf(float(p["rescale"])))
+    return out
+
+
+if __name__ == "__main__":
+    kw = case()
+    p = O.prepare(**kw)
+    res = {"modes": np.array(MODES)}
+    for k_, v in kw.items():
+        res["in." + k_] = np.asarray(v)
+    for m in MODES:
+        t0 = time.time()
+        res[f"um{m}"] = solve_mode(p, m)
+        print(f"mode {m}: {time.time() - t0:.0f} s", flush=True)
+        np.savez(os.path.join(ROOT, "tests", "golden", "hp_truth_q32.npz"), **res)
+    # the float64 oracle (the reference's algorithm) against the truth, mode by mode
+    tau = np.concatenate(([0.0], kw["tau_arr"]))
+    sol = O.Solution(p)
+    um = sol._um(list(MODES), tau)[0]  # [mode, Q, tau]
+    for i, m in enumerate(MODES):
+        scale = np.max(np.abs(res[f"um{m}"]))
+        print(f"mode {m}: oracle vs truth, max |d| / max |u^m| = {np.max(np.abs(um[i] * p['rescale'] - res[f'um{m}'])) / scale:.2e}")
