@@ -17,7 +17,9 @@ LIB = os.path.join(OUT_DIR, "librtd.so")
 SOURCES = ["rtd_api.hip", "rtd_eig.hip", "rtd_bc.hip", "rtd_eval.hip", "rtd_nt.hip", "rtd_bdrf.hip"]
 HEADERS = [os.path.join(CSRC, "rtd_device.h"), os.path.join(HERE, "..", "include", "rtd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + os.environ.get("RTD_EXTRA_FLAGS", "").split()
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-save-temps=obj",
+         "-Wno-unused-command-line-argument"] + os.environ.get("RTD_EXTRA_FLAGS", "").split()
+HAZARD_CHECK = os.path.join(HERE, "..", "tools", "check_dpp_hazards.py")
 
 
 def _stale(target, deps):
@@ -31,7 +33,17 @@ def _compile(src):
     obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
     path = os.path.join(CSRC, src)
     if _stale(obj, [path] + HEADERS):
-        subprocess.run([HIPCC] + FLAGS + ["-c", path, "-o", obj], check=True)
+        subprocess.run([HIPCC] + FLAGS + ["-c", path, "-o", obj], check=True, cwd=OBJ_DIR)
+        # the kernels update registers with v_fmac_f64_dpp from inline asm: the compiler's hazard recogniser cannot see
+        # those writes, so the generated ISA is scanned for a DPP read that follows one too closely
+        dev_asm = [os.path.join(OBJ_DIR, f) for f in os.listdir(OBJ_DIR)
+                   if f.startswith(src.replace(".hip", "-hip-amdgcn")) and f.endswith(".s")]
+        if dev_asm:
+            subprocess.run([sys.executable, HAZARD_CHECK] + dev_asm, check=True, stdout=subprocess.DEVNULL)
+        stem = src.replace(".hip", "")
+        for f in os.listdir(OBJ_DIR):  # -save-temps leaves ~10 MB of intermediates per source
+            if f.startswith(stem + "-h") or f.startswith(stem + ".hip-"):
+                os.remove(os.path.join(OBJ_DIR, f))
     return obj
 
 

@@ -838,6 +838,19 @@ __device__ __forceinline__ double bcast16_lds(double v) {
 #ifndef RTD_GJ_GROWTH
 #define RTD_GJ_GROWTH 64.0
 #endif
+#ifndef RTD_GJ_FMAC_DPP
+#define RTD_GJ_FMAC_DPP 1
+#endif
+template <int K, int Q0, int Q1>
+struct FmacRows {  // v[q] -= bcast_K(v[q]) * f for q in [Q0, Q1)
+  static __device__ __forceinline__ void run(double (&v)[4], const double f) {
+    if constexpr (Q0 < Q1) {
+      asm volatile("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(v[Q0]) : "v"(f), "n"(K));
+      FmacRows<K, Q0 + 1, Q1>::run(v, f);
+    }
+  }
+};
+
 template <int NB, int K>
 struct GjFast {
   static __device__ __forceinline__ void run(double (&ta)[4], double (&tb)[4], double& tv, int& bad, const int col) {
@@ -850,6 +863,18 @@ struct GjFast {
     const double rp = r0 * (2.0 - xk * r0);
     const double f = (col == K) ? 1.0 - rp : x * rp;
     bad |= (col > K && fabs(f) > RTD_GJ_GROWTH) ? 1 : 0;  // a zero pivot shows up as a non-finite result (checked by the caller)
+#if RTD_GJ_FMAC_DPP
+    // v -= bcast_K(v) * f as ONE instruction per register: v_fmac_f64 with a row_newbcast DPP source (the only DPP control
+    // the DP ALU has), the source being the accumulator itself.  The compiler's hazard recogniser does not see VALU writes
+    // made inside inline asm; a DPP read needs two wait states after a VALU write of the same VGPR: every register
+    // touched here was last written by the previous step's block (>= 9 instructions back), and the block ends with the
+    // wait states that cover the compiler's own DPP / permute reads of ta in the next step.  `volatile` keeps the blocks
+    // of consecutive steps in program order (the scheduler would otherwise put step K + 1's update of a register right
+    // behind step K's); build.py scans the generated ISA for the hazard pattern (tools/check_dpp_hazards.py).
+    FmacRows<K, QK, 4>::run(ta, f);
+    FmacRows<K, 0, NB>::run(tb, f);
+    asm volatile("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(tv) : "v"(f), "n"(K));
+#else
     static_for<QK, 4>([&](auto qc) {  // rows below 4 QK are finished: the pivot column is zero there
       constexpr int q = decltype(qc)::value;
       ta[q] = fma(-f, bcast16<K>(ta[q]), ta[q]);
@@ -866,6 +891,7 @@ struct GjFast {
     tv = fma(-f, bcast16_lds<K>(tv), tv);
 #else
     tv = fma(-f, bcast16<K>(tv), tv);
+#endif
 #endif
     GjFast<NB, K + 1>::run(ta, tb, tv, bad, col);
   }
