@@ -121,7 +121,11 @@ struct rtd_plan {
   int64_t bytes = 0;
   bool have_quad = false, have_cols = false, solved = false;
   int numeric_status = 0;  // RTD_ST_* bits of the last solve other than the tau range: reported until the next solve
+  std::vector<double> h_tau;  // host copy of tau_arr [C][L]: recognises evaluation points that are the layer interfaces
   // evaluation buffers (grown on demand)
+  bool ev_iface = false;  // the stored evaluation points are [0, tau_arr] of every column (fused evaluation possible)
+  double* um_buf = nullptr;  // [Cw][M][L+1][2 NP]: Fourier modes at the interfaces, written by the boundary-condition kernel
+  int64_t cap_um = 0;
   int ev_ntau = 0, ev_nphi = 0;
   double *ev_tau = nullptr, *ev_phi = nullptr, *ev_u = nullptr, *ev_u0 = nullptr, *ev_fl = nullptr;
   int64_t cap_tau = 0, cap_phi = 0, cap_u = 0, cap_u0 = 0, cap_fl = 0;
@@ -244,7 +248,7 @@ RtdNt window_nt(const rtd_plan* p, int64_t c0) {
 // Solve (and optionally evaluate) every window.  after_window(w, c0, cnt) is called once window w's kernels are
 // queued (rtd_plan_run_fetch hangs its device-to-host copies there).
 template <typename F>
-int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt, F&& after_window) {
+int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt, F&& after_window, bool allow_fused = true) {
   hipStream_t s = p->stream;
   const bool tm = p->timing;
   auto mark = [&](int k) {
@@ -259,7 +263,12 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
   for (int w = 0; w < p->nwin; ++w) {
     const int64_t c0 = (int64_t)w * p->Cw;
     const int cnt = (int)std::min<int64_t>(p->Cw, p->d.C - c0);
-    const RtdDev d = window_dev(p, c0, cnt);
+    RtdDev d = window_dev(p, c0, cnt);
+    // run-path points at the layer interfaces: the boundary-condition kernel evaluates the Fourier modes there itself
+    // (rtd_plan_evaluate -- the closures -- always takes the evaluation kernel, whatever the window count: a column's
+    // closure values must not depend on the batch it was solved in)
+    const bool fused = allow_fused && with_solve && ev && ev->antider == 0 && p->ev_iface && p->um_buf && rtd_bc_fuses_eval(d);
+    d.um = fused ? p->um_buf : nullptr;
     if (tm) {
       (void)hipStreamSynchronize(s);
       harvest(p);
@@ -284,7 +293,8 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
         (void)hipStreamWaitEvent(s, p->ev_gathered, 0);
         p->gather_inflight = false;
       }
-      const RtdEval e = window_eval(p, *ev, c0);
+      RtdEval e = window_eval(p, *ev, c0);
+      e.um_in = fused ? p->um_buf : nullptr;
       rtd_launch_eval(d, e, s);
       if (with_nt && e.u != nullptr) {
         const RtdNt nt = window_nt(p, c0);
@@ -618,6 +628,8 @@ int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* 
   }
 #undef UP
   HIP_TRY(hipStreamSynchronize(s));  // host staging vectors go out of scope
+  p->h_tau.assign(tau, tau + C * L);
+  p->ev_iface = false;  // stored evaluation points, if any, are no longer known to be this batch's interfaces
   p->have_cols = true;
   p->solved = false;
   return 0;
@@ -685,6 +697,17 @@ int rtd_plan_set_eval_points(rtd_plan* p, int32_t ntau, const double* tau, int32
   HIP_TRY(hipStreamSynchronize(p->stream));
   p->ev_ntau = ntau;
   p->ev_nphi = nphi;
+  // points = the layer interfaces [0, tau_arr] of every column?  Then rtd_plan_run takes the fused evaluation.
+  const int64_t L = p->d.L;
+  bool iface = ntau == L + 1 && (int64_t)p->h_tau.size() == C * L;
+  for (int64_t c = 0; iface && c < C; ++c) {
+    const double* t = tau + c * ntau;
+    iface = t[0] == 0.0 && std::memcmp(t + 1, p->h_tau.data() + c * L, (size_t)L * 8) == 0;
+  }
+  p->ev_iface = iface;
+  if (iface && rtd_bc_fuses_eval(p->d)) {
+    if ((rc = grow(p, &p->um_buf, &p->cap_um, (int64_t)p->Cw * p->d.M * (L + 1) * 2 * p->d.NP))) return rc;
+  }
   return 0;
 }
 
@@ -809,7 +832,7 @@ int rtd_plan_evaluate(rtd_plan* p, int32_t ntau, const double* tau, int32_t nphi
   // one window: the intermediates of the solve are resident, only the evaluation kernels run.  Several windows: they
   // are solved again, window by window, with the evaluation behind each (the throughput form rtd_plan_run is the
   // intended entry point for such batches).
-  rc = launch_windows(p, p->nwin > 1, &e, p->have_nt && !skip_nt, [](int, int64_t, int) { return 0; });
+  rc = launch_windows(p, p->nwin > 1, &e, p->have_nt && !skip_nt, [](int, int64_t, int) { return 0; }, false);
   if (rc) return rc;
   rc = rtd_plan_fetch(p, u, u0, flux_up, fdn, fdir);
   if (rc) return rc;

@@ -1173,11 +1173,54 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     // a singular system (the reference's solve_banded / solve raises LinAlgError, :326-333, :383) leaves inf / nan here,
     // and they propagate through the whole backward sweep: one test at its end is enough
   }
+  // ---- fused evaluation at the layer interfaces (d.um != null): u^m = G_l [e- C- ; e+ C+] + B_l exp(-tau*/mu0) (+ v) at
+  //      the bottom of layer l (e- = E_l, e+ = 1) and, for layer 0, at its top (e- = 1, e+ = E_0); with
+  //      Gp = (Y - A/k)/T, Gm = (Y + A/k)/T:  up = [Y (en + ep) - A (en - ep)/k]/T,  down = [Y (en + ep) + A (en - ep)/k]/T
+  //      (_assemble_intensity_and_fluxes.py:197-254).  Y_l, A_l are in registers (D layout), the sums over the eigen-index
+  //      are row sums over the 16 lanes of a lane-row.
+  double* um = d.um ? d.um + cm * (L + 1) * Q : nullptr;
+  v4f64 rT_row = {0.0, 0.0, 0.0, 0.0};
+  if (um) {
+    const v4f64 t_row = load_row(d.T, kq);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rT_row[q] = fast_rcp(t_row[q]);
+  }
+  auto emit = [&](const int l, const int tidx, const v4f64& yl, const v4f64& al, const double en, const double ep,
+                  const double rk, const int kq, const int col) {
+    const v4f64 P = row_dot(yl, en + ep), Qs = row_dot(al, (en - ep) * rk);
+    const double attv = beam ? d.att[(long)c * (L + 1) + tidx] : 0.0;
+    const double tsv = ts0[tidx];
+    const int c3 = col & 3, i = 4 * c3 + kq;  // lanes col < 4 store element i of the up- and of the down-streams
+    double up = 0.0, dn = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double u_q = (P[q] - Qs[q]) * rT_row[q], d_q = (P[q] + Qs[q]) * rT_row[q];
+      up = (c3 == q) ? u_q : up;
+      dn = (c3 == q) ? d_q : dn;
+    }
+    if (col < 4) {
+      if (beam) {
+        up += Bv[l * Q + i] * attv;
+        dn += Bv[l * Q + NP + i] * attv;
+      }
+      if (iso) {
+        up += vpoly(l, tsv, i);
+        dn += vpoly(l, tsv, NP + i);
+      }
+      um[(long)tidx * Q + i] = up;
+      um[(long)tidx * Q + NP + i] = dn;
+    }
+  };
   // ---- backward sweep: C+_l = Wq C-' + Wp E' C+' + rho_b ;  C-_l = s_l - S_l C+_l, with W applied through its
   //      factors.  The loads of layer l-1 are issued while layer l is processed.
   a1 = a0;
   y1 = y0;
   double k1b = kk[Lm1 * NP + col], e1b = Ek[Lm1 * NP + col];
+  if (um) {
+    const double rk = fast_rcp(k1b);
+    emit(Lm1, L, y0, a0, e1b * cminus, cplus, rk, kq, col);
+    if (Lm1 == 0) emit(0, 0, y0, a0, cminus, e1b * cplus, rk, kq, col);
+  }
   if (Lm1 == 0) {  // single layer: no interface, no workspace
     if (!(fabs(cminus) + fabs(cplus) < 1e300)) atomicOr(d.status, RTD_ST_BC);
     return;
@@ -1225,6 +1268,11 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       coef[(long)l * Q + col] = cmn;
       coef[(long)l * Q + NP + col] = cp;
     }
+    if (um) {
+      const double rk = fast_rcp(k0b);
+      emit(l, l + 1, y0, a0, e0b * cmn, cp, rk, kq, col);
+      if (l == 0) emit(0, 0, y0, a0, cmn, e0b * cp, rk, kq, col);
+    }
     cminus = cmn;
     cplus = cp;
     a1 = a0;
@@ -1236,6 +1284,11 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
 }
 
 }  // namespace
+
+bool rtd_bc_fuses_eval(const RtdDev& d) {
+  static const bool split = getenv("RTD_BC_SPLIT") != nullptr;
+  return d.NP == 16 && !split;
+}
 
 void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
   // part 0: interface operators (all interfaces in parallel), 1: carry recursion / bottom BC / backward sweep

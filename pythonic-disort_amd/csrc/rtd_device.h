@@ -39,6 +39,10 @@ struct RtdDev {
   double *Ym, *Am, *kk, *Bv, *dq, *zneg, *coef;
   double* Ek;         // [C][M][L][NP]  exp(-k dtau*_l): the Stamnes-Conklin scaling factors
   double* Fws;  // BC workspace: [C][M][L-1][4 NP^2]: Wp, Wq, S, rho_t, rho_b, s per interface (rtd_bc.hip)
+  // Fused evaluation (rtd_bc_mfma_kernel): when the evaluation points are the layer interfaces [0, tau_arr] the backward
+  // sweep of the boundary-condition kernel forms the Fourier modes of the intensity there itself -- Y_l, A_l and the
+  // coefficients are in its registers, the exponentials are E_l or 1 -- and the evaluation kernel only sums over the modes.
+  double* um;         // [C][M][L+1][Q2]  u^m at the interfaces (null: not wanted)
   int* sweeps;        // [1] max Jacobi sweeps (diagnostic)
   int* status;        // [1] device-side status flags (RTD_ST_*)
 };
@@ -57,6 +61,7 @@ struct RtdEval {
   const double* tau;  // [C][ntau]
   const double* phi;  // [nphi]
   double *u, *u0, *fup, *fdn, *fdir, *ulast;  // device outputs (may be null)
+  const double* um_in;  // [C][M][ntau][Q2] Fourier modes already formed by the boundary-condition kernel (else null)
 };
 
 // Nakajima-Tanaka corrections (rtd_nt.hip)
@@ -73,6 +78,7 @@ struct RtdNt {
 void rtd_launch_tables(const RtdDev& d, hipStream_t s, bool with_quad = true);  // with_quad: also the column-independent Y table
 void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part);  // the fused eigen kernel runs as part 1 (0, 2: empty timing slots)
 void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part);   // 0 iface, 1 sweep
+bool rtd_bc_fuses_eval(const RtdDev& d);  // the boundary-condition kernel chosen for d can fill d.um
 void rtd_launch_eval(const RtdDev& d, const RtdEval& e, hipStream_t s);
 void rtd_launch_nt_tables(const RtdDev& d, const RtdNt& nt, hipStream_t s);
 void rtd_launch_nt_apply(const RtdDev& d, const RtdNt& nt, const RtdEval& e, hipStream_t s);

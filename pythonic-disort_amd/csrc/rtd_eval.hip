@@ -63,6 +63,15 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
   const double sc = d.scale[(long)c * L + l];
   const bool antider = ev.antider != 0;
   const double dtop = ts - ts0[l], dbot = ts0[l + 1] - ts;
+  const bool beam = d.beam != 0;
+  const double mu0 = beam ? d.mu0[c] : 1.0;
+  if (ev.um_in != nullptr) {
+    // the boundary-condition kernel has formed u^m at this point (a layer interface) already: only the sums are left
+    for (int idx = tid; idx < M * Q; idx += EVAL_THREADS) {
+      const int m = idx / Q, i = idx % Q;
+      um[idx] = ev.um_in[(((long)c * M + m) * ev.ntau + t) * Q + i];
+    }
+  } else {
   // exponent * coefficient, both halves non-positive exponents (:197-203)
   for (int idx = tid; idx < M * NP; idx += EVAL_THREADS) {
     const int m = idx / NP, jj = idx % NP;
@@ -79,8 +88,6 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
     e_s[m * Q + NP + jj] = (en - ep) / k;
   }
   __syncthreads();
-  const bool beam = d.beam != 0;
-  const double mu0 = beam ? d.mu0[c] : 1.0;
   double bfac = beam ? exp(-ts / mu0) : 0.0;
   if (antider) bfac /= (-sc / mu0);
   // u^m_i = sum_j G_ij e_j + B_i exp(-tau*/mu0) (+ v_i for m = 0): NP lanes per (m, stream i); the up- and the
@@ -117,6 +124,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
     }
     um[m * Q + jj] = vu;
     um[m * Q + NP + jj] = vd;
+  }
   }
   __syncthreads();
   const double rescale = d.rescale[c];

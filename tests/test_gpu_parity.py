@@ -776,3 +776,39 @@ def test_high_precision_truth_32_streams(amd):
     assert worst < 1e-9       # measured 7.5e-11 of the field scale (mode 0; the oracle: 6.4e-8) -- the conditioning of
     #                           omega = 1 - 1e-6 layers (~1e6) times double rounding
     assert worst_pw < 1e-6    # measured 1.0e-7, pointwise down to intensities 1e-8 of the largest
+
+
+@pytest.mark.gpu
+def test_fused_interface_evaluation_equals_the_evaluation_kernel(amd):
+    """Run-path points at the layer interfaces are evaluated inside the boundary-condition kernel's backward sweep (u^m from
+    the Y_l, A_l and coefficients in its registers); any other set of points goes through the evaluation kernel.  Same
+    columns through both: interfaces + one interior point (general kernel) against interfaces only (fused), for a beam-only
+    batch (cfg4), a batch with every source type (cfg3 at 32 streams is not available: cfg4 + thermal + surface), one
+    layer, and Fourier-mode shards."""
+    from pydisort_amd import synthetic
+    from pydisort_amd._engine import Plan
+    phi = np.array([0.0, 1.1, pi])
+    cases = {"cfg4": synthetic.cfg4_columns(24), "one_layer": synthetic.cfg4_columns(5, L=1),
+             "26_streams": synthetic.cfg4_columns(6, L=7, NQuad=26)}
+    full = synthetic.cfg4_columns(12, L=9)
+    full.update(s_poly_coeffs=np.tile(np.array([[0.3, 0.02, 0.001]]), (12, 9, 1)), b_pos=0.2, b_neg=0.1,
+                bdrf_q=np.full((12, 1, 16, 16), 0.4), bdrf_q0=np.full((12, 1, 16), 0.4))
+    cases["all_sources"] = full
+    for name, cfg in cases.items():
+        C = cfg["tau_arr"].shape[0]
+        for shard in (None, (1, 3)):
+            _, sol = amd.pydisort_batch(mode_shard=shard, **cfg)
+            plan = sol.plan
+            iface = np.concatenate((np.zeros((C, 1)), cfg["tau_arr"]), axis=1)
+            plan.set_eval_points(iface, phi)
+            plan.run()
+            fused = plan.fetch()
+            general = np.concatenate((iface, 0.5 * cfg["tau_arr"][:, :1]), axis=1)  # one more point: not the interfaces
+            plan.set_eval_points(general, phi)
+            plan.run()
+            want = plan.fetch()
+            for k in ("u", "u0", "flux_up", "flux_down_diffuse", "flux_down_direct"):
+                a, b = fused[k], want[k][..., :-1, :] if k == "u" else want[k][..., :-1]
+                scale = max(np.max(np.abs(b)), 1e-300)
+                assert np.max(np.abs(a - b)) <= 1e-13 * scale, (name, shard, k, np.max(np.abs(a - b)) / scale)
+            plan.close()
