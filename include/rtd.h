@@ -85,6 +85,20 @@ int rtd_plan_set_columns(rtd_plan* plan, const double* scaled_omega, const doubl
                          const double* b_pos, const double* b_neg, const double* s_poly,
                          const double* bdrf_q, const double* bdrf_q0);
 
+/* The same batch from RAW inputs: the preparation of pydisort.py:316-372 (delta-M scaling of tau, omega and the moments,
+ * the thermal source polynomial in the scaled optical depth, the rescaling of every source by the largest one) runs on
+ * the device.  For throughput batches: the host hands over what the user gave, nothing is computed per column on the CPU.
+ *   tau_arr, omega_arr, f_arr [C][L]   as pydisort()'s arguments (f_arr = 0: no delta-M scaling)
+ *   leg_all   [C][L][nleg_all]         Leg_coeffs_all (nleg_all >= nleg; the first nleg moments are used)
+ *   mu0, I0, phi0 [C]                  I0 NOT rescaled
+ *   b_pos, b_neg  [C][M][N]            Dirichlet BCs per Fourier mode, NOT rescaled (NULL = 0)
+ *   s_poly    [C][L][Ns]               s_poly_coeffs as given by the user (NULL when Ns = 0)
+ *   bdrf_q, bdrf_q0                    as in rtd_plan_set_columns */
+int rtd_plan_set_columns_raw(rtd_plan* plan, const double* tau_arr, const double* omega_arr, const double* leg_all,
+                             int32_t nleg_all, const double* f_arr, const double* mu0, const double* I0,
+                             const double* phi0, const double* b_pos, const double* b_neg, const double* s_poly,
+                             const double* bdrf_q, const double* bdrf_q0);
+
 /* BDRF Fourier modes formed on the device.  The reference takes the surface as callables
  * BDRF_Fourier_modes[m](mu, -mu') evaluated on the quadrature grid (_solve_for_coeffs.py:121-134); for a reflectance
  * rho(mu, mu', dphi) its tests integrate every mode on the host (pydisotest/6_test.py:194-201).  Here the caller passes

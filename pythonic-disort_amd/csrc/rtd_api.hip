@@ -635,6 +635,66 @@ int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* 
   return 0;
 }
 
+int rtd_plan_set_columns_raw(rtd_plan* p, const double* tau_arr, const double* omega_arr, const double* leg_all,
+                             int32_t nleg_all, const double* f_arr, const double* mu0, const double* I0,
+                             const double* phi0, const double* b_pos, const double* b_neg, const double* s_poly,
+                             const double* bdrf_q, const double* bdrf_q0) {
+  if (!p || !tau_arr || !omega_arr || !leg_all || !f_arr || !mu0 || !I0 || !phi0) return fail(RTD_ERR_ARG, "null argument");
+  const RtdDev& d = p->d;
+  if (nleg_all < d.P) return fail(RTD_ERR_ARG, "nleg_all must be >= nleg");
+  if (d.Ns > 0 && !s_poly) return fail(RTD_ERR_ARG, "s_poly is required when nscoeffs > 0");
+  if (d.NBDRF > 0 && (!bdrf_q || !bdrf_q0)) return fail(RTD_ERR_ARG, "BDRF tables are required when nbdrf > 0");
+  HIP_TRY(hipSetDevice(p->device));
+  const int64_t C = d.C, L = d.L, M = d.M, N = d.N, NP = d.NP, Ns = d.Ns, NB = d.NBDRF;
+  if (!d.beam)
+    for (int64_t c = 0; c < C; ++c)
+      if (I0[c] > 0.0) return fail(RTD_ERR_ARG, "the plan was created with beam = 0 but a column has I0 > 0");
+  hipStream_t s = p->stream;
+  // one temporary device block for the raw arrays
+  const int64_t n_cl = C * L, n_leg = C * L * nleg_all, n_b = C * M * N, n_sp = C * L * Ns;
+  const int64_t total = 3 * n_cl + n_leg + 3 * C + (b_pos ? n_b : 0) + (b_neg ? n_b : 0) + n_sp;
+  double* raw = nullptr;
+  HIP_TRY(hipMalloc(&raw, (size_t)total * 8));
+  RtdRaw r{};
+  r.nleg_all = nleg_all;
+  double* q = raw;
+  hipError_t e = hipSuccess;
+  auto up = [&](const double*& dst, const double* src, int64_t n) {
+    dst = q;
+    if (e == hipSuccess && n > 0) e = hipMemcpyAsync(q, src, (size_t)n * 8, hipMemcpyHostToDevice, s);
+    q += n;
+  };
+  up(r.tau, tau_arr, n_cl); up(r.omega, omega_arr, n_cl); up(r.f, f_arr, n_cl); up(r.leg, leg_all, n_leg);
+  up(r.mu0, mu0, C); up(r.I0, I0, C); up(r.phi0, phi0, C);
+  if (b_pos) up(r.bpos, b_pos, n_b);
+  if (b_neg) up(r.bneg, b_neg, n_b);
+  if (Ns > 0) up(r.spoly, s_poly, n_sp);
+  std::vector<double> qh, q0h;
+  if (e == hipSuccess && NB > 0) {  // BDRF tables: padded from N to NP on the host (small)
+    qh.assign((size_t)(C * NB * NP * NP), 0.0);
+    q0h.assign((size_t)(C * NB * NP), 0.0);
+    for (int64_t cb = 0; cb < C * NB; ++cb)
+      for (int64_t i = 0; i < N; ++i) {
+        q0h[cb * NP + i] = bdrf_q0[cb * N + i];
+        for (int64_t j = 0; j < N; ++j) qh[(cb * NP + i) * NP + j] = bdrf_q[(cb * N + i) * N + j];
+      }
+    e = hipMemcpyAsync((void*)d.bdrfq, qh.data(), qh.size() * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync((void*)d.bdrfq0, q0h.data(), q0h.size() * 8, hipMemcpyHostToDevice, s);
+  }
+  if (e == hipSuccess) {
+    rtd_launch_prepare(d, r, s);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(raw);
+  if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("set_columns_raw: ") + hipGetErrorString(e));
+  p->h_tau.assign(tau_arr, tau_arr + C * L);
+  p->ev_iface = false;
+  p->have_cols = true;
+  p->solved = false;
+  return 0;
+}
+
 int rtd_plan_set_bdrf_samples(rtd_plan* p, int32_t nphi, const double* rho_qq, const double* rho_q0) {
   if (!p) return fail(RTD_ERR_ARG, "null plan");
   if (!p->have_cols) return fail(RTD_ERR_STATE, "set_columns must precede set_bdrf_samples");

@@ -74,7 +74,18 @@ struct RtdNt {
   double* R;               // [C][2][2][NP][L]  other-layer sums: [antiderivative][up|down]
 };
 
+// raw (unprepared) per-column inputs on the device, for rtd_prep.hip
+struct RtdRaw {
+  int nleg_all;        // phase-function moments given per layer (>= P)
+  const double *tau, *omega, *f;  // [C][L]    tau_arr, omega_arr, f_arr
+  const double* leg;   // [C][L][nleg_all]     Leg_coeffs_all
+  const double *mu0, *I0, *phi0;  // [C]
+  const double *bpos, *bneg;      // [C][M][N] or null (zero)
+  const double* spoly;            // [C][L][Ns] or null
+};
+
 // launchers (one per translation unit)
+void rtd_launch_prepare(const RtdDev& d, const RtdRaw& r, hipStream_t s);
 void rtd_launch_tables(const RtdDev& d, hipStream_t s, bool with_quad = true);  // with_quad: also the column-independent Y table
 void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part);  // the fused eigen kernel runs as part 1 (0, 2: empty timing slots)
 void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part);   // 0 iface, 1 sweep

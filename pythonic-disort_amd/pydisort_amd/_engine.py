@@ -27,7 +27,10 @@ class Plan:
         self._h = h
         mu, w = _f64(prep["mu"]), _f64(prep["W"])
         _lib.check(lib.rtd_plan_set_quadrature(h, _lib.dptr(mu), _lib.dptr(w)))
-        self.set_columns(prep)
+        if prep.get("raw") is not None:
+            self.set_columns_raw(prep["raw"])
+        else:
+            self.set_columns(prep)
         if prep.get("mode_shard") is not None:
             self.set_mode_shard(*prep["mode_shard"])
 
@@ -55,6 +58,20 @@ class Plan:
         arrs = [_f64(prep[k]) for k in keys]
         _lib.check(self._lib.rtd_plan_set_columns(self._h, *[_lib.dptr(a) for a in arrs]))
         self.prep = prep
+        self.solved = False
+
+    def set_columns_raw(self, raw):
+        """Upload a batch as the user gave it; delta-M scaling and source rescaling run on the device
+        (include/rtd.h: rtd_plan_set_columns_raw).  raw: dict(tau_arr, omega_arr, f_arr [C, L], leg [C, L, nleg_all],
+        mu0, I0, phi0 [C], b_pos / b_neg [C, M, N] or None, s_poly [C, L, Ns] or None, bdrf_q, bdrf_q0 or None)."""
+        keys = ("tau_arr", "omega_arr", "leg")
+        a = {k: _f64(raw.get(k)) for k in ("tau_arr", "omega_arr", "leg", "f_arr", "mu0", "I0", "phi0", "b_pos", "b_neg",
+                                           "s_poly", "bdrf_q", "bdrf_q0")}
+        if a["leg"].shape[:2] != (self.C, self.L) or a["tau_arr"].shape != (self.C, self.L):
+            raise ValueError("raw batch does not match the plan's column / layer counts")
+        _lib.check(self._lib.rtd_plan_set_columns_raw(
+            self._h, _lib.dptr(a["tau_arr"]), _lib.dptr(a["omega_arr"]), _lib.dptr(a["leg"]), a["leg"].shape[2],
+            *[_lib.dptr(a[k]) for k in ("f_arr", "mu0", "I0", "phi0", "b_pos", "b_neg", "s_poly", "bdrf_q", "bdrf_q0")]))
         self.solved = False
 
     def close(self):

@@ -38,6 +38,7 @@ SIGNATURES = {
     "rtd_plan_device_bytes": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "rtd_plan_set_quadrature": (C.c_int, [_vp, _dp, _dp]),
     "rtd_plan_set_columns": (C.c_int, [_vp] + [_dp] * 14),
+    "rtd_plan_set_columns_raw": (C.c_int, [_vp, _dp, _dp, _dp, C.c_int32] + [_dp] * 9),
     "rtd_plan_set_bdrf_samples": (C.c_int, [_vp, C.c_int32, _dp, _dp]),
     "rtd_plan_set_mode_shard": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32]),
     "rtd_plan_solve": (C.c_int, [_vp]),

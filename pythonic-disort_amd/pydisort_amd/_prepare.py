@@ -66,18 +66,20 @@ def prepare_columns(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NL
     wleg = leg_s * (2 * ell + 1)[None, None, :]
 
     I0 = np.asarray(I0, float).reshape(C)
-    b_pos = np.asarray(b_pos, float).reshape(C, N, NFourier)
-    b_neg = np.asarray(b_neg, float).reshape(C, N, NFourier)
+    # b_pos / b_neg = None: all zero (nothing is allocated or uploaded for them)
+    b_pos = None if b_pos is None else np.asarray(b_pos, float).reshape(C, N, NFourier)
+    b_neg = None if b_neg is None else np.asarray(b_neg, float).reshape(C, N, NFourier)
     # rescale of the sources (:351-372): max(I0, max b_pos, max b_neg[, s(0) top, s(tau_L) bottom])
-    cand = [I0, b_pos.reshape(C, -1).max(axis=1), b_neg.reshape(C, -1).max(axis=1)]
+    cand = [I0, np.zeros(C) if b_pos is None else b_pos.reshape(C, -1).max(axis=1),
+            np.zeros(C) if b_neg is None else b_neg.reshape(C, -1).max(axis=1)]
     if Ns > 0:
         cand.append(s_s[:, 0, 0])
         cand.append(np.einsum("cj,cj->c", s_s[:, -1, :], tau_s0[:, -1:] ** np.arange(Ns)[None, :]))
     rescale = np.max(np.stack(cand, axis=0), axis=0)
     div = np.where(rescale != 0, rescale, 1.0) if Ns == 0 else rescale
     I0s = I0 / div
-    b_pos = b_pos / div[:, None, None]
-    b_neg = b_neg / div[:, None, None]
+    b_pos = None if b_pos is None else b_pos / div[:, None, None]
+    b_neg = None if b_neg is None else b_neg / div[:, None, None]
     if Ns > 0:
         s_s = s_s / div[:, None, None]
     if Ns == 0:
@@ -88,8 +90,8 @@ def prepare_columns(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NL
                 mu=mu, W=W, omega_s=omega_s, tau=tau_arr, tau_s0=tau_s0, scale_tau=scale_tau, wleg=wleg,
                 mu0=np.asarray(mu0, float).reshape(C), I0=I0s, phi0=np.asarray(phi0, float).reshape(C),
                 rescale=np.asarray(rescale, float),
-                b_pos=np.ascontiguousarray(b_pos.transpose(0, 2, 1)),  # -> [C, M, N]
-                b_neg=np.ascontiguousarray(b_neg.transpose(0, 2, 1)),
+                b_pos=None if b_pos is None else np.ascontiguousarray(b_pos.transpose(0, 2, 1)),  # -> [C, M, N]
+                b_neg=None if b_neg is None else np.ascontiguousarray(b_neg.transpose(0, 2, 1)),
                 s_s=s_s if Ns > 0 else None,
                 bdrf_q=bdrf_q if bdrf_q.shape[1] > 0 else None,
                 bdrf_q0=bdrf_q0 if bdrf_q.shape[1] > 0 else None,

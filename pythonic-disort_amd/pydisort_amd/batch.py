@@ -43,7 +43,7 @@ class BatchSolution:
 def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLeg=None, NFourier=None,
                    b_pos=0, b_neg=0, only_flux=False, f_arr=0, NT_cor=False, bdrf_q=None, bdrf_q0=None,
                    s_poly_coeffs=None, device=0, bdrf_samples=None, NBDRF=None, mode_shard=None, work_columns=0,
-                   _defer_solve=False):
+                   device_prepare=False, _defer_solve=False):
     """Like ``pydisort`` with a leading column axis on every atmospheric input:
     tau_arr, omega_arr, f_arr [C, L]; Leg_coeffs_all [C, L, NLeg_all]; mu0, I0, phi0 [C];
     b_pos / b_neg: scalar, [C], [C, N] or [C, N, NFourier]; s_poly_coeffs [C, L, Ns];
@@ -56,6 +56,8 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
     mode_shard=(r, G): solve only the Fourier modes r, r + G, r + 2G, ... (the partition for
     fewer columns than GPUs); the evaluators then return this shard's partial sums -- the shards add up to the full
     result (u0, fluxes and NT corrections come from shard 0 only; ``Plan.allreduce_results`` sums across RCCL ranks).
+    device_prepare=True: the delta-M scaling and the source rescaling of pydisort.py:316-372 run on the device from the raw
+    inputs (``rtd_plan_set_columns_raw``) instead of in NumPy -- for throughput batches; not with NT_cor or mode_shard.
     work_columns: columns whose intermediates are resident on the device at a time (0: sized by the library); batches
     larger than that are solved window by window (include/rtd.h: rtd_plan_create_windowed).
     All columns share NQuad, NLeg, NFourier and the layer count.  Returns (mu_arr, BatchSolution)."""
@@ -84,6 +86,8 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
 
     def bc(b):
         b = np.asarray(b, float)
+        if b.ndim == 0 and b == 0:
+            return None  # all zero: nothing to allocate or upload
         out = np.zeros((C, N, NFourier))
         if b.ndim == 0 or b.shape == (C,):
             out[:, :, 0] = np.broadcast_to(b, (C,))[:, None]
@@ -107,15 +111,29 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
         if not 0 < nb <= NFourier:
             raise ValueError("Need 0 < NBDRF <= NFourier.")
         bq, bq0 = np.zeros((C, nb, N, N)), np.zeros((C, nb, N))  # placeholders: the device fills the tables
-    prep = prepare_columns(tau_arr, omega_arr, NQuad, Leg, mu0, I0, phi0, NLeg, NFourier, bc(b_pos), bc(b_neg),
-                           f_arr, sp, bq, bq0)
+    if device_prepare:
+        if NT_cor or mode_shard is not None:
+            raise ValueError("device_prepare cannot be combined with NT_cor or mode_shard.")
+        bp, bn = bc(b_pos), bc(b_neg)
+        raw = dict(tau_arr=tau_arr, omega_arr=omega_arr, leg=Leg, f_arr=f_arr, mu0=mu0, I0=I0, phi0=phi0,
+                   b_pos=None if bp is None else np.ascontiguousarray(bp.transpose(0, 2, 1)),
+                   b_neg=None if bn is None else np.ascontiguousarray(bn.transpose(0, 2, 1)),
+                   s_poly=sp if sp.shape[2] > 0 else None,
+                   bdrf_q=bq if bq.shape[1] > 0 else None, bdrf_q0=bq0 if bq.shape[1] > 0 else None)
+        mu, W = double_gauss(N)
+        prep = dict(C=C, L=L, N=N, P=NLeg, M=NFourier, Ns=sp.shape[2], NBDRF=bq.shape[1], beam=bool(np.any(I0 > 0)),
+                    mu=mu, W=W, tau=tau_arr, raw=raw)
+    else:
+        prep = prepare_columns(tau_arr, omega_arr, NQuad, Leg, mu0, I0, phi0, NLeg, NFourier, bc(b_pos), bc(b_neg),
+                               f_arr, sp, bq, bq0)
     if mode_shard is not None:
         r, G = int(mode_shard[0]), int(mode_shard[1])
         if not (0 <= r < G <= NFourier):
             raise ValueError("mode_shard=(r, G) needs 0 <= r < G <= NFourier.")
         modes = np.arange(r, NFourier, G)
-        prep["b_pos"] = np.ascontiguousarray(prep["b_pos"][:, modes, :])  # the source rescale above saw every mode
-        prep["b_neg"] = np.ascontiguousarray(prep["b_neg"][:, modes, :])
+        for k in ("b_pos", "b_neg"):  # the source rescale above saw every mode
+            if prep[k] is not None:
+                prep[k] = np.ascontiguousarray(prep[k][:, modes, :])
         prep["M"] = len(modes)
         prep["mode_shard"] = (r, G, NFourier)
         NT_cor = NT_cor and r == 0
@@ -146,7 +164,8 @@ def solve_columns_streamed(cfg, tau, phi, chunk_columns=0, device=0, only_flux=F
     Returns dict(u [C, NQuad, ntau, nphi] (absent when only_flux), u0, flux_up, flux_down_diffuse, flux_down_direct)."""
     tau = np.ascontiguousarray(np.asarray(tau, float))
     C, ntau = tau.shape
-    _, sol = pydisort_batch(only_flux=only_flux, device=device, work_columns=chunk_columns, _defer_solve=True, **cfg)
+    _, sol = pydisort_batch(only_flux=only_flux, device=device, work_columns=chunk_columns, device_prepare=True,
+                            _defer_solve=True, **cfg)
     plan = sol.plan
     try:
         sol._tau(tau)  # range check on the host, with the reference's message

@@ -429,7 +429,7 @@ def test_edge_cases_vs_oracle(amd, name):
 
 
 def test_streamed_chunks_equal_one_batch(amd):
-    """solve_columns_streamed (one reused plan, several chunks incl. a shorter last one) == one big batch, bit for bit."""
+    """solve_columns_streamed (one plan, several windows incl. a shorter last one, device-side preparation) == one batch."""
     from pydisort_amd import synthetic
     C = 50
     cfg = synthetic.cfg4_columns(C, L=6, NQuad=16)
@@ -438,7 +438,10 @@ def test_streamed_chunks_equal_one_batch(amd):
     _, sol = amd.pydisort_batch(**cfg)
     want_u, want_f = sol.u(tau, phi), sol.flux_up(tau)
     got = amd.solve_columns_streamed(cfg, tau, phi, chunk_columns=16)
-    assert np.array_equal(got["u"], want_u) and np.array_equal(got["flux_up"], want_f)
+    # (the streamed form prepares its inputs on the device, the batch above in NumPy: same mathematics, other rounding;
+    #  bit-equality of windowed and one-window plans is test_windowed_plan_equals_single_window)
+    assert np.max(np.abs(got["u"] - want_u)) <= 1e-12 * np.max(np.abs(want_u))
+    assert np.allclose(got["flux_up"], want_f, rtol=1e-12)
 
 
 # ---- BDRF Fourier modes formed on the device ---------------------------------------
@@ -702,7 +705,8 @@ def test_streamed_batch_takes_its_sources_from_every_column(amd):
     phi = np.array([0.3])
     got = amd.solve_columns_streamed(cfg, tau, phi, chunk_columns=16)
     _, sol = amd.pydisort_batch(**cfg)
-    assert np.array_equal(got["u"], sol.u(tau, phi))
+    want = sol.u(tau, phi)
+    assert np.max(np.abs(got["u"] - want)) <= 1e-12 * np.max(np.abs(want))
     # and against single-column solves of a sourced column and of a source-free column
     for i in (3, 30):
         kw = synthetic.column_kwargs(cfg, i)
@@ -812,3 +816,32 @@ def test_fused_interface_evaluation_equals_the_evaluation_kernel(amd):
                 scale = max(np.max(np.abs(b)), 1e-300)
                 assert np.max(np.abs(a - b)) <= 1e-13 * scale, (name, shard, k, np.max(np.abs(a - b)) / scale)
             plan.close()
+
+
+@pytest.mark.gpu
+def test_device_side_preparation_equals_host_preparation(amd):
+    """pydisort_batch(device_prepare=True): delta-M scaling, thermal-source recentring and source rescaling on the device
+    (rtd_prep.hip, pydisort.py:316-372) against the NumPy front end, on batches that exercise every branch: cfg4 (delta-M,
+    beam), cfg3 (thermal source of order 1, Dirichlet BCs, Lambertian surface, no delta-M), a batch with a cubic thermal
+    source + delta-M + per-column source-free columns, and 10 streams (padding 5 -> 8 lanes)."""
+    from pydisort_amd import synthetic
+    phi = np.array([0.0, 2.0])
+    mixed = synthetic.cfg4_columns(9, L=7, NQuad=16)
+    mixed.update(s_poly_coeffs=np.tile(np.array([[0.4, 0.03, -0.002, 1e-4]]), (9, 7, 1)), b_pos=0.3, b_neg=np.linspace(0, 0.2, 9))
+    mixed["I0"] = mixed["I0"].copy()
+    mixed["I0"][::3] = 0.0
+    cases = {"cfg4": synthetic.cfg4_columns(33), "cfg3": synthetic.cfg3_columns(20, big=True), "mixed": mixed,
+             "q10": synthetic.cfg4_columns(6, L=4, NQuad=10)}
+    for name, cfg in cases.items():
+        C = cfg["tau_arr"].shape[0]
+        tau = np.concatenate((np.zeros((C, 1)), cfg["tau_arr"], 0.37 * cfg["tau_arr"][:, :1]), axis=1)
+        _, host = amd.pydisort_batch(**cfg)
+        _, dev = amd.pydisort_batch(device_prepare=True, **cfg)
+        for fn in ("u", "u0", "flux_up"):
+            a = getattr(dev, fn)(tau, phi) if fn == "u" else getattr(dev, fn)(tau)
+            b = getattr(host, fn)(tau, phi) if fn == "u" else getattr(host, fn)(tau)
+            scale = np.max(np.abs(b))
+            # cubic thermal source: the recentred coefficients come out of a different operation order (2e-13)
+            assert np.max(np.abs(a - b)) <= (2e-12 if name == "mixed" else 1e-13) * scale, (name, fn, np.max(np.abs(a - b)) / scale)
+        fd_a, fd_b = dev.flux_down(tau), host.flux_down(tau)
+        assert np.allclose(fd_a[0], fd_b[0], rtol=1e-12, atol=1e-14) and np.allclose(fd_a[1], fd_b[1], rtol=1e-13)
