@@ -216,6 +216,19 @@ int rtd_comm_allgather_results(rtd_plan* plan);
 /* host copies of the gathered results: u [nranks][C][NQuad][ntau][nphi] (= all nranks * C columns in rank order),
  * fluxes [nranks][3][C][ntau]; either may be NULL */
 int rtd_comm_fetch_gathered_results(rtd_plan* plan, double* u, double* fluxes);
+/* Layer shards (the north star's variant "(layer x mode x column) instances sharded, a single
+ * all-gather to stitch the boundary-condition system"): the eigen stage is independent per layer
+ * (_solve_for_gen_and_part_sols.py:114), the boundary-condition solve couples the layers (_solve_for_coeffs.py:296-323).
+ * Rank r decomposes the layers [r * count, (r + 1) * count) of every (column, mode) with rtd_plan_solve_layers; ONE
+ * ncclAllGather (rtd_comm_allgather_layers: pack, gather, unpack on the plan's stream) gives every rank the eigen-stage
+ * results of all layers -- Y, A, k, E, B per (column, mode, layer) and the thermal-source vectors per (column, layer):
+ * 8 Lloc [C M (2 NP^2 + 2 NP + 2 NP) + C (2 NP Ns + NP)] bytes per rank (cfg4, one column, 4 ranks: 737 KB per rank) --
+ * and rtd_plan_solve_bc finishes the solve on each rank (or on the one that wants the result).  Worth it only for few
+ * columns with very large nlayers x nfourier; plans of one window only. */
+int rtd_plan_solve_layers(rtd_plan* plan, int32_t first_layer, int32_t count);
+int rtd_comm_allgather_layers(rtd_plan* plan, int32_t count_per_rank);
+int rtd_plan_solve_bc(rtd_plan* plan);
+
 /* mode shards: ncclAllReduce(sum) of the u, u0 and flux results of rtd_plan_run over the ranks, in place, asynchronous
  * on the plan's stream (rtd_plan_fetch then returns the complete fields on every rank) */
 int rtd_comm_allreduce_results(rtd_plan* plan);

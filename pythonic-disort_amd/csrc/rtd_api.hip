@@ -380,6 +380,7 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   d.NBDRF = (int)NB; d.beam = dims->beam ? 1 : 0;
   d.flags = getenv("RTD_BC_FORCE_PIVOT") ? 1 : 0;
   d.m0 = 0; d.mstep = 1; d.mtot = (int)M;
+  d.l0 = 0; d.ln = (int)L;
   // window of columns whose intermediates are resident: bytes of intermediates per column
   const int64_t per_col = 8 * (M * P + (L + 1) + 2 * M * L * NP * NP + 2 * M * L * NP + 2 * M * L * Q2 + L * Ns * Q2 + L * NP +
                                M * (L - 1) * Q2 * Q2);
@@ -1159,6 +1160,117 @@ int rtd_comm_fetch_gathered_results(rtd_plan* p, double* u, double* fluxes) {
   if (u && nu > 0) HIP_TRY(hipMemcpyAsync(u, p->gathered_u, (size_t)(nu * p->comm_size) * 8, hipMemcpyDeviceToHost, s));
   if (fluxes) HIP_TRY(hipMemcpyAsync(fluxes, p->gathered_fl, (size_t)(nfl * p->comm_size) * 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+namespace {
+// [CM][L][E] <-> layer-major staging [L'][CM][E] for the layers [l0, l0 + ln): to_stage packs, else unpacks
+__global__ void rtd_layer_stage_kernel(double* arr, double* stage, long CM, int L, int E, int l0, int ln, int to_stage) {
+  const long total = (long)ln * CM * E;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(idx % E);
+    const long cm = (idx / E) % CM;
+    const int ll = (int)(idx / ((long)E * CM));
+    double* a = arr + (cm * L + l0 + ll) * E + e;
+    if (to_stage) stage[idx] = *a;
+    else *a = stage[idx];
+  }
+}
+struct LayerSeg { double* arr; long CM; int E; };
+int layer_segments(rtd_plan* p, LayerSeg seg[7]) {
+  const RtdDev& d = p->d;
+  const long CM = (long)d.C * d.M;
+  const int NP = d.NP, Q2 = 2 * d.NP;
+  int n = 0;
+  seg[n++] = {d.Ym, CM, NP * NP};
+  seg[n++] = {d.Am, CM, NP * NP};
+  seg[n++] = {d.kk, CM, NP};
+  seg[n++] = {d.Ek, CM, NP};
+  seg[n++] = {d.Bv, CM, Q2};
+  if (d.Ns > 0) {
+    seg[n++] = {d.dq, (long)d.C, d.Ns * Q2};
+    seg[n++] = {d.zneg, (long)d.C, NP};
+  }
+  return n;
+}
+}  // namespace
+
+int rtd_plan_solve_layers(rtd_plan* p, int32_t first, int32_t count) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  if (!p->have_quad || !p->have_cols) return fail(RTD_ERR_STATE, "set_quadrature and set_columns must precede solve");
+  if (p->nwin != 1) return fail(RTD_ERR_STATE, "layer shards need a plan of one window");
+  if (first < 0 || count < 1 || first + count > p->d.L) return fail(RTD_ERR_ARG, "layer range outside the atmosphere");
+  HIP_TRY(hipSetDevice(p->device));
+  RtdDev d = p->d;
+  d.l0 = first;
+  d.ln = count;
+  d.um = nullptr;
+  HIP_TRY(hipMemsetAsync(d.sweeps, 0, sizeof(int), p->stream));
+  p->numeric_status = 0;
+  rtd_launch_tables(d, p->stream, true);
+  rtd_launch_eig(d, p->stream, 1);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  p->solved = false;
+  return 0;
+}
+
+int rtd_comm_allgather_layers(rtd_plan* p, int32_t count) {
+  if (!p || !p->comm) return fail(RTD_ERR_STATE, "communicator not initialised");
+  if (p->nwin != 1) return fail(RTD_ERR_STATE, "layer shards need a plan of one window");
+  if (count < 1 || (int64_t)count * p->comm_size != p->d.L)
+    return fail(RTD_ERR_ARG, "layer shards: nlayers must equal count_per_rank x nranks");
+  HIP_TRY(hipSetDevice(p->device));
+  LayerSeg seg[7];
+  const int nseg = layer_segments(p, seg);
+  int64_t per_rank = 0;
+  for (int k = 0; k < nseg; ++k) per_rank += (int64_t)count * seg[k].CM * seg[k].E;
+  int rc;
+  // staging: this rank's packed layers, then everybody's (reuses the gathered-u buffer slot of the plan)
+  double* mine = nullptr;
+  HIP_TRY(hipMalloc(&mine, (size_t)per_rank * 8));
+  if ((rc = grow(p, &p->gathered_u, &p->cap_gathered_u, per_rank * p->comm_size))) {
+    (void)hipFree(mine);
+    return rc;
+  }
+  hipStream_t s = p->stream;
+  const int L = p->d.L, l0 = p->comm_rank * count;
+  int64_t off = 0;
+  for (int k = 0; k < nseg; ++k) {
+    hipLaunchKernelGGL(rtd_layer_stage_kernel, dim3(1024), dim3(256), 0, s, seg[k].arr, mine + off, seg[k].CM, L, seg[k].E, l0, count, 1);
+    off += (int64_t)count * seg[k].CM * seg[k].E;
+  }
+  ncclResult_t nr = rccl()->AllGather(mine, p->gathered_u, (size_t)per_rank, ncclDouble, p->comm, s);
+  if (nr == ncclSuccess) {
+    for (int g = 0; g < p->comm_size; ++g) {
+      if (g == p->comm_rank) continue;  // this rank's own layers are in place
+      off = 0;
+      for (int k = 0; k < nseg; ++k) {
+        hipLaunchKernelGGL(rtd_layer_stage_kernel, dim3(1024), dim3(256), 0, s, seg[k].arr, p->gathered_u + g * per_rank + off,
+                           seg[k].CM, L, seg[k].E, g * count, count, 0);
+        off += (int64_t)count * seg[k].CM * seg[k].E;
+      }
+    }
+  }
+  hipError_t e = hipStreamSynchronize(s);
+  (void)hipFree(mine);
+  if (nr != ncclSuccess) return fail(RTD_ERR_HIP, std::string("ncclAllGather: ") + rccl()->GetErrorString(nr));
+  if (e != hipSuccess) return fail(RTD_ERR_HIP, hipGetErrorString(e));
+  return 0;
+}
+
+int rtd_plan_solve_bc(rtd_plan* p) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  if (!p->have_quad || !p->have_cols) return fail(RTD_ERR_STATE, "inputs missing");
+  if (p->nwin != 1) return fail(RTD_ERR_STATE, "layer shards need a plan of one window");
+  HIP_TRY(hipSetDevice(p->device));
+  RtdDev d = p->d;
+  d.um = nullptr;
+  rtd_launch_bc(d, p->stream, 0);
+  rtd_launch_bc(d, p->stream, 1);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  p->solved = true;
   return 0;
 }
 

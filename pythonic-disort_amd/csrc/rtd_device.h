@@ -22,6 +22,9 @@ struct RtdDev {
   int C, L, N, NP, P, M, Ns, NBDRF, beam;
   // Fourier-mode shard (secondary partition): local mode m stands for the mode m0 + mstep * m of mtot
   int m0, mstep, mtot;
+  // layer shard of the eigen stage (the north star's "all-gather to stitch the boundary-condition
+  // system"): only the layers [l0, l0 + ln) are decomposed by this launch; l0 = 0, ln = L without shards
+  int l0, ln;
   int flags;  // bit 0: the fused BC kernel skips its speculative elimination (test hook, env RTD_BC_FORCE_PIVOT)
   // quadrature (padded to NP)
   const double *mu, *w, *invmu, *S, *T;  // S = sqrt(w/mu), T = sqrt(w*mu) (1 for padding)

@@ -290,7 +290,8 @@ __device__ __forceinline__ ProbId locate(const RtdDev& d, const int tx = threadI
   // One wavefront = the 64/NP consecutive layers of ONE (column, mode): c and m depend on blockIdx only, so
   // they are wave-uniform and the Legendre-table reads (indexed by m and l only) become scalar loads.
   constexpr int GPW = 64 / NP;
-  const int nchunk = (d.L + GPW - 1) / GPW;
+  // layer shard (rtd_plan_solve_layers): only the layers [l0, l0 + ln) are decomposed; ln = L without shards
+  const int nchunk = (d.ln + GPW - 1) / GPW;
   const long cmi = (long)blockIdx.x / nchunk;
   const int chunk = (int)((long)blockIdx.x % nchunk);
   ProbId p;
@@ -298,8 +299,9 @@ __device__ __forceinline__ ProbId locate(const RtdDev& d, const int tx = threadI
   p.mg = d.m0 + d.mstep * p.m;
   p.c = (int)(cmi / d.M);
   const int slot = chunk * GPW + tx / NP;
-  p.valid = slot < d.L;
-  p.l = d.lperm[(long)p.c * d.L + (p.valid ? slot : d.L - 1)];  // invalid groups redo the last slot and skip the stores
+  p.valid = slot < d.ln;
+  const int sl = p.valid ? slot : d.ln - 1;  // invalid groups redo the last slot and skip the stores
+  p.l = d.ln == d.L ? d.lperm[(long)p.c * d.L + sl] : d.l0 + sl;
   p.pid = cmi * d.L + p.l;
   return p;
 }
@@ -812,7 +814,7 @@ void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part) {
   // One fused kernel (launched as part 1; parts 0 and 2 are the empty timing slots of the earlier three-kernel form).
   if (part != 1) return;
   const int gpw = 64 / d.NP;
-  const dim3 grid((unsigned)((long)d.C * d.M * ((d.L + gpw - 1) / gpw)));
+  const dim3 grid((unsigned)((long)d.C * d.M * ((d.ln + gpw - 1) / gpw)));
   // RTD_EIG_V1=1: the one-column-per-lane form of the sweeps (A/B runs and a regression test)
   static const bool v1 = getenv("RTD_EIG_V1") != nullptr;
 #define RTD_EIG_CASE(NPV)                                                                        \

@@ -216,6 +216,20 @@ class Plan:
     def allgather_fluxes(self):
         _lib.check(self._lib.rtd_comm_allgather_fluxes(self._h))
 
+    def solve_layers(self, first, count):
+        """Eigen stage of the layers [first, first + count) only (layer shards; include/rtd.h: rtd_plan_solve_layers)."""
+        _lib.check(self._lib.rtd_plan_solve_layers(self._h, int(first), int(count)))
+        self.solved = False
+
+    def allgather_layers(self, count_per_rank):
+        """ONE RCCL all-gather of the eigen-stage results of every rank's layers (rtd_comm_allgather_layers)."""
+        _lib.check(self._lib.rtd_comm_allgather_layers(self._h, int(count_per_rank)))
+
+    def solve_bc(self):
+        """Boundary-condition solve over all layers, after solve_layers / allgather_layers."""
+        _lib.check(self._lib.rtd_plan_solve_bc(self._h))
+        self.solved = True
+
     def allgather_results(self):
         """RCCL all-gather of u and the fluxes of the last run() over the ranks, on the plan's communication stream
         (overlaps the next run(); include/rtd.h: rtd_comm_allgather_results)."""

@@ -62,6 +62,9 @@ SIGNATURES = {
     "rtd_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int32, C.c_int32]),
     "rtd_comm_allgather_fluxes": (C.c_int, [_vp]),
     "rtd_comm_allreduce_results": (C.c_int, [_vp]),
+    "rtd_plan_solve_layers": (C.c_int, [_vp, C.c_int32, C.c_int32]),
+    "rtd_comm_allgather_layers": (C.c_int, [_vp, C.c_int32]),
+    "rtd_plan_solve_bc": (C.c_int, [_vp]),
     "rtd_comm_allgather_results": (C.c_int, [_vp]),
     "rtd_comm_fetch_gathered_results": (C.c_int, [_vp, _dp, _dp]),
     "rtd_comm_fetch_gathered": (C.c_int, [_vp, _dp]),

@@ -845,3 +845,39 @@ def test_device_side_preparation_equals_host_preparation(amd):
             assert np.max(np.abs(a - b)) <= (2e-12 if name == "mixed" else 1e-13) * scale, (name, fn, np.max(np.abs(a - b)) / scale)
         fd_a, fd_b = dev.flux_down(tau), host.flux_down(tau)
         assert np.allclose(fd_a[0], fd_b[0], rtol=1e-12, atol=1e-14) and np.allclose(fd_a[1], fd_b[1], rtol=1e-13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [1, 2, 5])
+def test_layer_shards_stitch_the_boundary_condition_system(amd, G):
+    """The north star's layer-sharded variant, emulated on one GPU: the eigen stage runs shard by
+    shard over disjoint layer ranges (what G ranks would do at once), then ONE boundary-condition solve over all layers
+    and the evaluation -- equal to the unsharded solve of the same plan.  With G = 1 the eigen-stage results also go
+    through the collective of the variant (pack -> ncclAllGather with a 1-rank communicator -> unpack)."""
+    from pydisort_amd import synthetic
+    from pydisort_amd._engine import Plan
+    cfg = synthetic.cfg4_columns(3, L=20)
+    cfg.update(s_poly_coeffs=np.tile(np.array([[0.3, 0.02]]), (3, 20, 1)), b_pos=0.1)  # thermal vectors travel too
+    tau = np.concatenate((np.zeros((3, 1)), cfg["tau_arr"], 0.5 * cfg["tau_arr"][:, :1]), axis=1)
+    phi = np.array([0.0, 2.0])
+    _, sol = amd.pydisort_batch(**cfg)
+    want = sol.plan.evaluate(tau, phi)
+    plan = sol.plan
+    Lloc = 20 // G
+    # wipe the eigen-stage results by solving other inputs, then put the right ones back shard by shard
+    for r in reversed(range(G)):  # any order: the shards are independent
+        plan.solve_layers(r * Lloc, Lloc)
+    if G == 1:
+        Plan.comm_preload()
+        plan.comm_init(Plan.comm_unique_id(), 0, 1)
+        plan.allgather_layers(Lloc)
+    plan.solve_bc()
+    got = plan.evaluate(tau, phi)
+    for k in ("u", "u0", "flux_up", "flux_down_diffuse"):
+        if G == 1:
+            assert np.array_equal(got[k], want[k]), k  # same launch geometry: bit-equal, through the collective
+        else:  # other layers share a wavefront (a wavefront sweeps until its slowest problem is done): rounding differs
+            assert np.max(np.abs(got[k] - want[k])) <= 1e-12 * np.max(np.abs(want[k])), k
+    with pytest.raises(RuntimeError):
+        plan.solve_layers(15, 10)  # beyond the last layer
+    plan.close()
