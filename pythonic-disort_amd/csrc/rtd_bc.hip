@@ -651,10 +651,6 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
 #ifndef RTD_BCF_WAVES
 #define RTD_BCF_WAVES 3
 #endif
-#ifndef RTD_BW_MFMA
-#define RTD_BW_MFMA 0  /* backward sweep: W applied through its factors on the VALU (0) or through M1^T, M2s^T from the matrix cores (1: 2 % slower, A/B) */
-#endif
-
 __device__ __forceinline__ v4f64 mm_t(const v4f64& X, const v4f64& Y) {  // X^T Y
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[0], Y[0], acc, 0, 0, 0);
@@ -663,43 +659,16 @@ __device__ __forceinline__ v4f64 mm_t(const v4f64& X, const v4f64& Y) {  // X^T 
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[3], Y[3], acc, 0, 0, 0);
   return acc;
 }
-#ifndef RTD_ROW_SWAP
-#define RTD_ROW_SWAP 0  /* cross-row moves with v_permlane16/32_swap (VALU latency) instead of ds_bpermute (LDS latency) */
-#endif
-typedef unsigned int u2x32 __attribute__((ext_vector_type(2)));
-// v_permlane16_swap(a, b): a' = rows (a0, b0, a2, b2), b' = rows (a1, b1, a3, b3);
-// v_permlane32_swap(a, b): a' = rows (a0, a1, b0, b1), b' = rows (a2, a3, b2, b3)   (tools/hiptests/permlane_swap.hip)
-template <int R>
-__device__ __forceinline__ unsigned int bcast_row32(unsigned int x) {
-  const u2x32 a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-  const unsigned int y = (R & 1) ? a[1] : a[0];  // rows (x0,x0,x2,x2) or (x1,x1,x3,x3)
-  const u2x32 b = __builtin_amdgcn_permlane32_swap(y, y, false, false);
-  return (R & 2) ? b[1] : b[0];
-}
 // value held by lane-row R (compile-time) in the same column, for every lane-row
 template <int R>
 __device__ __forceinline__ double bcast_row(double v, const int col) {
-#if RTD_ROW_SWAP
-  const unsigned int lo = bcast_row32<R>((unsigned int)__double2loint(v)), hi = bcast_row32<R>((unsigned int)__double2hiint(v));
-  return __hiloint2double((int)hi, (int)lo);
-#else
   return bperm(((R << 4) | col) << 2, v);
-#endif
 }
 // sum over the four lane-rows (kq) of the wavefront; the result is replicated over them
 __device__ __forceinline__ double sum_kq(double p) {
-#if RTD_ROW_SWAP
-  const u2x32 al = __builtin_amdgcn_permlane16_swap((unsigned int)__double2loint(p), (unsigned int)__double2loint(p), false, false);
-  const u2x32 ah = __builtin_amdgcn_permlane16_swap((unsigned int)__double2hiint(p), (unsigned int)__double2hiint(p), false, false);
-  const double s = __hiloint2double((int)ah[0], (int)al[0]) + __hiloint2double((int)ah[1], (int)al[1]);  // rows (01, 01, 23, 23)
-  const u2x32 bl = __builtin_amdgcn_permlane32_swap((unsigned int)__double2loint(s), (unsigned int)__double2loint(s), false, false);
-  const u2x32 bh = __builtin_amdgcn_permlane32_swap((unsigned int)__double2hiint(s), (unsigned int)__double2hiint(s), false, false);
-  return __hiloint2double((int)bh[0], (int)bl[0]) + __hiloint2double((int)bh[1], (int)bl[1]);
-#else
   p += xor_lane<16>(p);
   p += __shfl_xor(p, 32, 64);
   return p;
-#endif
 }
 // sum_rows X[r][col] v[r]  with v in row form (register q = v[4 q + kq]); result in column form
 __device__ __forceinline__ double col_dot(const v4f64& X, const v4f64& vr) {
@@ -808,20 +777,6 @@ struct GjT<NB, 16> {
   static __device__ __forceinline__ void run(double (&)[4], double (&)[4], double&, int&, const int, const int) {}
 };
 
-// value of lane K (compile-time) of this lane's 16-lane row through the LDS crossbar: ds_swizzle bit mode,
-// lane' = (lane & 0x10) | K inside each half wavefront.  Same move count as the DPP form (two per double) but on the
-// LDS pipe, which idles in the fused kernel while the VALU is its bound.
-#ifndef RTD_GJ_SWZ
-#define RTD_GJ_SWZ 0  /* 1: the Tb / t rows of the speculative elimination travel by ds_swizzle instead of DPP: 2 % slower (A/B) */
-#endif
-template <int K>
-__device__ __forceinline__ double bcast16_lds(double v) {
-  constexpr int pat = (K << 5) | 0x10;
-  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
-  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
-  return __hiloint2double(hi, lo);
-}
-
 // Speculative, branch-free form of the same elimination with the diagonal as pivot at every step: straight-line
 // code (the 16 steps schedule into each other), no pivot search.  A step whose diagonal candidate is more than a
 // factor RTD_GJ_GROWTH smaller than another unused entry of its row raises `bad` (a zero pivot leaves inf / nan in the
@@ -881,17 +836,9 @@ struct GjFast {
     });
     static_for<0, NB>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
-#if RTD_GJ_SWZ
-      tb[q] = fma(-f, bcast16_lds<K>(tb[q]), tb[q]);
-#else
       tb[q] = fma(-f, bcast16<K>(tb[q]), tb[q]);
-#endif
     });
-#if RTD_GJ_SWZ
-    tv = fma(-f, bcast16_lds<K>(tv), tv);
-#else
     tv = fma(-f, bcast16<K>(tv), tv);
-#endif
 #endif
     GjFast<NB, K + 1>::run(ta, tb, tv, bad, col);
   }
@@ -1246,23 +1193,8 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     pk = kk[lp * NP + col];
     pe = Ek[lp * NP + col];
     const double x = cminus, y = e1b * cplus;
-#if RTD_BW_MFMA
-    // (M u)_j = sum_c M^T[c][j] u_c: column dots with M1^T = Y'^T A_l and M2s^T = (A'/k')^T (Y_l k) from the matrix cores
-    v4f64 y0s, a1s;
-    {
-      const double rk1b = fast_rcp(k1b);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        y0s[q] = y0[q] * k0b;
-        a1s[q] = a1[q] * rk1b;
-      }
-    }
-    const v4f64 m1t = mm_t(y1, a0), m2st = mm_t(a1s, y0s);
-    const double cp = rb + 0.5 * (col_dot(m1t, col_to_row(x + y, rowbase, kq)) + col_dot(m2st, col_to_row(y - x, rowbase, kq)));
-#else
     const v4f64 w1 = row_dot(y1, x + y), w2 = row_dot(a1, (y - x) * fast_rcp(k1b));
     const double cp = rb + 0.5 * (col_dot(a0, w1) + k0b * col_dot(y0, w2));
-#endif
     const double cmn = sl - col_dot(hl, col_to_row(cp, rowbase, kq));
     if (kq == 0) {
       coef[(long)l * Q + col] = cmn;
@@ -1306,21 +1238,16 @@ void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
     RTD_BC_CASE(8)
     case 16: {
       // default: the fused MFMA kernel (launched as part 1; part 0 is empty).  RTD_BC_SPLIT=1 selects the two-kernel
-      // path (interface operators through HBM), RTD_IFACE_LDS=1 its LDS/VALU interface kernel (A/B comparisons).
+      // path (interface operators through HBM: A/B runs and a regression test).
       static const bool split = getenv("RTD_BC_SPLIT") != nullptr;
       if (!split) {
         if (part == 1) hipLaunchKernelGGL(rtd_bc_mfma_kernel, dim3((unsigned)((long)d.C * d.M)), dim3(64), 0, s, d);
         break;
       }
-      if (part == 0 && nif > 0) {
-        static const bool use_lds = getenv("RTD_IFACE_LDS") != nullptr;
-        if (use_lds)
-          hipLaunchKernelGGL(rtd_iface_kernel<16>, gi, dim3(64), 0, s, d);
-        else
-          hipLaunchKernelGGL(rtd_iface_mfma_kernel,
-                             dim3((unsigned)(((long)d.C * d.M * ((d.L - 1 + IFACE_CHUNK - 1) / IFACE_CHUNK) + 3) / 4)),
-                             dim3(256), 0, s, d);
-      }
+      if (part == 0 && nif > 0)
+        hipLaunchKernelGGL(rtd_iface_mfma_kernel,
+                           dim3((unsigned)(((long)d.C * d.M * ((d.L - 1 + IFACE_CHUNK - 1) / IFACE_CHUNK) + 3) / 4)),
+                           dim3(256), 0, s, d);
       if (part == 1) hipLaunchKernelGGL(rtd_sweep_kernel<16>, gs, dim3(64), 0, s, d);
       break;
     }

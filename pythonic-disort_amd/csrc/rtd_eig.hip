@@ -210,19 +210,6 @@ __device__ __forceinline__ double bcast_lane(double v) {
 // symmetric so that A^(K)[j][K] is available in the lane's own registers, and the scaling of a finished column by
 // 1/sqrt(pivot) is deferred to the end: a step is one broadcast and one FMA per element,
 //   col_j[i] -= A^(K)[i][K] * A^(K)[j][K] / A^(K)[K][K]   for j > K (factor 0 for the finished columns j <= K).
-// the same broadcast through the LDS crossbar (ds_swizzle bit mode: lane' = (lane & ~(NP-1) & 0x1f) | K inside each half
-// wavefront): same move count as DPP, other pipe.  RTD_CHOL_SWZ selects it for the trailing updates of the Cholesky steps.
-#ifndef RTD_CHOL_SWZ
-#define RTD_CHOL_SWZ 0  /* A/B: 2.5 % slower than DPP */
-#endif
-template <int NP, int K>
-__device__ __forceinline__ double bcast_lane_lds(double v) {
-  constexpr int pat = (K << 5) | (0x1F & ~(NP - 1));
-  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
-  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
-  return __hiloint2double(hi, lo);
-}
-
 template <int NP, int K, int I>
 struct CholRowDpp {  // col[i] -= bcast_K(col[i]) * f for i = I .. NP - 1, one v_fmac_f64_dpp each
   static __device__ __forceinline__ void run(double (&col)[NP], const double f) {
@@ -254,12 +241,7 @@ struct CholStep {
       CholRowDpp<NP, K, K + 1>::run(col, f);
     } else {
 #pragma unroll
-      for (int i = K + 1; i < NP; ++i) {
-        if constexpr (RTD_CHOL_SWZ && NP <= 16)
-          col[i] = fma(-bcast_lane_lds<NP, K>(col[i]), f, col[i]);
-        else
-          col[i] = fma(-bcast_lane<NP, K>(col[i]), f, col[i]);
-      }
+      for (int i = K + 1; i < NP; ++i) col[i] = fma(-bcast_lane<NP, K>(col[i]), f, col[i]);
     }
     CholStep<NP, K + 1>::run(col, diag, j);
   }

@@ -552,6 +552,23 @@ def test_fused_bc_kernel_pivoted_path_on_goldens():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["RTD_BC_SPLIT", "RTD_EIG_V1"])
+def test_alternative_kernel_paths_stay_correct(switch):
+    """The two runtime switches that select an alternative kernel for A/B runs -- RTD_BC_SPLIT=1: interface operators
+    through HBM + row-per-lane sweep kernel instead of the fused MFMA-layout kernel; RTD_EIG_V1=1: Jacobi sweeps with one
+    column per lane instead of the pair layout -- pass the golden replay, the synthetic configs and the random cases."""
+    import subprocess
+    import sys
+    env = dict(os.environ, **{switch: "1"})
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"),
+                        os.path.join(os.path.dirname(__file__), "test_gpu_random_parity.py"),
+                        "-k", "reference_golden or synthetic_config or random_many or edge_cases"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_high_precision_truth_m0(amd):
     """The HIP path against a 40-digit (mpmath) solution of the m = 0 discrete-ordinate problem computed straight from
     the ODE system (tools/hp_truth_m0.py; fixture tests/golden/hp_truth_m0.npz): a benign six-layer atmosphere and one
