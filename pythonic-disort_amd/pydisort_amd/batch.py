@@ -152,7 +152,7 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
     return sol.mu_arr, sol
 
 
-def solve_columns_streamed(cfg, tau, phi, chunk_columns=0, device=0, only_flux=False):
+def solve_columns_streamed(cfg, tau, phi, chunk_columns=0, device=0, only_flux=False, out=None):
     """Throughput form for large column counts: ONE plan holds the inputs and the results of all columns, the
     intermediates of the solve (~8 MB per cfg4 column) live for `chunk_columns` columns at a time (0: sized by the
     library) and the device-to-host copies of a window overlap the kernels of the next (``Plan.run_fetch``).
@@ -161,6 +161,7 @@ def solve_columns_streamed(cfg, tau, phi, chunk_columns=0, device=0, only_flux=F
     cfg : dict of ``pydisort_batch`` keyword arguments with a leading column axis (tau_arr, omega_arr, Leg_coeffs_all,
           mu0, I0, phi0, optional f_arr, b_pos, b_neg, s_poly_coeffs, bdrf_q, bdrf_q0, NLeg, NFourier); NQuad scalar.
     tau : [C, ntau] evaluation depths; phi : [nphi].
+    out : optional dict of preallocated C-contiguous float64 result arrays to fill (the same keys and shapes).
     Returns dict(u [C, NQuad, ntau, nphi] (absent when only_flux), u0, flux_up, flux_down_diffuse, flux_down_direct)."""
     tau = np.ascontiguousarray(np.asarray(tau, float))
     C, ntau = tau.shape
@@ -172,10 +173,16 @@ def solve_columns_streamed(cfg, tau, phi, chunk_columns=0, device=0, only_flux=F
         phi = np.array([0.0]) if only_flux else np.atleast_1d(np.asarray(phi, float))
         plan.set_eval_points(tau, phi)
         Q = plan.Q
-        out = dict(u0=np.empty((C, Q, ntau)), flux_up=np.empty((C, ntau)), flux_down_diffuse=np.empty((C, ntau)),
-                   flux_down_direct=np.empty((C, ntau)))
+        shapes = dict(u0=(C, Q, ntau), flux_up=(C, ntau), flux_down_diffuse=(C, ntau), flux_down_direct=(C, ntau))
         if not only_flux:
-            out["u"] = np.empty((C, Q, ntau, len(phi)))
+            shapes["u"] = (C, Q, ntau, len(phi))
+        if out is None:
+            out = {k: np.empty(shp) for k, shp in shapes.items()}
+        else:
+            for k, shp in shapes.items():
+                a = out.get(k)
+                if a is None or a.shape != shp or a.dtype != np.float64 or not a.flags["C_CONTIGUOUS"]:
+                    raise ValueError(f"out[{k!r}] must be a C-contiguous float64 array of shape {shp}.")
         plan.run_fetch(out)
     finally:
         plan.close()

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Turns the per-pass summaries of tools/pmc_summary.py (one text file per rocprofv3 --pmc pass) into the JSON that
+bench.py reads for roofline.traffic: HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (both counters are in
+KiB; FETCH_SIZE counts half of the bytes of coalesced streaming reads on gfx950: MI355X_MICROARCH.md, HBM section).
+
+Usage: python tools/pmc_to_json.py out.json "description" pass1.txt pass2.txt ..."""
+import ast
+import json
+import re
+import sys
+
+out, desc, files = sys.argv[1], sys.argv[2], sys.argv[3:]
+kern = {}
+for path in files:
+    for line in open(path):
+        m = re.match(r"(rtd_\w+) grid=(\d+) vgpr=(\d+) (\{.*\}) n=(\d+)", line)
+        if not m:
+            continue
+        k = kern.setdefault(m.group(1), {"grid": int(m.group(2)), "launches_averaged": int(m.group(5))})
+        k.update(ast.literal_eval(m.group(4)))
+total = 0.0
+for name, k in kern.items():
+    if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+        k["hbm_bytes_per_launch"] = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+        total += k["hbm_bytes_per_launch"]
+json.dump({"source": desc,
+           "correction": "FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE doubled (gfx950 reports half of the bytes of "
+                         "coalesced streaming reads); separate --pmc passes for FETCH_SIZE and WRITE_SIZE",
+           "kernels": kern, "total_hbm_bytes_per_step": total}, open(out, "w"), indent=1, sort_keys=True)
+print(out, "total GB per step: %.2f" % (total / 1e9))
