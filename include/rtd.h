@@ -194,6 +194,10 @@ int rtd_plan_enable_timing(rtd_plan* plan, int32_t enable);
  * [5] rtd_sweep_kernel, or the fused rtd_bc_mfma_kernel when 16 < NQuad <= 32 (slot 4 is then empty), [6] rtd_eval_kernel;
  * launches counted in nlaunch[7]. Synchronises. */
 int rtd_plan_get_timing(rtd_plan* plan, double ms[7], int64_t nlaunch[7], int32_t reset);
+/* number of (column, mode) chains of the last window solved whose speculative (diagonal-pivot) elimination failed in
+ * the tiled fused boundary-condition kernel (64 streams) and that the pivoted row-per-lane kernels solved instead
+ * (diagnostic; 0 for other stream counts) */
+int rtd_plan_pivoted_chains(rtd_plan* plan, int32_t* chains);
 /* maximum Jacobi sweeps used by any eigenproblem of the last solve (diagnostic) */
 int rtd_plan_max_sweeps(rtd_plan* plan, int32_t* sweeps);
 

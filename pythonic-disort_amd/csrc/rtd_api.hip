@@ -378,7 +378,7 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
                 Ns = dims->nscoeffs, NB = dims->nbdrf, Q2 = 2 * NP;
   d.C = (int)C; d.L = (int)L; d.N = N; d.NP = (int)NP; d.P = (int)P; d.M = (int)M; d.Ns = (int)Ns;
   d.NBDRF = (int)NB; d.beam = dims->beam ? 1 : 0;
-  d.flags = getenv("RTD_BC_FORCE_PIVOT") ? 1 : 0;
+  d.flags = (getenv("RTD_BC_FORCE_PIVOT") ? 1 : 0) | (getenv("RTD_BC_FORCE_HANDOVER") ? 2 : 0);
   d.m0 = 0; d.mstep = 1; d.mtot = (int)M;
   d.l0 = 0; d.ln = (int)L;
   // window of columns whose intermediates are resident: bytes of intermediates per column
@@ -425,7 +425,7 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
     A(d.Y0, Cw * M * P) A(d.att, Cw * (L + 1))
     A(d.Ym, Cw * M * L * NP * NP) A(d.Am, Cw * M * L * NP * NP) A(d.kk, Cw * M * L * NP) A(d.Bv, Cw * M * L * Q2)
     A(d.dq, Cw * L * Ns * Q2) A(d.zneg, Cw * L * NP) A(d.coef, Cw * M * L * Q2)
-    A(d.Fws, Cw * M * (L - 1) * Q2 * Q2) A(d.Ek, Cw * M * L * NP)
+    A(d.Fws, Cw * M * (L - 1) * Q2 * Q2) A(d.Ek, Cw * M * L * NP) A(d.need_split, Cw * M)
     A(d.sweeps, 1) A(d.status, 1)
 #undef A
     if (pass == 0) {
@@ -1036,6 +1036,24 @@ int rtd_plan_get_timing(rtd_plan* p, double ms[7], int64_t nlaunch[7], int32_t r
       p->nlaunch[k] = 0;
     }
   }
+  return 0;
+}
+
+int rtd_plan_pivoted_chains(rtd_plan* p, int32_t* chains) {
+  if (!p || !chains) return fail(RTD_ERR_ARG, "null argument");
+  *chains = 0;
+  if (p->d.NP != 32 && !getenv("RTD_BC_TILED")) return 0;
+  const size_t n = (size_t)p->Cw * p->d.M;
+  std::vector<int> h(n);
+  HIP_TRY(hipMemcpyAsync(h.data(), p->d.need_split, n * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  int k = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (h[i] != 0) {
+      ++k;
+      if (getenv("RTD_DEBUG")) fprintf(stderr, "[rtd] pivoted chain: column %zu mode %zu\n", i / p->d.M, i % p->d.M);
+    }
+  *chains = k;
   return 0;
 }
 

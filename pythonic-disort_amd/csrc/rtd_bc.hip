@@ -122,7 +122,7 @@ struct Ws {
 // Interface kernel: per (c, m, l < L-1):  Wp, Wq, rho_t, rho_b.
 // ------------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(64) void rtd_iface_kernel(RtdDev d) {
+__global__ __launch_bounds__(64) void rtd_iface_kernel(RtdDev d, const int* only) {  // only != null: flagged (c, m) chains
   constexpr int GPW = 64 / NP, LD = NP + 1, Q = 2 * NP;
   __shared__ double sA[GPW][NP * LD];  // A_l  (natural [i][j])
   __shared__ double sY[GPW][NP * LD];  // Y_l
@@ -130,8 +130,17 @@ __global__ __launch_bounds__(64) void rtd_iface_kernel(RtdDev d) {
   const int Lm1 = d.L - 1;
   const long nprob = (long)d.C * d.M * Lm1;
   long pid = (long)blockIdx.x * GPW + grp;
-  const bool valid = pid < nprob;
+  bool valid = pid < nprob;
   if (!valid) pid = nprob - 1;
+  if (only != nullptr) {  // only the chains handed over by the tiled kernel: the others keep what that kernel stored
+    valid = valid && only[pid / Lm1] != 0;
+    const unsigned long long want = __ballot(valid);
+    if (want == 0) return;
+    // groups with nothing to do redo the work of one that has (well-defined data, no stores)
+    const int src = __ffsll((long long)want) - 1;
+    const int pid_w = __shfl((int)pid, src, 64);
+    if (!valid) pid = pid_w;
+  }
   const int l = (int)(pid % Lm1);
   const long cm = pid / Lm1;
   const int m = (int)(cm % d.M), c = (int)(cm / d.M);
@@ -397,7 +406,7 @@ struct GjStep<NP, NB, NP> {
 // Sweep kernel: per (c, m): forward carry recursion over the layers, bottom BC, backward sweep.
 // ------------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1))) void rtd_sweep_kernel(RtdDev d) {
+__global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1))) void rtd_sweep_kernel(RtdDev d, const int* only) {
   constexpr int GPW = 64 / NP, LD = NP + 1, Q = 2 * NP;
   __shared__ double sA[GPW][NP * LD];  // Wq (forward) / S (bottom)
   __shared__ double sB[GPW][NP * LD];  // Wp
@@ -405,8 +414,18 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
   const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
   const long nprob = (long)d.C * d.M;
   long cm = (long)blockIdx.x * GPW + grp;
-  const bool valid = cm < nprob;
+  bool valid = cm < nprob;
   if (!valid) cm = nprob - 1;
+  if (only != nullptr) {  // only the chains handed over by the tiled kernel: the others keep what that kernel stored
+    valid = valid && only[cm] != 0;
+    const unsigned long long want = __ballot(valid);
+    if (want == 0) return;
+    // groups with nothing to do redo the work of one that has (well-defined data -- their own interface operators were
+    // not formed -- and no stores)
+    const int src = __ffsll((long long)want) - 1;
+    const int cm_w = __shfl((int)cm, src, 64);
+    if (!valid) cm = cm_w;
+  }
   const int m = (int)(cm % d.M), c = (int)(cm / d.M);
   const int L = d.L, Lm1 = L - 1;
   double* A_ = sA[grp];
@@ -1215,11 +1234,656 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
   if (!(fabs(cminus) + fabs(cplus) < 1e300)) atomicOr(d.status, RTD_ST_BC);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fused boundary-condition kernel for NP = 16 T streams per hemisphere (T x T tiles of 16 x 16, each in the D layout):
+// the 64-stream form (T = 2) of rtd_bc_mfma_kernel -- same recursion, same speculative column elimination, one
+// wavefront per (column, mode); a 32 x 32 matrix is 16 doubles per lane, so the kernel is compiled for one wavefront per
+// SIMD and prefetches the next layer's operands behind the elimination.  An elimination whose speculation fails is redone
+// column-pivoted on an LDS copy of its inputs; a chain that still cannot be solved (singular carry block) raises its flag
+// in `need_split` and leaves, and the row-per-lane kernels (rtd_iface_kernel / rtd_sweep_kernel, partial pivoting) solve
+// the flagged chains afterwards.  T = 1 reproduces the
+// arithmetic of rtd_bc_mfma_kernel (used as a cross-check of this generalisation in the tests, RTD_BC_TILED=1).
+// ------------------------------------------------------------------------------------------------
+// Growth threshold of the tiled kernel's speculative elimination.  A flagged chain is expensive here: it is redone as a
+// whole by the row-per-lane kernels, whose latency per chain (50 layers x 32 pivoted steps) is that of a whole launch.
+// On cfg5 (128 columns = 8 192 chains): threshold 64 flags 507 chains (the pivoted kernels then cost what they cost for all
+// chains, 15 ms), 1e3: 189, 1e5: 4 (2.8 ms), 1e8: none; the error against the reference goldens is 2.19e-10 of the field
+// scale at every one of them (the row-per-lane path alone: 2.1e-9).  1e6 bounds the relative perturbation of a step by
+// ~1e-10; zero pivots and overflow still go to the pivoted kernels through the non-finite check.
+#ifndef RTD_GJ_GROWTH_TILED
+#define RTD_GJ_GROWTH_TILED 1e6
+#endif
+template <int T> struct MatT { v4f64 t[T][T]; };  // t[I][J][q] at lane (kq, col) = element [16 I + 4 q + kq][16 J + col]
+template <int T> struct RowT { v4f64 r[T]; };     // vector in row form:    r[I][q] = v[16 I + 4 q + kq], same in every column
+template <int T> struct ColT { double c[T]; };    // vector in column form: c[J] = v[16 J + col], same in every lane-row
+
+template <int T>
+__device__ __forceinline__ MatT<T> mmT(const MatT<T>& X, const MatT<T>& Y) {  // X^T Y
+  MatT<T> R;
+#pragma unroll
+  for (int I = 0; I < T; ++I)
+#pragma unroll
+    for (int J = 0; J < T; ++J) {
+      v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int K = 0; K < T; ++K)
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X.t[K][I][sidx], Y.t[K][J][sidx], acc, 0, 0, 0);
+      R.t[I][J] = acc;
+    }
+  return R;
+}
+template <int T>
+__device__ __forceinline__ ColT<T> col_dotT(const MatT<T>& X, const RowT<T>& v) {  // X^T v
+  ColT<T> o;
+#pragma unroll
+  for (int J = 0; J < T; ++J) {
+    double a = 0.0;
+#pragma unroll
+    for (int I = 0; I < T; ++I) a += X.t[I][J][0] * v.r[I][0] + X.t[I][J][1] * v.r[I][1] + X.t[I][J][2] * v.r[I][2] + X.t[I][J][3] * v.r[I][3];
+    o.c[J] = sum_kq(a);
+  }
+  return o;
+}
+template <int T>
+__device__ __forceinline__ RowT<T> row_dotT(const MatT<T>& X, const ColT<T>& v) {  // X v
+  RowT<T> o;
+#pragma unroll
+  for (int I = 0; I < T; ++I)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double a = 0.0;
+#pragma unroll
+      for (int J = 0; J < T; ++J) a += X.t[I][J][q] * v.c[J];
+      o.r[I][q] = row_sum16(a);
+    }
+  return o;
+}
+template <int T>
+__device__ __forceinline__ RowT<T> col_to_rowT(const ColT<T>& v, const int rowbase, const int kq) {
+  RowT<T> o;
+#pragma unroll
+  for (int I = 0; I < T; ++I) o.r[I] = col_to_row(v.c[I], rowbase, kq);
+  return o;
+}
+
+template <int T, int K>
+struct GjFastT {
+  static __device__ __forceinline__ void run(MatT<T>& ta, MatT<T>& tb, ColT<T>& tv, int& bad, const int col) {
+    constexpr int KI = K >> 4, K16 = K & 15, QK = K16 >> 2, RK = K16 & 3;
+    double x[T], f[T];
+#pragma unroll
+    for (int J = 0; J < T; ++J) x[J] = bcast_row<RK>(ta.t[KI][J][QK], col);  // row K of Ta^T, replicated over the lane-rows
+    const double xk = bcast16<K16>(x[KI]);
+    const double r0 = __builtin_amdgcn_rcp(xk);
+    const double rp = r0 * (2.0 - xk * r0);
+#pragma unroll
+    for (int J = 0; J < T; ++J) {
+      f[J] = (J == KI && col == K16) ? 1.0 - rp : x[J] * rp;
+      bad |= (16 * J + col > K && fabs(f[J]) > RTD_GJ_GROWTH_TILED) ? 1 : 0;
+    }
+    // v[J] -= f[J] bcast(v[KI]) for every register row v of [Ta^T ; Tb^T ; t^T] that is not finished, the pivot tile column
+    // last (it is the source of the others); one v_fmac_f64_dpp each (see GjFast for the hazard notes)
+    // (ext-vector elements cannot be bound to asm operands by reference: copy in, update, copy out -- registers all the way)
+#define RTD_UPD(VEC, Q, SRC, FJ)                                                                                              \
+  {                                                                                                                           \
+    double t_ = VEC[Q];                                                                                                       \
+    const double s_ = SRC;                                                                                                    \
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(t_) : "v"(s_), "v"(FJ), "n"(K16)); \
+    VEC[Q] = t_;                                                                                                              \
+  }
+#define RTD_UPD_SELF(VEC, Q, FJ)                                                                                              \
+  {                                                                                                                           \
+    double t_ = VEC[Q];                                                                                                       \
+    asm volatile("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(t_) : "v"(FJ), "n"(K16));    \
+    VEC[Q] = t_;                                                                                                              \
+  }
+#pragma unroll
+    for (int I = KI; I < T; ++I)
+#pragma unroll
+      for (int q = (I == KI ? QK : 0); q < 4; ++q) {
+#pragma unroll
+        for (int J = 0; J < T; ++J)
+          if (J != KI) RTD_UPD(ta.t[I][J], q, ta.t[I][KI][q], f[J])
+        RTD_UPD_SELF(ta.t[I][KI], q, f[KI])
+      }
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int J = 0; J < T; ++J)
+          if (J != KI) RTD_UPD(tb.t[I][J], q, tb.t[I][KI][q], f[J])
+        RTD_UPD_SELF(tb.t[I][KI], q, f[KI])
+      }
+#pragma unroll
+    for (int J = 0; J < T; ++J)
+      if (J != KI) RTD_UPD(tv.c, J, tv.c[KI], f[J])
+    {
+      double t_ = tv.c[KI];
+      asm volatile("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(t_) : "v"(f[KI]), "n"(K16));
+      tv.c[KI] = t_;
+    }
+#undef RTD_UPD
+#undef RTD_UPD_SELF
+    if constexpr (K + 1 < 16 * T) GjFastT<T, K + 1>::run(ta, tb, tv, bad, col);
+  }
+};
+
+template <int T>
+__global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDev d, int* need_split) {
+  constexpr int NP = 16 * T, Q = 2 * NP, NN = NP * NP;
+  const int lane = threadIdx.x, kq = lane >> 4, col = lane & 15, rowbase = lane & 48;
+  const long cm = blockIdx.x;
+  const int m = (int)(cm % d.M), c = (int)(cm / d.M);
+  const int L = d.L, Lm1 = L - 1;
+  const double* Ym = d.Ym + cm * L * NN;
+  const double* Am = d.Am + cm * L * NN;
+  const double* kk = d.kk + cm * L * NP;
+  const double* Ek = d.Ek + cm * L * NP;
+  const double* Bv = d.Bv + cm * L * Q;
+  const double* ts0 = d.taus0 + (long)c * (L + 1);
+  const double* dq = d.dq + (long)c * L * d.Ns * Q;
+  double* wsb = d.Fws + cm * Lm1 * Ws<NP>::SLOT;
+  double* coef = d.coef + cm * L * Q;
+  const int mg = d.m0 + d.mstep * m;
+  const bool iso = d.Ns > 0 && mg == 0;
+  const bool beam = d.beam != 0;
+  const double mu0 = beam ? d.mu0[c] : 1.0;
+  if ((d.flags & 2) && cm % 3 == 0) {  // test hook (RTD_BC_FORCE_HANDOVER): every third chain goes to the pivoted kernels
+    if (lane == 0) need_split[cm] = 1;
+    return;
+  }
+  auto vpoly = [&](int l, double t, int idx) {
+    double a = 0.0, tp = 1.0;
+    for (int q = 0; q < d.Ns; ++q) {
+      a += dq[((long)l * d.Ns + q) * Q + idx] * tp;
+      tp *= t;
+    }
+    return a;
+  };
+  auto load_d = [](const double* p, const int kq, const int col) {  // row-major NP x NP matrix -> tiles in the D layout
+    MatT<T> x;
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+      for (int J = 0; J < T; ++J)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x.t[I][J][q] = p[(16 * I + 4 * q + kq) * NP + 16 * J + col];
+    return x;
+  };
+  auto load_row = [](const double* p, const int kq) {
+    RowT<T> x;
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x.r[I][q] = p[16 * I + 4 * q + kq];
+    return x;
+  };
+  auto load_col = [](const double* p, const int col) {
+    ColT<T> x;
+#pragma unroll
+    for (int J = 0; J < T; ++J) x.c[J] = p[16 * J + col];
+    return x;
+  };
+  auto make_eye = [](const int kq, const int col) {
+    MatT<T> e;
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+      for (int J = 0; J < T; ++J)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e.t[I][J][q] = (I == J && 4 * q + kq == col) ? 1.0 : 0.0;
+    return e;
+  };
+  auto fail_chain = [&]() {  // this chain could not be solved here: hand it to the row-per-lane kernels
+    if (lane == 0) need_split[cm] = 1;
+  };
+  // The inputs of the running elimination, row-major [2 NP + 1][NP] (+1 padding): read back only when its speculation fails.
+  // Then the same elimination is done once more, column-pivoted, straight on this LDS copy: every lane owns a row (rows
+  // lane and lane + 64), a step reads the pivot row, picks the largest unused column, and every lane updates its row.
+  // Slow (~25 us) and rare (1 of 8 192 chains x 50 layers on cfg5 at the growth threshold used).
+  constexpr int LDM = NP + 1, NROW = 2 * NP + 1;
+  __shared__ double sM[NROW * LDM];
+  __shared__ double sF[NP];
+  __shared__ int sPerm[NP];
+  auto save_inputs = [&](const MatT<T>& xa, const MatT<T>& xb, const ColT<T>& xv, const int kq, const int col) {
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+      for (int J = 0; J < T; ++J)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          sM[(16 * I + 4 * q + kq) * LDM + 16 * J + col] = xa.t[I][J][q];
+          sM[(NP + 16 * I + 4 * q + kq) * LDM + 16 * J + col] = xb.t[I][J][q];
+        }
+    if (kq == 0)
+#pragma unroll
+      for (int J = 0; J < T; ++J) sM[2 * NP * LDM + 16 * J + col] = xv.c[J];
+  };
+  // -> false when the matrix is singular (no usable pivot); on success xb, xv hold Tb^T Ta^-T and t^T Ta^-T, columns in
+  //    their natural order
+  auto pivoted_redo = [&](MatT<T>& xb, ColT<T>& xv, const int kq, const int col) -> bool {
+    __syncthreads();
+    unsigned long long used = 0;
+    bool ok = true;
+    for (int K = 0; K < NP; ++K) {
+      float key = (lane < NP && !((used >> lane) & 1ull)) ? fabsf((float)sM[K * LDM + lane]) : -1.0f;
+      int idx = lane;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {  // wave argmax
+        const float k2 = __shfl_xor(key, o, 64);
+        const int i2 = __shfl_xor(idx, o, 64);
+        if (k2 > key || (k2 == key && i2 < idx)) {
+          key = k2;
+          idx = i2;
+        }
+      }
+      const int pcol = idx;
+      if (!(key > 0.0f)) ok = false;
+      used |= 1ull << pcol;
+      const double piv = sM[K * LDM + pcol];
+      const double rp = 1.0 / piv;
+      if (lane < NP) sF[lane] = (lane == pcol) ? 0.0 : sM[K * LDM + lane] * rp;
+      if (lane == 0) sPerm[K] = pcol;
+      __syncthreads();
+      for (int row = lane; row < NROW; row += 64) {
+        double* r = sM + row * LDM;
+        const double mp = r[pcol];
+        for (int jj = 0; jj < NP; ++jj) r[jj] -= sF[jj] * mp;
+        r[pcol] = mp * rp;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int J = 0; J < T; ++J) {
+      const int src = sPerm[16 * J + col];  // unknown 16 J + col sits in the column that was the pivot of step 16 J + col
+#pragma unroll
+      for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xb.t[I][J][q] = sM[(NP + 16 * I + 4 * q + kq) * LDM + src];
+      xv.c[J] = sM[2 * NP * LDM + src];
+    }
+    __syncthreads();
+    return ok;
+  };
+
+  MatT<T> a0 = load_d(Am, kq, col), y0 = load_d(Ym, kq, col);
+  const int lsecond = min(1, Lm1);
+  MatT<T> a1 = load_d(Am + (long)lsecond * NN, kq, col), y1 = load_d(Ym + (long)lsecond * NN, kq, col);
+  ColT<T> k0c = load_col(kk, col), k1c = load_col(kk + lsecond * NP, col);
+  ColT<T> rT_col;
+  {
+    const ColT<T> tc = load_col(d.T, col);
+#pragma unroll
+    for (int J = 0; J < T; ++J) rT_col.c[J] = fast_rcp(tc.c[J]);
+  }
+  // carry rows (transposed): top boundary, down-streams at tau = 0 (:161-179, :284-285):
+  //   Ta = Gm_0 = (Y + A/k)/T-rows,  Tb = Gp_0 E_0 = (Y - A/k)/T-rows E_0
+  MatT<T> ta, tb;
+  {
+    const MatT<T> eye = make_eye(kq, col);
+    const MatT<T> yt = mmT<T>(y0, eye), at = mmT<T>(a0, eye);
+    const RowT<T> k_row = load_row(kk, kq), e_row = load_row(Ek, kq);
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+      for (int J = 0; J < T; ++J)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double av = at.t[I][J][q] * fast_rcp(k_row.r[I][q]);
+          ta.t[I][J][q] = (yt.t[I][J][q] + av) * rT_col.c[J];
+          tb.t[I][J][q] = (yt.t[I][J][q] - av) * rT_col.c[J] * e_row.r[I][q];
+        }
+  }
+  ColT<T> tv = load_col(d.bneg + cm * NP, col);
+  if (beam) {
+    const ColT<T> b = load_col(Bv + NP, col);
+#pragma unroll
+    for (int J = 0; J < T; ++J) tv.c[J] -= b.c[J];
+  }
+  if (iso) {
+    const ColT<T> b = load_col(dq + NP, col);
+#pragma unroll
+    for (int J = 0; J < T; ++J) tv.c[J] -= b.c[J];
+  }
+
+  for (int l = 0; l < L; ++l) {
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const int kq = lv >> 4, col = lv & 15, rowbase = lv & 48;
+    const int ln = min(l + 1, Lm1), l2 = min(l + 2, Lm1);
+    // layer l+2's operands: consumed by the NEXT iteration (one wavefront per SIMD: nothing else hides their latency)
+    const MatT<T> a2 = load_d(Am + (long)l2 * NN, kq, col), y2 = load_d(Ym + (long)l2 * NN, kq, col);
+    const ColT<T> k2c = load_col(kk + l2 * NP, col);
+    const ColT<T> e0c = load_col(Ek + l * NP, col);
+    const RowT<T> e1r = load_row(Ek + ln * NP, kq);
+    // ---- elimination: [Ta^T ; Tb^T ; t^T] -> H = S^T (in tb), s (in tv)
+    {
+      save_inputs(ta, tb, tv, kq, col);
+      int bad = d.flags & 1;  // test hook (RTD_BC_FORCE_PIVOT): every elimination takes the pivoted redo
+      if (!bad) GjFastT<T, 0>::run(ta, tb, tv, bad, col);
+      auto finite = [&]() {
+        double chk = 0.0;
+#pragma unroll
+        for (int J = 0; J < T; ++J) {
+          chk += fabs(tv.c[J]);
+#pragma unroll
+          for (int I = 0; I < T; ++I) chk += fabs(tb.t[I][J][0]) + fabs(tb.t[I][J][1]) + fabs(tb.t[I][J][2]) + fabs(tb.t[I][J][3]);
+        }
+        return chk < 1e300;
+      };
+      bad |= finite() ? 0 : 1;  // zero pivot: inf / nan
+      if (__any(bad)) {  // some diagonal pivot was too small: the pivoted elimination from the saved inputs
+        const bool ok = pivoted_redo(tb, tv, kq, col);
+        if (__any(!ok || !finite())) {
+          fail_chain();
+          return;
+        }
+      }
+    }
+    if (l == Lm1) break;
+    double* ws = wsb + (long)l * Ws<NP>::SLOT;
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+      for (int J = 0; J < T; ++J)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ws[Ws<NP>::S + (16 * I + 4 * q + kq) * NP + 16 * J + col] = tb.t[I][J][q];
+    if (kq == 0)
+#pragma unroll
+      for (int J = 0; J < T; ++J) ws[Ws<NP>::SV + 16 * J + col] = tv.c[J];
+    // ---- particular-solution jump r_l at the interface (:184-205, :242-245) and rho = G_l^-1 r_l:
+    //   rho_t/b = 1/4 [ V^-1 (r_up + r_dn) +- U^-1 (r_up - r_dn) ],  V^-1[j][i] = T_i A[i][j],  U^-1[j][i] = -k_j T_i Y[i][j]
+    MatT<T> y0s, a1s;
+#pragma unroll
+    for (int J = 0; J < T; ++J) {
+      const double rk1 = fast_rcp(k1c.c[J]);
+#pragma unroll
+      for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          y0s.t[I][J][q] = y0.t[I][J][q] * k0c.c[J];
+          a1s.t[I][J][q] = a1.t[I][J][q] * rk1;
+        }
+    }
+    ColT<T> rt, rb;
+    {
+      const double tbnd = ts0[l + 1];
+      const double att = beam ? d.att[(long)c * (L + 1) + l + 1] : 0.0;
+      const RowT<T> t_row = load_row(d.T, kq);
+      RowT<T> vs, vd;  // T (r_up + r_dn), -T (r_up - r_dn) in row form
+#pragma unroll
+      for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = 16 * I + 4 * q + kq;
+          double ru = 0.0, rd = 0.0;
+          if (beam) {
+            ru = (Bv[ln * Q + i] - Bv[l * Q + i]) * att;
+            rd = (Bv[ln * Q + NP + i] - Bv[l * Q + NP + i]) * att;
+          }
+          if (iso) {
+            ru += vpoly(l + 1, tbnd, i) - vpoly(l, tbnd, i);
+            rd += vpoly(l + 1, tbnd, NP + i) - vpoly(l, tbnd, NP + i);
+          }
+          vs.r[I][q] = t_row.r[I][q] * (ru + rd);
+          vd.r[I][q] = -t_row.r[I][q] * (ru - rd);
+        }
+#pragma unroll
+      for (int J = 0; J < T; ++J) {
+        double pa = 0.0, pb = 0.0;
+#pragma unroll
+        for (int I = 0; I < T; ++I)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            pa += a0.t[I][J][q] * vs.r[I][q];
+            pb += y0s.t[I][J][q] * vd.r[I][q];
+          }
+        rt.c[J] = 0.25 * sum_kq(pa + pb);
+        rb.c[J] = 0.25 * sum_kq(pa - pb);
+      }
+      if (kq == 0)
+#pragma unroll
+        for (int J = 0; J < T; ++J) ws[Ws<NP>::RB + 16 * J + col] = rb.c[J];
+    }
+    // ---- carry of the next layer:  Ta'^T = -(Wq^T H E + Wp^T),  Tb'^T = -E' (Wp^T H E + Wq^T)  with
+    //      Wp/Wq = (M1 +- M2s)/2, M1 = A_l^T Y', M2s = diag(k) Y_l^T A' diag(1/k'):  X = M1^T H E, Z = M2s^T H E;
+    //      t' = rho_t - E (s - S rho_b).  Products are formed and consumed one after the other (registers).
+    ColT<T> tnew;
+    {
+      const ColT<T> srb = col_dotT<T>(tb, col_to_rowT<T>(rb, rowbase, kq));
+#pragma unroll
+      for (int J = 0; J < T; ++J) tnew.c[J] = rt.c[J] - e0c.c[J] * (tv.c[J] - srb.c[J]);
+    }
+    MatT<T> he;
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+      for (int J = 0; J < T; ++J)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) he.t[I][J][q] = tb.t[I][J][q] * e0c.c[J];
+    MatT<T> s1;  // X + M1^T
+    {
+      const MatT<T> m1 = mmT<T>(a0, y1);
+      const MatT<T> xx = mmT<T>(m1, he);
+      const MatT<T> m1t = mmT<T>(y1, a0);
+#pragma unroll
+      for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int J = 0; J < T; ++J)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s1.t[I][J][q] = xx.t[I][J][q] + m1t.t[I][J][q];
+    }
+    {
+      const MatT<T> m2s = mmT<T>(y0s, a1s);
+      const MatT<T> zz = mmT<T>(m2s, he);
+      const MatT<T> m2st = mmT<T>(a1s, y0s);
+#pragma unroll
+      for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int J = 0; J < T; ++J)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const double dd = zz.t[I][J][q] - m2st.t[I][J][q];
+            ta.t[I][J][q] = -0.5 * (s1.t[I][J][q] - dd);
+            tb.t[I][J][q] = -0.5 * (s1.t[I][J][q] + dd) * e1r.r[I][q];
+          }
+    }
+    tv = tnew;
+    a0 = a1;
+    y0 = y1;
+    a1 = a2;
+    y1 = y2;
+    k0c = k1c;
+    k1c = k2c;
+  }
+
+  // ---- bottom boundary (up-streams at tau_L) (:208-232, :248-254, :288-293):  Ba C- + Bb C+ = br,
+  //      with C- = s - S C+  ->  (Bb - Ba S) C+ = br - Ba s;  Ba = [(I - R) P0 - (I + R) Q0] E_L, Bb = (I - R) P0 + (I + R) Q0,
+  //      P0 = Y/T-rows, Q0 = A/(k T-rows), R = (1 + delta_m0) q (mu w).  Solved transposed like the carry.
+  ColT<T> cminus, cplus;
+  {
+    const int l = Lm1;
+    const RowT<T> eLr = load_row(Ek + l * NP, kq), t_row = load_row(d.T, kq);
+    const ColT<T> kLc = load_col(kk + l * NP, col);
+    const MatT<T> eye = make_eye(kq, col);
+    MatT<T> p0, q0, x1 = eye, x2 = eye, rtr;
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+      for (int J = 0; J < T; ++J)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double rTr = fast_rcp(t_row.r[I][q]);
+          p0.t[I][J][q] = y0.t[I][J][q] * rTr;
+          q0.t[I][J][q] = a0.t[I][J][q] * rTr * fast_rcp(kLc.c[J]);
+          rtr.t[I][J][q] = 0.0;
+        }
+    const bool refl = mg < d.NBDRF;
+    if (refl) {
+      const double delta = (mg == 0) ? 2.0 : 1.0;
+#pragma unroll
+      for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int J = 0; J < T; ++J)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int j2 = 16 * I + 4 * q + kq, j = 16 * J + col;  // R^T in the D layout: [row j2][col j] = R[j][j2]
+            const double r = delta * d.bdrfq[(((long)c * d.NBDRF + mg) * NP + j) * NP + j2] * d.mu[j2] * d.w[j2];
+            rtr.t[I][J][q] = r;
+            x1.t[I][J][q] -= r;
+            x2.t[I][J][q] += r;
+          }
+    }
+    const MatT<T> g1 = mmT<T>(p0, x1), g2 = mmT<T>(q0, x2);  // ((I - R) P0)^T, ((I + R) Q0)^T
+    MatT<T> bat, mt;
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+      for (int J = 0; J < T; ++J)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          bat.t[I][J][q] = eLr.r[I][q] * (g1.t[I][J][q] - g2.t[I][J][q]);
+          mt.t[I][J][q] = g1.t[I][J][q] + g2.t[I][J][q];
+        }
+    {
+      const MatT<T> sd = mmT<T>(tb, eye);   // S in the D layout
+      const MatT<T> hb = mmT<T>(sd, bat);   // S^T Ba^T
+#pragma unroll
+      for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int J = 0; J < T; ++J)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) mt.t[I][J][q] -= hb.t[I][J][q];  // (Bb - Ba S)^T
+    }
+    ColT<T> br = load_col(d.bpos + cm * NP, col);
+    const double tL = ts0[L];
+    const double att = beam ? d.att[(long)c * (L + 1) + L] : 0.0;
+    if (refl) {
+      if (beam) {
+        const ColT<T> rbm = col_dotT<T>(rtr, load_row(Bv + l * Q + NP, kq));
+#pragma unroll
+        for (int J = 0; J < T; ++J) {
+          const double Xs = mu0 * d.I0[c] / M_PI * d.bdrfq0[((long)c * d.NBDRF + mg) * NP + 16 * J + col];
+          br.c[J] += (Xs + rbm.c[J] - Bv[l * Q + 16 * J + col]) * att;
+        }
+      }
+      if (iso) {
+        RowT<T> vr;
+#pragma unroll
+        for (int I = 0; I < T; ++I)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) vr.r[I][q] = vpoly(l, tL, NP + 16 * I + 4 * q + kq);
+        const ColT<T> rv = col_dotT<T>(rtr, vr);
+#pragma unroll
+        for (int J = 0; J < T; ++J) br.c[J] += rv.c[J] - vpoly(l, tL, 16 * J + col);
+      }
+    } else {
+#pragma unroll
+      for (int J = 0; J < T; ++J) {
+        if (beam) br.c[J] -= Bv[l * Q + 16 * J + col] * att;
+        if (iso) br.c[J] -= vpoly(l, tL, 16 * J + col);
+      }
+    }
+    ColT<T> rhs;
+    {
+      const ColT<T> bs = col_dotT<T>(bat, col_to_rowT<T>(tv, rowbase, kq));
+#pragma unroll
+      for (int J = 0; J < T; ++J) rhs.c[J] = br.c[J] - bs.c[J];
+    }
+    {
+      MatT<T> none;
+#pragma unroll
+      for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int J = 0; J < T; ++J) none.t[I][J] = v4f64{0.0, 0.0, 0.0, 0.0};
+      save_inputs(mt, none, rhs, kq, col);
+      int bad = d.flags & 1;
+      if (!bad) GjFastT<T, 0>::run(mt, none, rhs, bad, col);  // (the updates of the zero block cost 16 T^2 FMAs per step: once per chain)
+      auto finite = [&]() {
+        double chk = 0.0;
+#pragma unroll
+        for (int J = 0; J < T; ++J) chk += fabs(rhs.c[J]);
+        return chk < 1e300;
+      };
+      bad |= finite() ? 0 : 1;
+      if (__any(bad)) {
+        const bool ok = pivoted_redo(none, rhs, kq, col);
+        if (__any(!ok || !finite())) {
+          fail_chain();
+          return;
+        }
+      }
+    }
+    cplus = rhs;
+    {
+      const ColT<T> sc = col_dotT<T>(tb, col_to_rowT<T>(cplus, rowbase, kq));
+#pragma unroll
+      for (int J = 0; J < T; ++J) cminus.c[J] = tv.c[J] - sc.c[J];
+    }
+    if (kq == 0)
+#pragma unroll
+      for (int J = 0; J < T; ++J) {
+        coef[(long)l * Q + 16 * J + col] = cminus.c[J];
+        coef[(long)l * Q + NP + 16 * J + col] = cplus.c[J];
+      }
+  }
+  // ---- backward sweep: C+_l = Wq C-' + Wp E' C+' + rho_b ;  C-_l = s_l - S_l C+_l, with W applied through its factors
+  //      Wq x + Wp y = [A_l^T Y' (x + y) + k_l Y_l^T A' ((y - x)/k')] / 2
+  a1 = a0;
+  y1 = y0;
+  ColT<T> k1b = load_col(kk + Lm1 * NP, col), e1b = load_col(Ek + Lm1 * NP, col);
+  for (int l = Lm1 - 1; l >= 0; --l) {
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const int kq = lv >> 4, col = lv & 15, rowbase = lv & 48;
+    const double* ws = wsb + (long)l * Ws<NP>::SLOT;
+    a0 = load_d(Am + (long)l * NN, kq, col);
+    y0 = load_d(Ym + (long)l * NN, kq, col);
+    const MatT<T> hl = load_d(ws + Ws<NP>::S, kq, col);
+    const ColT<T> sl = load_col(ws + Ws<NP>::SV, col), rb = load_col(ws + Ws<NP>::RB, col);
+    const ColT<T> k0b = load_col(kk + l * NP, col), e0b = load_col(Ek + l * NP, col);
+    ColT<T> xpy, ymx;
+#pragma unroll
+    for (int J = 0; J < T; ++J) {
+      const double x = cminus.c[J], y = e1b.c[J] * cplus.c[J];
+      xpy.c[J] = x + y;
+      ymx.c[J] = (y - x) * fast_rcp(k1b.c[J]);
+    }
+    const RowT<T> w1 = row_dotT<T>(y1, xpy), w2 = row_dotT<T>(a1, ymx);
+    const ColT<T> t1 = col_dotT<T>(a0, w1), t2 = col_dotT<T>(y0, w2);
+    ColT<T> cp;
+#pragma unroll
+    for (int J = 0; J < T; ++J) cp.c[J] = rb.c[J] + 0.5 * (t1.c[J] + k0b.c[J] * t2.c[J]);
+    const ColT<T> hc = col_dotT<T>(hl, col_to_rowT<T>(cp, rowbase, kq));
+#pragma unroll
+    for (int J = 0; J < T; ++J) cminus.c[J] = sl.c[J] - hc.c[J];
+    cplus = cp;
+    if (kq == 0)
+#pragma unroll
+      for (int J = 0; J < T; ++J) {
+        coef[(long)l * Q + 16 * J + col] = cminus.c[J];
+        coef[(long)l * Q + NP + 16 * J + col] = cplus.c[J];
+      }
+    a1 = a0;
+    y1 = y0;
+    k1b = k0b;
+    e1b = e0b;
+  }
+  double chk = 0.0;
+#pragma unroll
+  for (int J = 0; J < T; ++J) chk += fabs(cminus.c[J]) + fabs(cplus.c[J]);
+  if (!(chk < 1e300)) atomicOr(d.status, RTD_ST_BC);
+}
+
 }  // namespace
 
 bool rtd_bc_fuses_eval(const RtdDev& d) {
-  static const bool split = getenv("RTD_BC_SPLIT") != nullptr;
-  return d.NP == 16 && !split;
+  static const bool split = getenv("RTD_BC_SPLIT") != nullptr, tiled = getenv("RTD_BC_TILED") != nullptr;
+  return d.NP == 16 && !split && !tiled;
 }
 
 void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
@@ -1228,31 +1892,56 @@ void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
   const long nif = (long)d.C * d.M * (d.L - 1);
   const dim3 gi((unsigned)((nif + gpw - 1) / gpw));
   const dim3 gs((unsigned)(((long)d.C * d.M + gpw - 1) / gpw));
-#define RTD_BC_CASE(NPV)                                                                             \
-  case NPV:                                                                                          \
-    if (part == 0 && nif > 0) hipLaunchKernelGGL(rtd_iface_kernel<NPV>, gi, dim3(64), 0, s, d);      \
-    if (part == 1) hipLaunchKernelGGL(rtd_sweep_kernel<NPV>, gs, dim3(64), 0, s, d);                 \
+  const dim3 gc((unsigned)((long)d.C * d.M));
+  // RTD_BC_SPLIT=1: the two-kernel path for every stream count (A/B runs and a regression test);
+  // RTD_BC_TILED=1: the tiled fused kernel also at NP = 16 (T = 1: cross-check of the 64-stream kernel's generalisation)
+  static const bool split = getenv("RTD_BC_SPLIT") != nullptr, tiled16 = getenv("RTD_BC_TILED") != nullptr;
+  const int* none = nullptr;
+#define RTD_BC_CASE(NPV)                                                                                    \
+  case NPV:                                                                                                 \
+    if (part == 0 && nif > 0) hipLaunchKernelGGL(rtd_iface_kernel<NPV>, gi, dim3(64), 0, s, d, none);       \
+    if (part == 1) hipLaunchKernelGGL(rtd_sweep_kernel<NPV>, gs, dim3(64), 0, s, d, none);                  \
     break;
+  // fused tiled kernel first (part 0); the chains whose speculative elimination failed raise need_split and are solved by
+  // the pivoted row-per-lane kernels (part 1), which leave at once when none of their chains is flagged
+#define RTD_BC_TILED_CASE(NPV, TV)                                                                          \
+  if (part == 0) {                                                                                          \
+    (void)hipMemsetAsync(d.need_split, 0, sizeof(int) * (size_t)d.C * d.M, s);                              \
+    hipLaunchKernelGGL(rtd_bc_tile_kernel<TV>, gc, dim3(64), 0, s, d, d.need_split);                        \
+  } else {                                                                                                  \
+    if (nif > 0) hipLaunchKernelGGL(rtd_iface_kernel<NPV>, gi, dim3(64), 0, s, d, (const int*)d.need_split); \
+    hipLaunchKernelGGL(rtd_sweep_kernel<NPV>, gs, dim3(64), 0, s, d, (const int*)d.need_split);             \
+  }
   switch (d.NP) {
     RTD_BC_CASE(4)
     RTD_BC_CASE(8)
     case 16: {
-      // default: the fused MFMA kernel (launched as part 1; part 0 is empty).  RTD_BC_SPLIT=1 selects the two-kernel
-      // path (interface operators through HBM: A/B runs and a regression test).
-      static const bool split = getenv("RTD_BC_SPLIT") != nullptr;
+      // default: the fused MFMA kernel (launched as part 1; part 0 is empty)
+      if (tiled16 && !split) {
+        RTD_BC_TILED_CASE(16, 1)
+        break;
+      }
       if (!split) {
-        if (part == 1) hipLaunchKernelGGL(rtd_bc_mfma_kernel, dim3((unsigned)((long)d.C * d.M)), dim3(64), 0, s, d);
+        if (part == 1) hipLaunchKernelGGL(rtd_bc_mfma_kernel, gc, dim3(64), 0, s, d);
         break;
       }
       if (part == 0 && nif > 0)
         hipLaunchKernelGGL(rtd_iface_mfma_kernel,
                            dim3((unsigned)(((long)d.C * d.M * ((d.L - 1 + IFACE_CHUNK - 1) / IFACE_CHUNK) + 3) / 4)),
                            dim3(256), 0, s, d);
-      if (part == 1) hipLaunchKernelGGL(rtd_sweep_kernel<16>, gs, dim3(64), 0, s, d);
+      if (part == 1) hipLaunchKernelGGL(rtd_sweep_kernel<16>, gs, dim3(64), 0, s, d, none);
       break;
     }
-    RTD_BC_CASE(32)
+    case 32:
+      if (!split) {
+        RTD_BC_TILED_CASE(32, 2)
+        break;
+      }
+      if (part == 0 && nif > 0) hipLaunchKernelGGL(rtd_iface_kernel<32>, gi, dim3(64), 0, s, d, none);
+      if (part == 1) hipLaunchKernelGGL(rtd_sweep_kernel<32>, gs, dim3(64), 0, s, d, none);
+      break;
     default: break;
   }
 #undef RTD_BC_CASE
+#undef RTD_BC_TILED_CASE
 }

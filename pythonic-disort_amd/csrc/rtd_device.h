@@ -25,7 +25,7 @@ struct RtdDev {
   // layer shard of the eigen stage (the north star's "all-gather to stitch the boundary-condition
   // system"): only the layers [l0, l0 + ln) are decomposed by this launch; l0 = 0, ln = L without shards
   int l0, ln;
-  int flags;  // bit 0: the fused BC kernel skips its speculative elimination (test hook, env RTD_BC_FORCE_PIVOT)
+  int flags;  // bit 1: the tiled fused BC kernel hands every third chain to the pivoted kernels (RTD_BC_FORCE_HANDOVER); bit 0: the fused BC kernel skips its speculative elimination (test hook, env RTD_BC_FORCE_PIVOT)
   // quadrature (padded to NP)
   const double *mu, *w, *invmu, *S, *T;  // S = sqrt(w/mu), T = sqrt(w*mu) (1 for padding)
   // Legendre tables
@@ -46,6 +46,7 @@ struct RtdDev {
   // sweep of the boundary-condition kernel forms the Fourier modes of the intensity there itself -- Y_l, A_l and the
   // coefficients are in its registers, the exponentials are E_l or 1 -- and the evaluation kernel only sums over the modes.
   double* um;         // [C][M][L+1][Q2]  u^m at the interfaces (null: not wanted)
+  int* need_split;    // [C][M]  chains the tiled fused BC kernel hands to the pivoted row-per-lane kernels (64 streams)
   int* sweeps;        // [1] max Jacobi sweeps (diagnostic)
   int* status;        // [1] device-side status flags (RTD_ST_*)
 };

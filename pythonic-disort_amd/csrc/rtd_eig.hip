@@ -89,6 +89,13 @@ __device__ __forceinline__ double approx_rcp(double x) {
 #define RTD_CHOL_FMAC_DPP 1  /* Cholesky trailing updates as ONE v_fmac_f64_dpp (row_newbcast) per element, NP = 16 */
 #endif
 
+#ifndef RTD_EIG_SEQ_ASSEMBLY
+#define RTD_EIG_SEQ_ASSEMBLY 0  /* 1: the one-parity-at-a-time assembly (always used at NP = 32) for every stream count */
+#endif
+
+#ifndef RTD_EIGEN32_WAVES
+#define RTD_EIGEN32_WAVES 2  /* waves per SIMD of the 64-stream eigen kernel (256 VGPRs, 23 spilled dwords; 1: 278 VGPRs) */
+#endif
 #ifndef RTD_EIGEN_WAVES
 #define RTD_EIGEN_WAVES 3  /* waves per SIMD the fused eigen kernel is compiled for (LDS: 10 KB per wave) */
 #endif
@@ -419,7 +426,7 @@ struct PairStep<NP, NP - 1> {  // the last step of a sweep is step NP - 2
 // total) and the Lw / Qw workspaces.
 // ------------------------------------------------------------------------------------------------
 template <int NP, int JV>  // JV: 2 = Jacobi sweeps in the pair layout (default), 1 = one column per lane (RTD_EIG_V1)
-__global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : 1)) void rtd_eigen_kernel(RtdDev d) {
+__global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES)) void rtd_eigen_kernel(RtdDev d) {
   constexpr int GPW = 64 / NP;
   constexpr int LD = NP + 1;
   __shared__ double sL[GPW][NP * LD];  // Cholesky factor L of Pm
@@ -435,6 +442,47 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : 1)) void rtd_eige
   const double om = d.omega[(long)c * d.L + l];
   const double* Ym = d.Y + (long)m * P * NP;
 
+  const double invmu_j = d.invmu[j], S_j = d.S[j];
+  if constexpr (RTD_EIG_SEQ_ASSEMBLY || NP == 32) {
+    // One parity at a time: Pm is assembled, factorised and parked in LDS before Qm is touched, so that the accumulator
+    // and the Cholesky column of only ONE of the two matrices are alive at once (NP = 32: 128 VGPRs less).
+    double cmax = 0.0;
+    for (int ell = id.mg; ell < P; ++ell) cmax = fmax(cmax, fabs(0.5 * om * wl[ell]));
+    // "shortcut" of the reference when multiple scattering is insignificant (:119, :162-168): the layer
+    // is treated as non-scattering; the general path then gives G = [[0,D],[D,0]], k = 1/mu, B = 0.
+    const double live = (cmax > 1e-8) ? 1.0 : 0.0;
+    auto assemble = [&](const int first, double (&col)[NP]) {  // M^-1 - S (2 sum_{l = first, first + 2, ...} c_l Y_l Y_l^T) S
+      double acc[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) acc[i] = 0.0;
+      for (int ell = first; ell < P; ell += 2) {
+        const double* Yr = Ym + (long)ell * NP;
+        const double coef = om * wl[ell] * Yr[j];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) acc[i] += coef * Yr[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) col[i] = (i == j ? invmu_j : 0.0) - d.S[i] * (live * acc[i]) * S_j;
+    };
+    {
+      double pcol[NP];
+      assemble(id.mg, pcol);                    // Pm = M^-1 - S Ae S  (D+/D- split by parity of l - m, :123-125)
+      dinv[j] = cholesky_columns<NP>(pcol, j);  // Pm = L L^T
+#pragma unroll
+      for (int i = 0; i < NP; ++i) L_[i * LD + j] = pcol[i];
+    }
+    double qcol[NP];
+    assemble(id.mg + 1, qcol);       // Qm = M^-1 - S Ao S
+    cholesky_columns<NP>(qcol, j);   // Qm = R R^T
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      double a = 0.0;
+#pragma unroll
+      for (int r = i; r < NP; ++r) a += L_[r * LD + i] * qcol[r];
+      w[i] = a;
+    }
+  } else {
   // D+/D- split by parity of (l - m): Ae = 2 sum_even c_l Y_l Y_l^T, Ao likewise (:123-125)
   double acc_e[NP], acc_o[NP];
 #pragma unroll
@@ -464,7 +512,6 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : 1)) void rtd_eige
 #pragma unroll
     for (int i = 0; i < NP; ++i) acc_e[i] = acc_o[i] = 0.0;
   }
-  const double invmu_j = d.invmu[j], S_j = d.S[j];
   {
     double pcol[NP], qcol[NP];
 #pragma unroll
@@ -485,6 +532,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : 1)) void rtd_eige
       for (int r = i; r < NP; ++r) a += L_[r * LD + i] * qcol[r];
       w[i] = a;
     }
+  }
   }
   // one-sided Jacobi on the columns of F
   int nsweep = 0;

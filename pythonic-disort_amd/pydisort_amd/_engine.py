@@ -258,6 +258,12 @@ class Plan:
         names = ("tables", "asm", "jacobi", "post", "iface", "sweep", "eval")
         return {k: (ms[i], n[i]) for i, k in enumerate(names)}
 
+    def pivoted_chains(self):
+        """(column, mode) chains of the last window that the tiled 64-stream BC kernel handed to the pivoted kernels."""
+        n = C.c_int32()
+        _lib.check(self._lib.rtd_plan_pivoted_chains(self._h, C.byref(n)))
+        return n.value
+
     def max_sweeps(self):
         s = C.c_int32()
         _lib.check(self._lib.rtd_plan_max_sweeps(self._h, C.byref(s)))

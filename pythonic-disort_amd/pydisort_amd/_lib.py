@@ -57,6 +57,7 @@ SIGNATURES = {
     "rtd_plan_enable_timing": (C.c_int, [_vp, C.c_int32]),
     "rtd_plan_get_timing": (C.c_int, [_vp, _dp, C.POINTER(C.c_int64), C.c_int32]),
     "rtd_plan_max_sweeps": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
+    "rtd_plan_pivoted_chains": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "rtd_comm_preload": (C.c_int, []),
     "rtd_comm_unique_id": (C.c_int, [C.c_char_p]),
     "rtd_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int32, C.c_int32]),

@@ -26,5 +26,5 @@ for name, maker, kw, C in [("cfg3_small(L6,Q8)", synthetic.cfg3_columns, dict(bi
     dt = (time.perf_counter() - t0) / n
     st = plan.timing()
     print(f"{name:20s} C={C:5d}  {C / dt:10.1f} col/s   stage ms:", {k: round(v[0] / max(v[1], 1), 2) for k, v in st.items()},
-          "sweeps", plan.max_sweeps(), flush=True)
+          "sweeps", plan.max_sweeps(), "pivoted chains", plan.pivoted_chains(), "of", C * plan.M, flush=True)
     plan.close()
