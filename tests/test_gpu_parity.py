@@ -901,3 +901,28 @@ def test_layer_shards_stitch_the_boundary_condition_system(amd, G):
     with pytest.raises(RuntimeError):
         plan.solve_layers(15, 10)  # beyond the last layer
     plan.close()
+
+
+@pytest.mark.gpu
+def test_bdrf_samples_with_many_azimuths(amd):
+    """rtd_plan_set_bdrf_samples keeps cos(2 pi p / nphi) for all p in LDS: 12 000 azimuths are 96 KB of dynamic LDS (more
+    than the 64 KB a workgroup gets by default elsewhere, within gfx950's 160 KB).  A Lambertian + one-harmonic
+    reflectance whose Fourier modes are known exactly."""
+    from pydisort_amd import synthetic
+    from pydisort_amd._engine import Plan
+    from pydisort_amd._prepare import double_gauss
+    C, NQ, nphi = 2, 8, 12000
+    N = NQ // 2
+    cfg = synthetic.cfg4_columns(C, L=3, NQuad=NQ)
+    mu, _ = double_gauss(N)
+    dphi = 2 * pi * np.arange(nphi) / nphi
+    a, b = 0.3, 0.1
+    rho_qq = a + b * np.cos(dphi)[None, None, None, :] * (mu[None, :, None, None] * mu[None, None, :, None]) * np.ones((C, 1, 1, 1))
+    rho_q0 = a + b * np.cos(dphi)[None, None, :] * mu[None, :, None] * cfg["mu0"][:, None, None]
+    _, got = amd.pydisort_batch(bdrf_samples=(rho_qq, rho_q0), NBDRF=2, **cfg)
+    q = np.stack((np.full((C, N, N), a), b * np.broadcast_to(np.outer(mu, mu), (C, N, N))), axis=1)
+    q0 = np.stack((np.full((C, N), a), b * mu[None, :] * cfg["mu0"][:, None]), axis=1)
+    _, want = amd.pydisort_batch(bdrf_q=q, bdrf_q0=q0, **cfg)
+    tau = np.concatenate((np.zeros((C, 1)), cfg["tau_arr"]), axis=1)
+    phi = np.array([0.0, 1.0])
+    assert np.max(np.abs(got.u(tau, phi) - want.u(tau, phi))) <= 1e-12 * np.max(np.abs(want.u(tau, phi)))
