@@ -425,7 +425,8 @@ struct PairStep<NP, NP - 1> {  // the last step of a sweep is step NP - 2
 // compared with the three-kernel pipeline this removes 10.6 KB of HBM traffic per problem (a third of the path's
 // total) and the Lw / Qw workspaces.
 // ------------------------------------------------------------------------------------------------
-template <int NP, int JV>  // JV: 2 = Jacobi sweeps in the pair layout (default), 1 = one column per lane (RTD_EIG_V1)
+template <int NP, int JV>  // JV: 2 = Jacobi sweeps in the pair layout (default), 1 = one column per lane (RTD_EIG_V1),
+//                             3 = 2 with the assembly of Pm, Qm on the matrix cores (RTD_EIG_MFMA, NP = 16)
 __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES)) void rtd_eigen_kernel(RtdDev d) {
   constexpr int GPW = 64 / NP;
   constexpr int LD = NP + 1;
@@ -443,7 +444,96 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
   const double* Ym = d.Y + (long)m * P * NP;
 
   const double invmu_j = d.invmu[j], S_j = d.S[j];
-  if constexpr (RTD_EIG_SEQ_ASSEMBLY || NP == 32) {
+  if constexpr (JV == 3 && NP == 16) {
+    // Assembly on the matrix cores (the north star's "MFMA for the batched dense GEMMs in matrix assembly"); RTD_EIG_MFMA=1.
+    // Measured (profiles/r02_eigen_mfma_assembly.json, same box): 2.346 G VALU instructions per launch instead of 2.421 G,
+    // SQ_VALU_MFMA_BUSY_CYCLES 0.42 G, kernel 5.48 ms instead of 5.17 ms: the four dependent MFMA per accumulator and the
+    // lane-row transposes behind them sit on the critical path of a kernel that was not short of issue slots there.  Kept as
+    // a selectable, tested variant; not the default.
+    //   Pm = M^-1 - sum_{l - m even} (omega w_l) (S Y_l)(S Y_l)^T,  Qm likewise over the odd terms  (:123-135)
+    // as rank-4 updates v_mfma_f64_16x16x4_f64 of an accumulator that starts as M^-1: the A operand of a lane (i, k) is
+    // -(omega w_l S_i Y_l[i]) for the k-th l of the chunk, the B operand S_j Y_l[j] -- the same table element, so one load
+    // feeds both and the four problems of the wavefront (four layers of one (column, mode): the table is shared) differ
+    // by their coefficient only.  The accumulators come out in the D layout (lane (kq, col): rows 4 q + kq of column col of
+    // ONE problem); the Cholesky wants column col of problem g in lane (g, col): a 4 x 4 transpose of the lane-rows per
+    // register, two v_permlane16_swap + two v_permlane32_swap per dword.
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    const int tx = threadIdx.x, i16 = tx & 15, k4 = tx >> 4;
+    const int chunk = (int)((long)blockIdx.x % ((d.L + GPW - 1) / GPW));
+    // "shortcut" (:119): per problem, multiple scattering is switched off when max_l |omega w_l / 2| <= 1e-8
+    double cm_ = 0.0;
+    for (int ell = id.mg + j; ell < P; ell += NP) cm_ = fmax(cm_, fabs(0.5 * om * wl[ell]));
+    const unsigned long long livemask = __ballot(cm_ > 1e-8);
+    const double S_i = d.S[i16], invmu_c = d.invmu[i16];
+    v4d accP[GPW], accQ[GPW];
+#pragma unroll
+    for (int g = 0; g < GPW; ++g)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) accP[g][q] = accQ[g][q] = (4 * q + k4 == i16) ? invmu_c : 0.0;
+    const double* wlg[GPW];
+    double omg[GPW];
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {  // wave-uniform: the layers of the four problems (scalar loads)
+      const int slot = chunk * GPW + g;
+      const int lg = d.lperm[(long)c * d.L + (slot < d.L ? slot : d.L - 1)];
+      wlg[g] = d.wleg + ((long)c * d.L + lg) * P;
+      omg[g] = ((livemask >> (NP * g)) & 0xffffull) ? -d.omega[(long)c * d.L + lg] : 0.0;
+    }
+    for (int base = id.mg; base < P; base += 8) {  // 4 even and 4 odd terms per chunk
+      const int le = base + 2 * k4, lo = le + 1;
+      const double ye = le < P ? Ym[(long)le * NP + i16] * S_i : 0.0;
+      const double yo = lo < P ? Ym[(long)lo * NP + i16] * S_i : 0.0;
+#pragma unroll
+      for (int g = 0; g < GPW; ++g) {
+        const double ce = le < P ? omg[g] * wlg[g][le] : 0.0, co = lo < P ? omg[g] * wlg[g][lo] : 0.0;
+        accP[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(ce * ye, ye, accP[g], 0, 0, 0);
+        accQ[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(co * yo, yo, accQ[g], 0, 0, 0);
+      }
+    }
+    // D layout -> one column per lane: T_k = rows (R0[k], R1[k], R2[k], R3[k]) of the registers R_g = acc[g][q]
+    double pcol[NP], qcol[NP];
+    auto transpose4 = [](const v4d (&acc)[GPW], const int q, double (&out)[NP]) {
+      unsigned r[4][2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        r[g][0] = (unsigned)__double2loint(acc[g][q]);
+        r[g][1] = (unsigned)__double2hiint(acc[g][q]);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const u2 s01 = __builtin_amdgcn_permlane16_swap(r[0][h], r[1][h], false, false);  // (R0[0],R1[0],R0[2],R1[2]), (R0[1],R1[1],R0[3],R1[3])
+        const u2 s23 = __builtin_amdgcn_permlane16_swap(r[2][h], r[3][h], false, false);
+        const u2 t02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);    // T_0, T_2
+        const u2 t13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);    // T_1, T_3
+        r[0][h] = t02[0];
+        r[2][h] = t02[1];
+        r[1][h] = t13[0];
+        r[3][h] = t13[1];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out[4 * q + k] = __hiloint2double((int)r[k][1], (int)r[k][0]);
+    };
+    if constexpr (GPW == 4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        transpose4(accP, q, pcol);
+        transpose4(accQ, q, qcol);
+      }
+    }
+    dinv[j] = cholesky_columns<NP>(pcol, j);  // Pm = L L^T
+    cholesky_columns<NP>(qcol, j);            // Qm = R R^T
+#pragma unroll
+    for (int i = 0; i < NP; ++i) L_[i * LD + j] = pcol[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      double a = 0.0;
+#pragma unroll
+      for (int r = i; r < NP; ++r) a += L_[r * LD + i] * qcol[r];
+      w[i] = a;
+    }
+  } else if constexpr (RTD_EIG_SEQ_ASSEMBLY || NP == 32) {
     // One parity at a time: Pm is assembled, factorised and parked in LDS before Qm is touched, so that the accumulator
     // and the Cholesky column of only ONE of the two matrices are alive at once (NP = 32: 128 VGPRs less).
     double cmax = 0.0;
@@ -846,7 +936,8 @@ void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part) {
   const int gpw = 64 / d.NP;
   const dim3 grid((unsigned)((long)d.C * d.M * ((d.ln + gpw - 1) / gpw)));
   // RTD_EIG_V1=1: the one-column-per-lane form of the sweeps (A/B runs and a regression test)
-  static const bool v1 = getenv("RTD_EIG_V1") != nullptr;
+  // RTD_EIG_MFMA=1: the assembly of Pm, Qm on the matrix cores (NP = 16; A/B runs and a regression test)
+  static const bool v1 = getenv("RTD_EIG_V1") != nullptr, mfma = getenv("RTD_EIG_MFMA") != nullptr;
 #define RTD_EIG_CASE(NPV)                                                                        \
   case NPV:                                                                                      \
     if (v1) hipLaunchKernelGGL((rtd_eigen_kernel<NPV, 1>), grid, dim3(64), 0, s, d);             \
@@ -855,7 +946,11 @@ void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part) {
   switch (d.NP) {
     RTD_EIG_CASE(4)
     RTD_EIG_CASE(8)
-    RTD_EIG_CASE(16)
+    case 16:
+      if (v1) hipLaunchKernelGGL((rtd_eigen_kernel<16, 1>), grid, dim3(64), 0, s, d);
+      else if (mfma) hipLaunchKernelGGL((rtd_eigen_kernel<16, 3>), grid, dim3(64), 0, s, d);
+      else hipLaunchKernelGGL((rtd_eigen_kernel<16, 2>), grid, dim3(64), 0, s, d);
+      break;
     RTD_EIG_CASE(32)
     default: break;
   }

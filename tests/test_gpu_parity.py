@@ -552,11 +552,11 @@ def test_fused_bc_kernel_pivoted_path_on_goldens():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["RTD_BC_SPLIT", "RTD_EIG_V1", "RTD_BC_TILED", "RTD_BC_FORCE_HANDOVER"])
+@pytest.mark.parametrize("switch", ["RTD_BC_SPLIT", "RTD_EIG_V1", "RTD_EIG_MFMA", "RTD_BC_TILED", "RTD_BC_FORCE_HANDOVER"])
 def test_alternative_kernel_paths_stay_correct(switch):
     """The runtime switches that select an alternative kernel path -- RTD_BC_SPLIT=1: interface operators through HBM +
     row-per-lane sweep kernel instead of the fused MFMA-layout kernels; RTD_EIG_V1=1: Jacobi sweeps with one column per lane
-    instead of the pair layout; RTD_BC_TILED=1: the tiled fused kernel (the 64-stream kernel) with one tile, in place of the
+    instead of the pair layout; RTD_EIG_MFMA=1: the assembly of Pm, Qm as rank-4 MFMA updates (32 streams); RTD_BC_TILED=1: the tiled fused kernel (the 64-stream kernel) with one tile, in place of the
     32-stream kernel it generalises; RTD_BC_FORCE_HANDOVER=1: the tiled kernel hands every third chain to the pivoted
     row-per-lane kernels (its last resort for singular carry blocks) -- pass the golden replay (it has 40-, 48- and
     64-stream cases), the synthetic configs incl. cfg5 and the random cases."""
