@@ -97,7 +97,8 @@ __device__ __forceinline__ double approx_rcp(double x) {
 #define RTD_EIGEN32_WAVES 2  /* waves per SIMD of the 64-stream eigen kernel (256 VGPRs, 23 spilled dwords; 1: 278 VGPRs) */
 #endif
 #ifndef RTD_EIGEN_WAVES
-#define RTD_EIGEN_WAVES 3  /* waves per SIMD the fused eigen kernel is compiled for (LDS: 10 KB per wave) */
+#define RTD_EIGEN_WAVES 3  /* waves per SIMD the fused eigen kernel is compiled for at NP <= 16 (145 VGPRs, no spills, LDS 10.75 KB per
+                              wavefront).  4 (128 VGPRs, 21-41 dwords spilled in the once-per-wavefront stages, packed L): 2 % slower (A/B) */
 #endif
 
 // A sweep is the last one when every pair it met had cos^2(angle) <= RTD_JAC_TOL before its rotation.  Quadratic
@@ -425,12 +426,21 @@ struct PairStep<NP, NP - 1> {  // the last step of a sweep is step NP - 2
 // compared with the three-kernel pipeline this removes 10.6 KB of HBM traffic per problem (a third of the path's
 // total) and the Lw / Qw workspaces.
 // ------------------------------------------------------------------------------------------------
+// packed lower triangle: element (r, c), r >= c
+__host__ __device__ constexpr int tri(int r, int c) { return r * (r + 1) / 2 + c; }
+
 template <int NP, int JV>  // JV: 2 = Jacobi sweeps in the pair layout (default), 1 = one column per lane (RTD_EIG_V1),
 //                             3 = 2 with the assembly of Pm, Qm on the matrix cores (RTD_EIG_MFMA, NP = 16)
 __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES)) void rtd_eigen_kernel(RtdDev d) {
   constexpr int GPW = 64 / NP;
+  // Cholesky factor L of Pm in LDS: a padded square at NP <= 16; at NP = 32 the packed lower triangle (element (r, c), r >= c,
+  // at r (r + 1) / 2 + c): half the LDS, which is what lets two wavefronts per SIMD fit there (A/B: 12.4 -> 11.6 ms per 128
+  // cfg5 columns; at NP = 16 the selects of the two full-row / full-column products cost more than the LDS buys: 5.18 -> 5.27 ms)
+  constexpr bool PACKED = NP == 32;
   constexpr int LD = NP + 1;
-  __shared__ double sL[GPW][NP * LD];  // Cholesky factor L of Pm
+  constexpr int LSIZE = PACKED ? NP * (NP + 1) / 2 : NP * LD;
+  __shared__ double sL[GPW][LSIZE];
+  auto lix = [](const int r, const int c) { return PACKED ? tri(r, c) : r * LD + c; };  // element (r, c) of L, r >= c
   __shared__ double sV[GPW][4][NP];
   double w[NP];  // column j of F = L^T R, then of k Z
   {  // ---- stage 1: assembly, Cholesky factors, F, Jacobi.  Only w (and the LDS tile of L) leaves this block.
@@ -524,13 +534,14 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
     dinv[j] = cholesky_columns<NP>(pcol, j);  // Pm = L L^T
     cholesky_columns<NP>(qcol, j);            // Qm = R R^T
 #pragma unroll
-    for (int i = 0; i < NP; ++i) L_[i * LD + j] = pcol[i];
+    for (int i = 0; i < NP; ++i)
+        if (!PACKED || j <= i) L_[lix(i, 0) + j] = pcol[i];
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       double a = 0.0;
 #pragma unroll
-      for (int r = i; r < NP; ++r) a += L_[r * LD + i] * qcol[r];
+      for (int r = i; r < NP; ++r) a += L_[lix(r, i)] * qcol[r];
       w[i] = a;
     }
   } else if constexpr (RTD_EIG_SEQ_ASSEMBLY || NP == 32) {
@@ -559,7 +570,8 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
       assemble(id.mg, pcol);                    // Pm = M^-1 - S Ae S  (D+/D- split by parity of l - m, :123-125)
       dinv[j] = cholesky_columns<NP>(pcol, j);  // Pm = L L^T
 #pragma unroll
-      for (int i = 0; i < NP; ++i) L_[i * LD + j] = pcol[i];
+      for (int i = 0; i < NP; ++i)
+        if (!PACKED || j <= i) L_[lix(i, 0) + j] = pcol[i];
     }
     double qcol[NP];
     assemble(id.mg + 1, qcol);       // Qm = M^-1 - S Ao S
@@ -569,7 +581,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
     for (int i = 0; i < NP; ++i) {
       double a = 0.0;
 #pragma unroll
-      for (int r = i; r < NP; ++r) a += L_[r * LD + i] * qcol[r];
+      for (int r = i; r < NP; ++r) a += L_[lix(r, i)] * qcol[r];
       w[i] = a;
     }
   } else {
@@ -613,13 +625,14 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
     dinv[j] = cholesky_columns<NP>(pcol, j);  // Pm = L L^T
     cholesky_columns<NP>(qcol, j);  // Qm = R R^T
 #pragma unroll
-    for (int i = 0; i < NP; ++i) L_[i * LD + j] = pcol[i];
+    for (int i = 0; i < NP; ++i)
+        if (!PACKED || j <= i) L_[lix(i, 0) + j] = pcol[i];
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       double a = 0.0;
 #pragma unroll
-      for (int r = i; r < NP; ++r) a += L_[r * LD + i] * qcol[r];
+      for (int r = i; r < NP; ++r) a += L_[lix(r, i)] * qcol[r];
       w[i] = a;
     }
   }
@@ -725,7 +738,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
   for (int i = NP - 1; i >= 0; --i) {
     double a = zc[i];
 #pragma unroll
-    for (int r = i + 1; r < NP; ++r) a -= L_[r * LD + i] * ya[r];
+    for (int r = i + 1; r < NP; ++r) a -= L_[lix(r, i)] * ya[r];
     ya[i] = a * dinv[i];
     RTD_FENCE();
   }
@@ -777,7 +790,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
     __syncthreads();
     double g = 0.0;  // g = L^T rhat
 #pragma unroll
-    for (int r = 0; r < NP; ++r) g += L_[r * LD + j] * v1[r];
+    for (int r = 0; r < NP; ++r) g += ((!PACKED || r >= j) ? L_[lix(r, 0) + j] : 0.0) * v1[r];  // column j of L (zero above the diagonal)
     v2[j] = g;
     __syncthreads();
     double h = 0.0;  // h = Z^T g / (1/mu0^2 - k^2)
@@ -800,7 +813,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
     __syncthreads();
     double ps = 0.0;  // Pm shat = L (L^T shat) = L t
 #pragma unroll
-    for (int r = 0; r < NP; ++r) ps += L_[j * LD + r] * v2[r];
+    for (int r = 0; r < NP; ++r) ps += ((!PACKED || r <= j) ? L_[lix(j, 0) + r] : 0.0) * v2[r];  // row j of L
     const double rT = fast_rcp(T_j);
     const double s_j = sh * rT;
     const double d_j = mu0 * (txd - ps) * rT;
@@ -818,7 +831,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
   for (int i = 0; i < NP; ++i) {
     double a = 0.0;
 #pragma unroll
-    for (int r = 0; r <= i; ++r) a += L_[i * LD + r] * zc[r];
+    for (int r = 0; r <= i; ++r) a += L_[lix(i, r)] * zc[r];
     aa[i] = a;
     RTD_FENCE();
   }
