@@ -322,6 +322,12 @@ def spawn_ranks(n, argv, timeout=None):
 # one rank
 # ---------------------------------------------------------------------------------------------------------
 def run_rank(a, rank, world, local):
+    # gloo ("[Gloo] Rank 0 is connected to ...") and RCCL (its version banner) write to the C-level stdout: file descriptor 1
+    # points at stderr for the whole run and the result line goes out through a private duplicate of the real stdout, so that
+    # the JSON line is the only thing this program writes there
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     stub = os.environ.get("RTD_BENCH_STUB") == "1"  # CPU test of the launch / control plane: no GPU, no librtd
     if stub and os.environ.get("RTD_BENCH_STUB_FAIL_RANK") == str(rank):
         sys.exit(7)  # test hook: a rank that dies before it joins
@@ -354,7 +360,8 @@ def run_rank(a, rank, world, local):
     watchdog = None
     if multi:
         import torch.distributed as dist
-        dist.init_process_group("gloo")  # control plane: barriers, status and the max-over-ranks of the time
+        # control plane: barriers, status and the max-over-ranks of the time
+        dist.init_process_group("gloo")
         if dist.get_world_size() != world:
             print(f"[bench] rank {rank}: process group has {dist.get_world_size()} ranks, expected {world}", file=sys.stderr)
             os._exit(EXIT_RANKS)
@@ -493,8 +500,8 @@ def run_rank(a, rank, world, local):
                 "whole_path_frac": fl["total"] * value / world / 1e12 / FP64_PEAK_TFLOPS}
         out["cpu_baseline"] = cpu
         out.update(extras)
-        print(json.dumps(out))
         sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
