@@ -14,7 +14,8 @@ fixture tests/golden/hp_truth_q32.npz holds the inputs and u^m at the 21 layer i
 compare the HIP path (ulast of a solve with NFourier = m + 1) and the float64 oracle against it: the oracle's distance
 to the truth is the error budget of every oracle-based tolerance in tests/.
 
-Usage (build container, ~15 minutes):  python3 tools/hp_truth_q32.py
+Usage (build container, ~2 minutes):  python3 tools/hp_truth_q32.py            (fixture hp_truth_q32.npz)
+                                      python3 tools/hp_truth_q32.py --q56      (fixture hp_truth_q56.npz, see case_q56)
 """
 import os
 import sys
@@ -175,7 +176,37 @@ def solve_mode(p, m):
     return out
 
 
+def case_q56():
+    """A second atmosphere, found by the random 64-stream parity cases (tests/test_gpu_random_parity.py,
+    make_case_64_streams(5) without its surface): 56 streams, 8 layers, the top layer thin with omega = 1 - 1e-6, no beam,
+    isotropic illumination from above (b_neg = 0.5), black surface.  Here the reference's algorithm in float64 is 3.4e-6
+    off the truth -- more than the north star's 1e-6 -- and the HIP path 1e-11."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_random_parity as T
+    kw = T.make_case_64_streams(5)
+    kw.pop("BDRF_Fourier_modes", None)
+    kw["only_flux"] = True
+    return kw
+
+
+def run_q56():
+    kw = case_q56()
+    p = O.prepare(**kw)
+    p["mu0"] = 1.0  # no beam (I0 = 0): any mu0 will do, the beam terms carry the factor I0 / 4 pi = 0
+    hp = solve_mode(p, 0)
+    res = {"um0": hp}
+    for k_, v in kw.items():
+        res["in." + k_] = np.asarray(v)
+    np.savez(os.path.join(ROOT, "tests", "golden", "hp_truth_q56.npz"), **res)
+    tau = np.concatenate(([0.0], kw["tau_arr"]))
+    orc = O.pydisort(**kw)[3](tau)
+    print(f"q56: oracle vs truth, max |d| / max |u^0| = {np.max(np.abs(orc - hp)) / np.max(np.abs(hp)):.2e}")
+
+
 if __name__ == "__main__":
+    if "--q56" in sys.argv:
+        run_q56()
+        sys.exit(0)
     kw = case()
     p = O.prepare(**kw)
     res = {"modes": np.array(MODES)}
