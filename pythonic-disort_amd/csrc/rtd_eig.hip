@@ -443,7 +443,10 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
   auto lix = [](const int r, const int c) { return PACKED ? tri(r, c) : r * LD + c; };  // element (r, c) of L, r >= c
   __shared__ double sV[GPW][4][NP];
   double w[NP];  // column j of F = L^T R, then of k Z
-  {  // ---- stage 1: assembly, Cholesky factors, F, Jacobi.  Only w (and the LDS tile of L) leaves this block.
+  // beam source terms of this lane's stream, sum_l (omega w_l Y_l[j]) Ybar_l(-mu0) over the even / odd l - m: they fall out of
+  // the assembly loop for one FMA per term (the second pass over the moments that stage 2 used to make is gone)
+  double xe_sum = 0.0, xo_sum = 0.0;
+  {  // ---- stage 1: assembly, Cholesky factors, F, Jacobi.  Only w, the two sums (and the LDS tile of L) leave this block.
   const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
   const ProbId id = locate<NP>(d);
   const int P = d.P, m = id.m, c = id.c, l = id.l;
@@ -475,6 +478,13 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
     double cm_ = 0.0;
     for (int ell = id.mg + j; ell < P; ell += NP) cm_ = fmax(cm_, fabs(0.5 * om * wl[ell]));
     const unsigned long long livemask = __ballot(cm_ > 1e-8);
+    if (d.beam && ((livemask >> (NP * grp)) & 0xffffull)) {  // the beam sums of this lane's stream (not a matrix product)
+      const double* Y0b = d.Y0 + ((long)c * d.M + m) * P;
+      for (int ell = id.mg; ell < P; ell += 2) {
+        xe_sum = fma(om * wl[ell] * Ym[(long)ell * NP + j], Y0b[ell], xe_sum);
+        if (ell + 1 < P) xo_sum = fma(om * wl[ell + 1] * Ym[(long)(ell + 1) * NP + j], Y0b[ell + 1], xo_sum);
+      }
+    }
     const double S_i = d.S[i16], invmu_c = d.invmu[i16];
     v4d accP[GPW], accQ[GPW];
 #pragma unroll
@@ -552,13 +562,15 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
     // "shortcut" of the reference when multiple scattering is insignificant (:119, :162-168): the layer
     // is treated as non-scattering; the general path then gives G = [[0,D],[D,0]], k = 1/mu, B = 0.
     const double live = (cmax > 1e-8) ? 1.0 : 0.0;
-    auto assemble = [&](const int first, double (&col)[NP]) {  // M^-1 - S (2 sum_{l = first, first + 2, ...} c_l Y_l Y_l^T) S
+    const double* Y0b = d.Y0 + ((long)c * d.M + m) * P;  // Ybar_l^m(-mu0): wave-uniform; read only with a beam
+    auto assemble = [&](const int first, double (&col)[NP], double& beam_sum) {  // M^-1 - S (2 sum_{l = first, first + 2, ...} c_l Y_l Y_l^T) S
       double acc[NP];
 #pragma unroll
       for (int i = 0; i < NP; ++i) acc[i] = 0.0;
       for (int ell = first; ell < P; ell += 2) {
         const double* Yr = Ym + (long)ell * NP;
         const double coef = om * wl[ell] * Yr[j];
+        if (d.beam) beam_sum = fma(live * coef, Y0b[ell], beam_sum);
 #pragma unroll
         for (int i = 0; i < NP; ++i) acc[i] += coef * Yr[i];
       }
@@ -567,14 +579,14 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
     };
     {
       double pcol[NP];
-      assemble(id.mg, pcol);                    // Pm = M^-1 - S Ae S  (D+/D- split by parity of l - m, :123-125)
+      assemble(id.mg, pcol, xe_sum);            // Pm = M^-1 - S Ae S  (D+/D- split by parity of l - m, :123-125)
       dinv[j] = cholesky_columns<NP>(pcol, j);  // Pm = L L^T
 #pragma unroll
       for (int i = 0; i < NP; ++i)
         if (!PACKED || j <= i) L_[lix(i, 0) + j] = pcol[i];
     }
     double qcol[NP];
-    assemble(id.mg + 1, qcol);       // Qm = M^-1 - S Ao S
+    assemble(id.mg + 1, qcol, xo_sum);  // Qm = M^-1 - S Ao S
     cholesky_columns<NP>(qcol, j);   // Qm = R R^T
     __syncthreads();
 #pragma unroll
@@ -590,12 +602,14 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
 #pragma unroll
   for (int i = 0; i < NP; ++i) acc_e[i] = acc_o[i] = 0.0;
   double cmax = 0.0;
+  const double* Y0b = d.Y0 + ((long)c * d.M + m) * P;  // Ybar_l^m(-mu0): wave-uniform (scalar loads); read only with a beam
   for (int ell = id.mg; ell < P; ell += 2) {
     {
       const double cl = 0.5 * om * wl[ell];
       cmax = fmax(cmax, fabs(cl));
       const double* Yr = Ym + (long)ell * NP;
       const double coef = 2.0 * cl * Yr[j];
+      if (d.beam) xe_sum = fma(coef, Y0b[ell], xe_sum);
 #pragma unroll
       for (int i = 0; i < NP; ++i) acc_e[i] += coef * Yr[i];
     }
@@ -604,6 +618,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
       cmax = fmax(cmax, fabs(cl));
       const double* Yr = Ym + (long)(ell + 1) * NP;
       const double coef = 2.0 * cl * Yr[j];
+      if (d.beam) xo_sum = fma(coef, Y0b[ell + 1], xo_sum);
 #pragma unroll
       for (int i = 0; i < NP; ++i) acc_o[i] += coef * Yr[i];
     }
@@ -613,6 +628,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
   if (!(cmax > 1e-8)) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) acc_e[i] = acc_o[i] = 0.0;
+    xe_sum = xo_sum = 0.0;
   }
   {
     double pcol[NP], qcol[NP];
@@ -756,18 +772,9 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
   //  T dd = mu0 [ T (x+ - x-) - Pm T s ],  Qm Pm = L^-T Z k^2 Z^T L^T
   if (d.beam) {
     const double mu0 = d.mu0[c];
-    const double fac = d.I0[c] * (0.25 / M_PI) * (id.mg == 0 ? 1.0 : 2.0) * om;
-    const double* Y0 = d.Y0 + ((long)c * d.M + m) * P;
-    double xe = 0.0, xo = 0.0, cmax = 0.0;  // X^e_j, X^o_j of this lane's stream
-    for (int ell = id.mg; ell < P; ell += 2) {
-      cmax = fmax(cmax, fabs(0.5 * om * wl[ell]));
-      xe += fac * wl[ell] * Y0[ell] * Ym[(long)ell * NP + j];
-      if (ell + 1 < P) {
-        cmax = fmax(cmax, fabs(0.5 * om * wl[ell + 1]));
-        xo += fac * wl[ell + 1] * Y0[ell + 1] * Ym[(long)(ell + 1) * NP + j];
-      }
-    }
-    if (!(cmax > 1e-8)) xe = xo = 0.0;
+    // X^e_j, X^o_j of this lane's stream (:143-152): I0/(4 pi) (2 - delta_m0) omega sum_l w_l Ybar_l(-mu0) Y_l[j], from stage 1
+    const double fac = d.I0[c] * (0.25 / M_PI) * (id.mg == 0 ? 1.0 : 2.0);
+    const double xe = fac * xe_sum, xo = fac * xo_sum;
     const double txd = 2.0 * T_j * xe * invmu_j;  // T (x+ - x-)
     v0[j] = txd;
     __syncthreads();
