@@ -670,6 +670,9 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
 #ifndef RTD_BCF_WAVES
 #define RTD_BCF_WAVES 3
 #endif
+#ifndef RTD_BCF_WIN
+#define RTD_BCF_WIN 20  // layers of small vectors resident in LDS (12.6 KB per wavefront with the save area: 12 per CU)
+#endif
 __device__ __forceinline__ v4f64 mm_t(const v4f64& X, const v4f64& Y) {  // X^T Y
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[0], Y[0], acc, 0, 0, 0);
@@ -726,89 +729,18 @@ __device__ __forceinline__ v4f64 col_to_row(const double vc, const int rowbase, 
   r[3] = bperm((rowbase | (12 + kq)) << 2, vc);
   return r;
 }
-__device__ __forceinline__ double push_lane(int addr, double v) {  // this lane's v lands in lane addr / 4
-  const int lo = __builtin_amdgcn_ds_permute(addr, __double2loint(v));
-  const int hi = __builtin_amdgcn_ds_permute(addr, __double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
-
-// Column-pivoted Gauss-Jordan on the stacked rows [Ta^T ; Tb^T (NB registers) ; t^T]: step K makes row K of Ta^T a
-// unit vector.  The pivot is the largest unused column of that row (threshold 1/4 in favour of the diagonal, as
-// in GjStep); on exit the lane-column that was the pivot of step pc holds column pc of Tb^T Ta^-T and t^T Ta^-T.
-template <int NB, int K>
-struct GjT {
-  static __device__ __forceinline__ void run(double (&ta)[4], double (&tb)[4], double& tv, int& pc, const int col, const int rowbase) {
-    constexpr int QK = K >> 2, RK = K & 3;
-    const double x = bperm(((RK << 4) | col) << 2, ta[QK]);  // row K of Ta^T, replicated over the lane-rows
-    const float key = (pc < 0) ? fabsf((float)x) : -1.0f;
-    const float kmax = group_max_key<16>(key);
-    const float kd = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(key), 0x150 + K, 0xF, 0xF, true));
-    const bool fast = __all(kd >= 0.25f * kmax && kd > 0.0f);
-    double f, rp;
-    bool isp;
-    if (fast) {
-      isp = (col == K);
-      rp = fast_rcp(bcast16<K>(x));
-      f = isp ? 0.0 : x * rp;
-      static_for<QK, 4>([&](auto qc) {  // rows below 4 QK are finished: the pivot column is zero there
-        constexpr int q = decltype(qc)::value;
-        ta[q] -= f * bcast16<K>(ta[q]);
-      });
-      static_for<0, NB>([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        tb[q] -= f * bcast16<K>(tb[q]);
-      });
-      tv -= f * bcast16<K>(tv);
-    } else {
-      const unsigned int bits = (unsigned int)(__ballot(key == kmax) & 0xffffull);
-      const int src = __ffs((int)bits) - 1;
-      isp = (col == src);
-      const int addr = (rowbase | src) << 2;
-      rp = fast_rcp(bperm(addr, x));
-      f = isp ? 0.0 : x * rp;
-      static_for<QK, 4>([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        ta[q] -= f * bperm(addr, ta[q]);
-      });
-      static_for<0, NB>([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        tb[q] -= f * bperm(addr, tb[q]);
-      });
-      tv -= f * bperm(addr, tv);
-    }
-    if (isp) {
-      pc = K;
-      static_for<QK, 4>([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        ta[q] *= rp;
-      });
-      static_for<0, NB>([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        tb[q] *= rp;
-      });
-      tv *= rp;
-    }
-    GjT<NB, K + 1>::run(ta, tb, tv, pc, col, rowbase);
-  }
-};
-template <int NB>
-struct GjT<NB, 16> {
-  static __device__ __forceinline__ void run(double (&)[4], double (&)[4], double&, int&, const int, const int) {}
-};
-
 // Speculative, branch-free form of the same elimination with the diagonal as pivot at every step: straight-line
 // code (the 16 steps schedule into each other), no pivot search.  A step whose diagonal candidate is more than a
 // factor RTD_GJ_GROWTH smaller than another unused entry of its row raises `bad` (a zero pivot leaves inf / nan in the
 // result, which the caller tests); the caller then
-// repeats the elimination from its saved inputs with the pivoted GjT (counts from a temporary statistics build).
+// repeats the elimination from its saved inputs with column pivoting (counts from a temporary statistics build).
 // The pivot column is scaled by the same FMA as the others: its own broadcast value is itself, so f = 1 - 1/pivot
 // gives v - f v = v / pivot.
-// Threshold: a multiplier |f| > RTD_GJ_GROWTH flags the elimination.  The pivoted redo is slow (LDS-latency-bound
-// ds_bpermute chains; measured ~45 000 cycles each, 3 % more instructions but 20 % more kernel time at threshold 8, where
-// 3.1 % of the eliminations are flagged: 5.2 ms against 4.1 ms with the fallback compiled out; the instruction cache is
-// not the reason, SQC_ICACHE_MISSES stays at ~1 600 per launch).  64 is the classical relaxed threshold of sparse direct
-// solvers (u = 1/64: local growth <= 65, i.e. ~1e-14 instead of 1e-16 relative): well under 1 % flagged, 4.3 ms, parity
-// against the oracle unchanged to all printed digits (1.62e-11 abs, 4.10e-10 rel; also at 512).
+// Threshold: a multiplier |f| > RTD_GJ_GROWTH flags the elimination.  The pivoted redo is slow (a rolled loop on the LDS
+// copy of the inputs, one stacked row per lane; its register-resident predecessor took ~45 000 cycles per elimination and
+// cost 20 % of kernel time at threshold 8, where 3.1 % of the eliminations are flagged).  64 is the classical relaxed
+// threshold of sparse direct solvers (u = 1/64: local growth <= 65, i.e. ~1e-14 instead of 1e-16 relative): well under
+// 1 % flagged, parity against the oracle unchanged to all printed digits (1.62e-11 abs, 4.10e-10 rel; also at 512).
 #ifndef RTD_GJ_GROWTH
 #define RTD_GJ_GROWTH 64.0
 #endif
@@ -920,9 +852,106 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     e[3] = (12 + kq == col) ? 1.0 : 0.0;
     return e;
   };
-  const double rT_col = fast_rcp(d.T[col]);
+  // ---- LDS.  (1) The save area of the running elimination, read back only when its speculation fails; the backward sweep
+  //      stages its results there.  (2) The chain's small vectors for a window of RTD_BCF_WIN layers, filled by coalesced
+  //      loads: exp(-k_l dtau_l), the stream scaling T, and the particular solution p_l(tau) = B_l exp(-tau / mu0) + v_l(tau)
+  //      (beam + thermal polynomial) in the form each sweep needs -- forward: its jump at the interface below layer l,
+  //      r_l = p_(l+1)(tau_(l+1)) - p_l(tau_(l+1)) (:184-205, :242-245); backward: its value at the top of layer l, which the
+  //      fused evaluation adds.  The loops then read them in whatever form they need (row form = a broadcast read)
+  //      without keeping dozens of registers in flight, know nothing of beam or thermal sources, and have no global load
+  //      that is consumed right away (one such load makes the wave wait for everything it has in flight: the counter is
+  //      in-order).
+  constexpr int W = RTD_BCF_WIN;
+  __shared__ double sSave[9][64];
+  __shared__ double sPs[W][Q];  // forward: r_l; backward: p_l(tau_l)
+  __shared__ double sEk[W][NP];
+  __shared__ double sT[2][NP];  // T and 1 / T
+  __shared__ double sF[NP];
+  // Diagnostic build (-DRTD_BCF_STAMPS): lane 0 of three chains records s_memtime at the phase boundaries and prints the
+  // differences (tools/bc_phase_cycles.py formats them); this is how the stalls named in the comments were measured.
+#ifdef RTD_BCF_STAMPS
+  __shared__ long long sStamp[512];
+  int nstamp = 0;
+#define RTD_STAMP()                                                                  \
+  {                                                                                  \
+    if (lane == 0 && nstamp < 512) sStamp[nstamp] = (long long)__builtin_amdgcn_s_memtime(); \
+    ++nstamp;                                                                        \
+  }
+#else
+#define RTD_STAMP()
+#endif
+  RTD_STAMP();
+  __shared__ int sPerm[NP];
+  int wb = 0;                   // the window holds layers [wb, wb + W) and interfaces [wb, wb + W]
+  // Column-pivoted Gauss-Jordan on the save area: the stacked rows [Ta^T ; Tb^T (with_tb) ; t^T] in the D layout, row r of
+  // the stack = sSave[r >> 2][16 (r & 3) + column].  Step K makes row K of Ta^T a unit vector; the pivot is the largest
+  // unused column of that row (threshold 1/4 in favour of the diagonal); afterwards the column that was the pivot of
+  // step c holds column c of Tb^T Ta^-T and t^T Ta^-T.  Rolled loops, one stacked row per lane: slow and small -- it runs
+  // for the few eliminations whose speculation fails and must not cost the others registers.
+  auto pivoted_lds = [&](const bool with_tb) {
+    __syncthreads();
+    double* const sM = &sSave[0][0];
+    unsigned int used = 0;
+    const int r = lane;
+    const bool mine = r < NP || (with_tb && r < 2 * NP) || r == 2 * NP;
+    double* const myrow = sM + (r >> 2) * 64 + 16 * (r & 3);
+#pragma unroll 1
+    for (int K = 0; K < NP; ++K) {
+      const double* rowK = sM + (K >> 2) * 64 + 16 * (K & 3);
+      float key = (lane < NP && !((used >> lane) & 1u)) ? fabsf((float)rowK[lane]) : -1.0f;
+      const float kd = __shfl(key, K, 64);
+      int idx = lane;
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) {  // argmax over lanes 0..15 (lowest index among equals)
+        const float k2 = __shfl_xor(key, o, 64);
+        const int i2 = __shfl_xor(idx, o, 64);
+        if (k2 > key || (k2 == key && i2 < idx)) {
+          key = k2;
+          idx = i2;
+        }
+      }
+      const float kmax = __shfl(key, 0, 64);
+      const int pcol = (kd >= 0.25f * kmax && kd > 0.0f) ? K : __shfl(idx, 0, 64);
+      used |= 1u << pcol;
+      const double rp = 1.0 / rowK[pcol];
+      if (lane < NP) sF[lane] = (lane == pcol) ? 0.0 : rowK[lane] * rp;
+      if (lane == 0) sPerm[K] = pcol;
+      __syncthreads();
+      if (mine) {
+        const double mp = myrow[pcol];
+#pragma unroll 4
+        for (int jj = 0; jj < NP; ++jj) myrow[jj] -= sF[jj] * mp;
+        myrow[pcol] = mp * rp;
+      }
+      __syncthreads();
+    }
+  };
+  auto fill = [&](const int base, const bool backward) {
+    __syncthreads();
+    wb = base;
+    const int nl = min(W, L - base);
+    for (int e = lane; e < nl * Q; e += 64) {
+      const int l = base + (e >> 5), i = e & 31;
+      double v = 0.0;
+      if (backward) {
+        if (beam) v = Bv[l * Q + i] * d.att[(long)c * (L + 1) + l];
+        if (iso) v += vpoly(l, ts0[l], i);
+      } else if (l < Lm1) {
+        if (beam) v = (Bv[(l + 1) * Q + i] - Bv[l * Q + i]) * d.att[(long)c * (L + 1) + l + 1];
+        if (iso) v += vpoly(l + 1, ts0[l + 1], i) - vpoly(l, ts0[l + 1], i);
+      }
+      (&sPs[0][0])[e] = v;
+    }
+    for (int e = lane; e < nl * NP; e += 64) (&sEk[0][0])[e] = Ek[(long)base * NP + e];
+    __syncthreads();
+  };
+  if (lane < NP) {
+    const double t = d.T[lane];
+    sT[0][lane] = t;
+    sT[1][lane] = fast_rcp(t);
+  }
+  fill(0, false);
 
-  __shared__ double sSave[9][64];  // inputs of the running elimination, read back only when its speculation fails
   v4f64 a0 = load_d(Am, kq, col), y0 = load_d(Ym, kq, col);
   const int lsecond = min(1, Lm1);
   v4f64 a1 = load_d(Am + (long)lsecond * NN, kq, col), y1 = load_d(Ym + (long)lsecond * NN, kq, col);
@@ -931,9 +960,10 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
   //   Ta = Gm_0 = (Y + A/k)/T-rows,  Tb = Gp_0 E_0 = (Y - A/k)/T-rows E_0
   double ta[4], tb[4];
   {
+    const double rT_col = sT[1][col];
     const v4f64 eye = make_eye(kq, col);
     const v4f64 yt = mm_t(y0, eye), at = mm_t(a0, eye);
-    const v4f64 k_row = load_row(kk, kq), e_row = load_row(Ek, kq);
+    const v4f64 k_row = load_row(kk, kq), e_row = load_row(&sEk[0][0], kq);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const double av = at[q] * fast_rcp(k_row[q]);
@@ -945,18 +975,32 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
   if (beam) tv -= Bv[NP + col];
   if (iso) tv -= dq[NP + col];
 
+  // One layer per iteration, in this order:
+  //   loads     the operands of layer l + 2 (consumed by the NEXT iteration);
+  //   products  M1 = A_l^T Y', M2s = diag(k) Y_l^T A' diag(1/k') and their transposes, the particular-solution jump rho:
+  //             independent of the carry, in one block with
+  //   the elimination  [Ta^T ; Tb^T ; t^T] -> H = S^T, s   whose dependent steps leave the issue slots the MFMAs fill;
+  //   a wait    for the loads (issued a whole elimination ago), THEN the stores of H, s, rho_b: with loads and stores
+  //             both in flight every wait is a wait for the youngest store's acknowledgement (~4 000 cycles, measured:
+  //             40 % of an iteration when the stores came before the wait); stored here they have a whole iteration;
+  //   the carry of the next layer.
+  // (Everything the prologue loaded is waited for here: a register that still had a load pending at the loop's entry would
+  //  get a counted wait at its first use in the loop, and a counted wait is a wait for every OLDER operation -- the
+  //  previous iteration's stores.)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   for (int l = 0; l < L; ++l) {
-    // ---- loads: layer l+2's operands (consumed by the NEXT iteration: a full elimination hides their HBM latency)
-    //      and this interface's small vectors (consumed after the elimination)
+    // (kq, col from an opaque copy of the lane index: the compiler then rebuilds the few address VGPRs per iteration
+    //  instead of keeping dozens of hoisted ones alive and spilling)
     int lv = lane;
     asm volatile("" : "+v"(lv));
     const int kq = lv >> 4, col = lv & 15, rowbase = lv & 48;
     const int ln = min(l + 1, Lm1), l2 = min(l + 2, Lm1);
     const v4f64 a2 = load_d(Am + (long)l2 * NN, kq, col), y2 = load_d(Ym + (long)l2 * NN, kq, col);
     const double k2c = kk[l2 * NP + col];
-    const double e0c = Ek[l * NP + col];
-    const v4f64 e1r = load_row(Ek + ln * NP, kq);
-    // ---- elimination: [Ta^T ; Tb^T ; t^T] -> H = S^T (in tb), s (in tv)
+    if (ln >= wb + W) fill(l, false);
+    RTD_STAMP();  // 4 l + 1: loop top (register rotation, loads issued)
+    const int r0 = l - wb, r1 = ln - wb;
+    // ---- elimination (speculative: the diagonal as pivot; see GjFast)
     {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -964,42 +1008,27 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
         sSave[4 + q][lane] = tb[q];
       }
       sSave[8][lane] = tv;
-      int bad = d.flags & 1;
-      if (!bad) GjFast<4, 0>::run(ta, tb, tv, bad, col);
+      int bad = 0;
+      GjFast<4, 0>::run(ta, tb, tv, bad, col);
       bad |= (fabs(tv) + fabs(tb[0]) + fabs(tb[1]) + fabs(tb[2]) + fabs(tb[3]) < 1e300) ? 0 : 1;  // zero pivot: inf / nan
-      if (__any(bad)) {  // some diagonal pivot was too small: pivoted elimination from the saved inputs
+      bad |= d.flags & 1;
+      if (__any(bad)) {  // some diagonal pivot was too small: pivoted elimination of the saved inputs
+        pivoted_lds(true);
+        const int src = sPerm[col];  // unknown `col` sits in the column that was the pivot of step `col`
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          ta[q] = sSave[q][lane];
-          tb[q] = sSave[4 + q][lane];
-        }
-        tv = sSave[8][lane];
-        int pc = -1;
-        GjT<4, 0>::run(ta, tb, tv, pc, col, rowbase);
-        if (__any(pc != col)) {  // bring the columns back to their natural order
-          const int addr = (rowbase | pc) << 2;
-          tb[0] = push_lane(addr, tb[0]);
-          tb[1] = push_lane(addr, tb[1]);
-          tb[2] = push_lane(addr, tb[2]);
-          tb[3] = push_lane(addr, tb[3]);
-          tv = push_lane(addr, tv);
-        }
+        for (int q = 0; q < 4; ++q) tb[q] = sSave[4 + q][16 * kq + src];
+        tv = sSave[8][src];
+        __syncthreads();
       }
     }
+    RTD_STAMP();  // 4 l + 2: elimination
     if (l == Lm1) break;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loads of this iteration, before the stores go out
     double* ws = wsb + (long)l * Ws<NP>::SLOT;
 #pragma unroll
     for (int q = 0; q < 4; ++q) ws[Ws<NP>::S + (4 * q + kq) * NP + col] = tb[q];
     if (kq == 0) ws[Ws<NP>::SV + col] = tv;
-    v4f64 bu0 = {0.0, 0.0, 0.0, 0.0}, bd0 = bu0, bu1 = bu0, bd1 = bu0;
-    if (beam) {
-      bu0 = load_row(Bv + l * Q, kq);
-      bd0 = load_row(Bv + l * Q + NP, kq);
-      bu1 = load_row(Bv + ln * Q, kq);
-      bd1 = load_row(Bv + ln * Q + NP, kq);
-    }
-    // ---- interface products  M1 = A_l^T Y',  M2s = diag(k) Y_l^T A' diag(1/k')  and their transposes; the diagonal
-    //      scalings are column scalings of the operands
+    // ---- interface products; the diagonal scalings are column scalings of the operands (at l = L - 1 they are not used)
     v4f64 y0s, a1s;
     {
       const double rk1c = fast_rcp(k1c);
@@ -1010,29 +1039,28 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       }
     }
     const v4f64 m1 = mm_t(a0, y1), m1t = mm_t(y1, a0), m2s = mm_t(y0s, a1s), m2st = mm_t(a1s, y0s);
-    // particular-solution jump r_l at the interface (:184-205, :242-245) and rho = G_l^-1 r_l:
+    __builtin_amdgcn_sched_barrier(0);  // the products' operands die here; what follows keeps ~40 registers in flight
+    // rho = G_l^-1 r_l for the particular-solution jump r_l at the interface:
     //   rho_t/b = 1/4 [ V^-1 (r_up + r_dn) +- U^-1 (r_up - r_dn) ],  V^-1[j][i] = T_i A[i][j],  U^-1[j][i] = -k_j T_i Y[i][j]
-    const double tbnd = ts0[l + 1];
-    const double att = beam ? d.att[(long)c * (L + 1) + l + 1] : 0.0;
-    const v4f64 t_row = load_row(d.T, kq);
     double rt = 0.0, rb = 0.0;
+    {
+      const v4f64 t_row = load_row(&sT[0][0], kq);
+      const v4f64 ru = load_row(&sPs[r0][0], kq), rd = load_row(&sPs[r0][NP], kq);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int i = 4 * s + kq;
-      double ru = (bu1[s] - bu0[s]) * att, rd = (bd1[s] - bd0[s]) * att;
-      if (iso) {
-        ru += vpoly(l + 1, tbnd, i) - vpoly(l, tbnd, i);
-        rd += vpoly(l + 1, tbnd, NP + i) - vpoly(l, tbnd, NP + i);
+      for (int s = 0; s < 4; ++s) {
+        const double pa = t_row[s] * a0[s] * (ru[s] + rd[s]), pb = -t_row[s] * y0s[s] * (ru[s] - rd[s]);
+        rt += pa + pb;
+        rb += pa - pb;
       }
-      const double pa = t_row[s] * a0[s] * (ru + rd), pb = -t_row[s] * y0s[s] * (ru - rd);
-      rt += pa + pb;
-      rb += pa - pb;
+      rt = 0.25 * sum_kq(rt);
+      rb = 0.25 * sum_kq(rb);
     }
-    rt = 0.25 * sum_kq(rt);
-    rb = 0.25 * sum_kq(rb);
     if (kq == 0) ws[Ws<NP>::RB + col] = rb;
+    RTD_STAMP();  // 4 l + 3: wait, stores, products, rho
     // ---- carry of the next layer:  Ta'^T = -(Wq^T H E + Wp^T),  Tb'^T = -E' (Wp^T H E + Wq^T)  with
     //      Wp/Wq = (M1 +- M2s)/2:  X = M1^T H E, Z = M2s^T H E
+    const double e0c = sEk[r0][col];
+    const v4f64 e1r = load_row(&sEk[r1][0], kq);
     v4f64 he;
 #pragma unroll
     for (int q = 0; q < 4; ++q) he[q] = tb[q] * e0c;
@@ -1045,6 +1073,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       tb[q] = -0.5 * (xx[q] + zz[q] + m1t[q] - m2st[q]) * e1r[q];
     }
     tv = tnew;
+    RTD_STAMP();  // 4 l + 4: carry
     a0 = a1;
     y0 = y1;
     a1 = a2;
@@ -1058,15 +1087,14 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
   //      P0 = Y/T-rows, Q0 = A/(k T-rows), R = (1 + delta_m0) q (mu w).  Solved transposed like the carry.
   double cminus, cplus;
   {
-    const int l = Lm1;
+    const int l = Lm1, rL = Lm1 - wb;
     const double rkLc = fast_rcp(kk[l * NP + col]);
-    const v4f64 eLr = load_row(Ek + l * NP, kq), t_row = load_row(d.T, kq), eye = make_eye(kq, col);
+    const v4f64 eLr = load_row(&sEk[rL][0], kq), rT_row = load_row(&sT[1][0], kq), eye = make_eye(kq, col);
     v4f64 p0, q0, x1 = eye, x2 = eye, rtr = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const double rTr = fast_rcp(t_row[q]);
-      p0[q] = y0[q] * rTr;
-      q0[q] = a0[q] * rTr * rkLc;
+      p0[q] = y0[q] * rT_row[q];
+      q0[q] = a0[q] * rT_row[q] * rkLc;
     }
     const bool refl = mg < d.NBDRF;
     if (refl) {
@@ -1116,130 +1144,201 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     double rhs = br - col_dot(bat, col_to_row(tv, rowbase, kq));
     double none[4] = {0.0, 0.0, 0.0, 0.0};
     {
-      const double mt_in[4] = {mt[0], mt[1], mt[2], mt[3]};
-      const double rhs_in = rhs;
-      int bad = d.flags & 1;
-      if (!bad) GjFast<0, 0>::run(mt, none, rhs, bad, col);
-      bad |= (fabs(rhs) < 1e300) ? 0 : 1;
-      if (__any(bad)) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) mt[q] = mt_in[q];
-        rhs = rhs_in;
-        int pc = -1;
-        GjT<0, 0>::run(mt, none, rhs, pc, col, rowbase);
-        if (__any(pc != col)) rhs = push_lane((rowbase | pc) << 2, rhs);
+      for (int q = 0; q < 4; ++q) sSave[q][lane] = mt[q];
+      sSave[8][lane] = rhs;
+      int bad = 0;
+      GjFast<0, 0>::run(mt, none, rhs, bad, col);
+      bad |= (fabs(rhs) < 1e300) ? 0 : 1;
+      bad |= d.flags & 1;
+      if (__any(bad)) {
+        pivoted_lds(false);
+        rhs = sSave[8][sPerm[col]];
+        __syncthreads();
       }
     }
     cplus = rhs;
     cminus = tv - col_dot(hcur, col_to_row(cplus, rowbase, kq));
-    if (kq == 0) {
-      coef[(long)l * Q + col] = cminus;
-      coef[(long)l * Q + NP + col] = cplus;
-    }
     // a singular system (the reference's solve_banded / solve raises LinAlgError, :326-333, :383) leaves inf / nan here,
     // and they propagate through the whole backward sweep: one test at its end is enough
   }
   // ---- fused evaluation at the layer interfaces (d.um != null): u^m = G_l [e- C- ; e+ C+] + B_l exp(-tau*/mu0) (+ v) at
-  //      the bottom of layer l (e- = E_l, e+ = 1) and, for layer 0, at its top (e- = 1, e+ = E_0); with
+  //      the top of layer l (e- = 1, e+ = E_l) and, for the last layer, at its bottom (e- = E_L, e+ = 1); with
   //      Gp = (Y - A/k)/T, Gm = (Y + A/k)/T:  up = [Y (en + ep) - A (en - ep)/k]/T,  down = [Y (en + ep) + A (en - ep)/k]/T
-  //      (_assemble_intensity_and_fluxes.py:197-254).  Y_l, A_l are in registers (D layout), the sums over the eigen-index
-  //      are row sums over the 16 lanes of a lane-row.
+  //      (_assemble_intensity_and_fluxes.py:197-254).  The sums over the eigen-index are row sums over the 16 lanes of a
+  //      lane-row of the D layout.
+  RTD_STAMP();  // bottom boundary
   double* um = d.um ? d.um + cm * (L + 1) * Q : nullptr;
-  v4f64 rT_row = {0.0, 0.0, 0.0, 0.0};
-  if (um) {
-    const v4f64 t_row = load_row(d.T, kq);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) rT_row[q] = fast_rcp(t_row[q]);
-  }
-  // u^m at interface `tidx` from the two row sums  P = Y_l (e- C- + e+ C+),  Qs = A_l (e- C- - e+ C+) / k_l  of layer l
-  auto emit_pq = [&](const int l, const int tidx, const v4f64& P, const v4f64& Qs, const int kq, const int col) {
-    const double attv = beam ? d.att[(long)c * (L + 1) + tidx] : 0.0;
-    const double tsv = ts0[tidx];
-    const int c3 = col & 3, i = 4 * c3 + kq;  // lanes col < 4 store element i of the up- and of the down-streams
-    double up = 0.0, dn = 0.0;
+  // Results leave through LDS: a global store issued inside the sweep would make every later wait for a prefetched operand
+  // a wait for that store's acknowledgement as well.  The elimination's save area is free during the sweep: it takes the
+  // rows [C-_l, C+_l | u^m(tau_l)] of nine layers (row L: u^m(tau_L) only), which then go out as nine full-width stores,
+  // followed by an explicit wait: the stores are then out of the way of the counted waits of the next steps.
+  double* const sOut = &sSave[0][0];
+  int nstage = 0, ltop = L;  // slot k holds the rows of layer / interface ltop - k
+  auto flush = [&]() {
+    __syncthreads();
+#pragma unroll 1
+    for (int k2 = 0; k2 < nstage; ++k2) {
+      const long row = ltop - k2;
+      const double v = sOut[k2 * 64 + lane];
+      if (lane < 32) {
+        if (row < L) coef[row * Q + lane] = v;
+      } else if (um) {
+        um[row * Q + lane - 32] = v;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    ltop -= nstage;
+    nstage = 0;
+  };
+  // the homogeneous part of u^m at an interface from the two row sums  P = Y_l (e- C- + e+ C+),  Qs = A_l (e- C- - e+ C+) / k_l
+  // of layer l; lanes col < 4 hold element i = 4 (col & 3) + kq of the up- and of the down-streams
+  auto um_values = [&](const v4f64& P, const v4f64& Qs, const int kq, const int col, double& up, double& dn) {
+    const int c3 = col & 3;
+    const v4f64 rT_row = load_row(&sT[1][0], kq);
+    up = 0.0;
+    dn = 0.0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const double u_q = (P[q] - Qs[q]) * rT_row[q], d_q = (P[q] + Qs[q]) * rT_row[q];
       up = (c3 == q) ? u_q : up;
       dn = (c3 == q) ? d_q : dn;
     }
-    if (col < 4) {
-      if (beam) {
-        up += Bv[l * Q + i] * attv;
-        dn += Bv[l * Q + NP + i] * attv;
-      }
-      if (iso) {
-        up += vpoly(l, tsv, i);
-        dn += vpoly(l, tsv, NP + i);
-      }
-      um[(long)tidx * Q + i] = up;
-      um[(long)tidx * Q + NP + i] = dn;
-    }
   };
-  auto emit = [&](const int l, const int tidx, const v4f64& yl, const v4f64& al, const double en, const double ep,
-                  const double rk, const int kq, const int col) {
-    emit_pq(l, tidx, row_dot(yl, en + ep), row_dot(al, (en - ep) * rk), kq, col);
+  // C-_l, C+_l and (with the fused evaluation) u^m at the top of layer l into the next slot
+  auto stage = [&](const int l, const double cmn, const double cp, const v4f64& P, const v4f64& Qs, const int kq, const int col) {
+    if (nstage == 9) flush();
+    double* o = sOut + nstage * 64;
+    if (kq == 0) {
+      o[col] = cmn;
+      o[NP + col] = cp;
+    }
+    if (um) {
+      double up, dn;
+      um_values(P, Qs, kq, col, up, dn);
+      if (col < 4) {
+        const int i = 4 * (col & 3) + kq;
+        o[32 + i] = up + sPs[l - wb][i];
+        o[32 + NP + i] = dn + sPs[l - wb][NP + i];
+      }
+    }
+    ++nstage;
   };
   // ---- backward sweep: C+_l = Wq C-' + Wp E' C+' + rho_b ;  C-_l = s_l - S_l C+_l, with W applied through its
-  //      factors.  The loads of layer l-1 are issued while layer l is processed.
-  a1 = a0;
-  y1 = y0;
-  double k1b = kk[Lm1 * NP + col], e1b = Ek[Lm1 * NP + col];
-  if (um) {
-    const double rk = fast_rcp(k1b);
-    emit(Lm1, L, y0, a0, e1b * cminus, cplus, rk, kq, col);
-    if (Lm1 == 0) emit(0, 0, y0, a0, cminus, e1b * cplus, rk, kq, col);
+  //      factors: the row sums  w1 = Y' (C-' + E' C+'),  w2 = A' (E' C+' - C-') / k'  of the layer below are carried from
+  //      step to step, so that a step touches the operands of ONE layer only:
+  //          C+_l = rho_b + (A_l^T w1 + k_l Y_l^T w2) / 2 ,  C-_l = s_l - H_l^T C+_l ,  then w1, w2 of layer l.
+  //      Interface l for free: w1 and -w2 are the two row sums of the TOP of layer l (e- = 1, e+ = E_l).  The reference
+  //      evaluates tau = tau_arr[l - 1] in layer l - 1, from above the interface (_assemble_intensity_and_fluxes.py:185);
+  //      the continuity rows of the boundary-condition system make the two sides equal to the residual of the solve,
+  //      which is what the fused-vs-kernel test holds to 1e-13 of the field scale.
+  //      The sweep moves 6 KB per layer and does ~300 instructions on them: it runs at the speed of its loads (~3 000
+  //      cycles of latency against ~1 300 of arithmetic).  Three register sets rotate (the loop is unrolled by three so that
+  //      the rotation is a renaming, not a copy that would wait for the load): the operands of layer l - 3 are requested
+  //      when layer l has been consumed; a step has no load of its own and no store.
+  v4f64 w1, w2;
+  fill(max(L - W, 0), true);
+  {
+    const double kL = kk[Lm1 * NP + col], eL = sEk[Lm1 - wb][col], rk = fast_rcp(kL);
+    nstage = 1;  // slot 0 = row L: u^m at tau_L, the bottom of the last layer (e- = E_L, e+ = 1); no coefficients
+    if (um) {
+      const double en = eL * cminus, ep = cplus;
+      double up, dn;
+      um_values(row_dot(y0, en + ep), row_dot(a0, (en - ep) * rk), kq, col, up, dn);
+      if (col < 4) {
+        const int i = 4 * (col & 3) + kq;
+        if (beam) {
+          const double attv = d.att[(long)c * (L + 1) + L];
+          up += Bv[Lm1 * Q + i] * attv;
+          dn += Bv[Lm1 * Q + NP + i] * attv;
+        }
+        if (iso) {
+          up += vpoly(Lm1, ts0[L], i);
+          dn += vpoly(Lm1, ts0[L], NP + i);
+        }
+        sOut[32 + i] = up;
+        sOut[32 + NP + i] = dn;
+      }
+    }
+    const double x = cminus, y = eL * cplus;
+    w1 = row_dot(y0, x + y);
+    w2 = row_dot(a0, (y - x) * rk);
+    v4f64 nw2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) nw2[q] = -w2[q];
+    stage(Lm1, cminus, cplus, w1, nw2, kq, col);
   }
   if (Lm1 == 0) {  // single layer: no interface, no workspace
+    flush();
     if (!(fabs(cminus) + fabs(cplus) < 1e300)) atomicOr(d.status, RTD_ST_BC);
     return;
   }
-  int lp = Lm1 - 1;
-  v4f64 pa = load_d(Am + (long)lp * NN, kq, col), py = load_d(Ym + (long)lp * NN, kq, col), ph = load_d(wsb + (long)lp * Ws<NP>::SLOT + Ws<NP>::S, kq, col);
-  double psl = wsb[(long)lp * Ws<NP>::SLOT + Ws<NP>::SV + col], prb = wsb[(long)lp * Ws<NP>::SLOT + Ws<NP>::RB + col];
-  double pk = kk[lp * NP + col], pe = Ek[lp * NP + col];
-  for (int l = Lm1 - 1; l >= 0; --l) {
-    a0 = pa;
-    y0 = py;
-    const v4f64 hl = ph;
-    const double sl = psl, rb = prb, k0b = pk, e0b = pe;
+  struct BwSet {
+    v4f64 a, y, h;
+    double sl, rb, k;
+  };
+  auto load_set = [&](const int l) {
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const int kq = lv >> 4, col = lv & 15;
+    BwSet s;
+    const double* w = wsb + (long)l * Ws<NP>::SLOT;
+    s.a = load_d(Am + (long)l * NN, kq, col);
+    s.y = load_d(Ym + (long)l * NN, kq, col);
+    s.h = load_d(w + Ws<NP>::S, kq, col);
+    s.sl = w[Ws<NP>::SV + col];
+    s.rb = w[Ws<NP>::RB + col];
+    s.k = kk[l * NP + col];
+    return s;
+  };
+  auto step = [&](const int l, const BwSet& s) {
     int lv = lane;
     asm volatile("" : "+v"(lv));
     const int kq = lv >> 4, col = lv & 15, rowbase = lv & 48;
-    lp = max(l - 1, 0);
-    pa = load_d(Am + (long)lp * NN, kq, col);
-    py = load_d(Ym + (long)lp * NN, kq, col);
-    ph = load_d(wsb + (long)lp * Ws<NP>::SLOT + Ws<NP>::S, kq, col);
-    psl = wsb[(long)lp * Ws<NP>::SLOT + Ws<NP>::SV + col];
-    prb = wsb[(long)lp * Ws<NP>::SLOT + Ws<NP>::RB + col];
-    pk = kk[lp * NP + col];
-    pe = Ek[lp * NP + col];
-    const double x = cminus, y = e1b * cplus;
-    const v4f64 w1 = row_dot(y1, x + y), w2 = row_dot(a1, (y - x) * fast_rcp(k1b));
-    const double cp = rb + 0.5 * (col_dot(a0, w1) + k0b * col_dot(y0, w2));
-    if (um) {
-      // Interface l + 1 for free: w1 = Y' (C-' + E' C+') and -w2 = A' (C-' - E' C+') / k' are the two row sums of the TOP of
-      // layer l + 1 (e- = 1, e+ = E').  The reference evaluates tau = tau_arr[l] in layer l, from below the interface
-      // (_assemble_intensity_and_fluxes.py:185); the continuity rows of the boundary-condition system make the two sides
-      // equal to the residual of the solve, which is what the fused-vs-kernel test holds to 1e-13 of the field scale.
-      v4f64 nw2;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) nw2[q] = -w2[q];
-      emit_pq(l + 1, l + 1, w1, nw2, kq, col);
-    }
-    const double cmn = sl - col_dot(hl, col_to_row(cp, rowbase, kq));
-    if (kq == 0) {
-      coef[(long)l * Q + col] = cmn;
-      coef[(long)l * Q + NP + col] = cp;
-    }
-    if (um && l == 0) emit(0, 0, y0, a0, cmn, e0b * cp, fast_rcp(k0b), kq, col);  // tau = 0: the top of layer 0
+    if (l < wb) fill(max(l - W + 1, 0), true);
+    const double cp = s.rb + 0.5 * (col_dot(s.a, w1) + s.k * col_dot(s.y, w2));
+    RTD_STAMP();  // backward step: operands arrived, C+
+    const double cmn = s.sl - col_dot(s.h, col_to_row(cp, rowbase, kq));
     cminus = cmn;
     cplus = cp;
-    a1 = a0;
-    y1 = y0;
-    k1b = k0b;
-    e1b = e0b;
+    v4f64 nw2 = {0.0, 0.0, 0.0, 0.0};
+    if (l > 0 || um) {
+      const double x = cmn, y = sEk[l - wb][col] * cp;
+      w1 = row_dot(s.y, x + y);
+      w2 = row_dot(s.a, (y - x) * fast_rcp(s.k));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) nw2[q] = -w2[q];
+    }
+    stage(l, cmn, cp, w1, nw2, kq, col);
+    RTD_STAMP();  // backward step: C-, row sums, staging
+  };
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing pending at the loop's entry (see the forward loop)
+  // (issued in the order of their use: a set requested after a younger one would be waited for with a smaller count)
+  BwSet s0 = load_set(Lm1 - 1);
+  __builtin_amdgcn_sched_barrier(0);
+  BwSet s1 = load_set(max(Lm1 - 2, 0));
+  __builtin_amdgcn_sched_barrier(0);
+  BwSet s2 = load_set(max(Lm1 - 3, 0));
+  __builtin_amdgcn_sched_barrier(0);
+  // (the requests are unconditional -- past the top they repeat layer 0 -- so that the number of younger loads behind each
+  //  set is the same on every path and the waits stay counted)
+  for (int l = Lm1 - 1; l >= 0; l -= 3) {
+    step(l, s0);
+    s0 = load_set(max(l - 3, 0));
+    if (l < 1) break;
+    step(l - 1, s1);
+    s1 = load_set(max(l - 4, 0));
+    if (l < 2) break;
+    step(l - 2, s2);
+    s2 = load_set(max(l - 5, 0));
   }
+  flush();
+  RTD_STAMP();
+#ifdef RTD_BCF_STAMPS
+  if (lane == 0 && (cm == 1000 || cm == 30000 || cm == 60000 || (d.C <= 64 && (cm == 100 || cm == 300))))
+    for (int i = 1; i < min(nstamp, 512); ++i) printf("ST %d %d %lld\n", (int)cm, i, sStamp[i] - sStamp[i - 1]);
+#endif
   if (!(fabs(cminus) + fabs(cplus) < 1e300)) atomicOr(d.status, RTD_ST_BC);
 }
 
