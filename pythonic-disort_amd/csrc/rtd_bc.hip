@@ -869,13 +869,17 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
   __shared__ double sF[NP];
   // Diagnostic build (-DRTD_BCF_STAMPS): lane 0 of three chains records s_memtime at the phase boundaries and prints the
   // differences (tools/bc_phase_cycles.py formats them); this is how the stalls named in the comments were measured.
+  // The stamps split basic blocks: read the stamped build's own ISA before trusting a phase (its forward loop, unlike the
+  // product's, ends with a vmcnt(0) that waits for the stores).
 #ifdef RTD_BCF_STAMPS
   __shared__ long long sStamp[512];
   int nstamp = 0;
 #define RTD_STAMP()                                                                  \
   {                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                               \
     if (lane == 0 && nstamp < 512) sStamp[nstamp] = (long long)__builtin_amdgcn_s_memtime(); \
     ++nstamp;                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                               \
   }
 #else
 #define RTD_STAMP()
@@ -1073,6 +1077,9 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       tb[q] = -0.5 * (xx[q] + zz[q] + m1t[q] - m2st[q]) * e1r[q];
     }
     tv = tnew;
+#ifdef RTD_BCF_STAMPS
+    asm volatile("" ::"v"(ta[0]), "v"(ta[3]), "v"(tb[0]), "v"(tb[3]), "v"(tv));
+#endif
     RTD_STAMP();  // 4 l + 4: carry
     a0 = a1;
     y0 = y1;
