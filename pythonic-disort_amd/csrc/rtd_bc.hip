@@ -1369,6 +1369,9 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
 #ifndef RTD_GJ_GROWTH_TILED
 #define RTD_GJ_GROWTH_TILED 1e6
 #endif
+#ifndef RTD_BCT_WIN
+#define RTD_BCT_WIN 24  // layers of small vectors resident in LDS (T = 2: 18 KB next to the 17 KB save area, 4 wavefronts per CU)
+#endif
 template <int T> struct MatT { v4f64 t[T][T]; };  // t[I][J][q] at lane (kq, col) = element [16 I + 4 q + kq][16 J + col]
 template <int T> struct RowT { v4f64 r[T]; };     // vector in row form:    r[I][q] = v[16 I + 4 q + kq], same in every column
 template <int T> struct ColT { double c[T]; };    // vector in column form: c[J] = v[16 J + col], same in every lane-row
@@ -1625,6 +1628,34 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
     return ok;
   };
 
+  // The chain's small vectors for a window of RTD_BCT_WIN layers in LDS, as in rtd_bc_mfma_kernel: exp(-k dtau), the stream
+  // scaling T, and the particular solution (beam + thermal) as the forward sweep needs it -- its jump r_l at the interface
+  // below layer l (:184-205, :242-245).  The loops then have no global load that is consumed at once.
+  constexpr int W = RTD_BCT_WIN;
+  __shared__ double sPs[W][Q];
+  __shared__ double sEk[W][NP];
+  __shared__ double sT[NP];
+  int wb = 0;  // the window holds layers [wb, wb + W)
+  auto fill = [&](const int base, const bool with_jump) {
+    __syncthreads();
+    wb = base;
+    const int nl = min(W, L - base);
+    if (with_jump)
+      for (int e = lane; e < nl * Q; e += 64) {
+        const int l = base + e / Q, i = e % Q;
+        double v = 0.0;
+        if (l < Lm1) {
+          if (beam) v = (Bv[(l + 1) * Q + i] - Bv[l * Q + i]) * d.att[(long)c * (L + 1) + l + 1];
+          if (iso) v += vpoly(l + 1, ts0[l + 1], i) - vpoly(l, ts0[l + 1], i);
+        }
+        (&sPs[0][0])[e] = v;
+      }
+    for (int e = lane; e < nl * NP; e += 64) (&sEk[0][0])[e] = Ek[(long)base * NP + e];
+    __syncthreads();
+  };
+  if (lane < NP) sT[lane] = d.T[lane];
+  fill(0, true);
+
   MatT<T> a0 = load_d(Am, kq, col), y0 = load_d(Ym, kq, col);
   const int lsecond = min(1, Lm1);
   MatT<T> a1 = load_d(Am + (long)lsecond * NN, kq, col), y1 = load_d(Ym + (long)lsecond * NN, kq, col);
@@ -1641,7 +1672,7 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
   {
     const MatT<T> eye = make_eye(kq, col);
     const MatT<T> yt = mmT<T>(y0, eye), at = mmT<T>(a0, eye);
-    const RowT<T> k_row = load_row(kk, kq), e_row = load_row(Ek, kq);
+    const RowT<T> k_row = load_row(kk, kq), e_row = load_row(&sEk[0][0], kq);
 #pragma unroll
     for (int I = 0; I < T; ++I)
 #pragma unroll
@@ -1665,21 +1696,24 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
     for (int J = 0; J < T; ++J) tv.c[J] -= b.c[J];
   }
 
+  // One layer per iteration: loads (layer l + 2's operands, consumed by the NEXT iteration: one wavefront per SIMD, nothing
+  // else hides their latency), the elimination, an explicit wait for the loads and only THEN the stores of H, s, rho_b (with
+  // loads and stores both in flight every wait is a wait for the youngest store's acknowledgement), rho, the carry.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing of the prologue pending at the loop's entry (see rtd_bc_mfma_kernel)
   for (int l = 0; l < L; ++l) {
     int lv = lane;
     asm volatile("" : "+v"(lv));
     const int kq = lv >> 4, col = lv & 15, rowbase = lv & 48;
     const int ln = min(l + 1, Lm1), l2 = min(l + 2, Lm1);
-    // layer l+2's operands: consumed by the NEXT iteration (one wavefront per SIMD: nothing else hides their latency)
     const MatT<T> a2 = load_d(Am + (long)l2 * NN, kq, col), y2 = load_d(Ym + (long)l2 * NN, kq, col);
     const ColT<T> k2c = load_col(kk + l2 * NP, col);
-    const ColT<T> e0c = load_col(Ek + l * NP, col);
-    const RowT<T> e1r = load_row(Ek + ln * NP, kq);
+    if (ln >= wb + W) fill(l, true);
+    const int r0 = l - wb, r1 = ln - wb;
     // ---- elimination: [Ta^T ; Tb^T ; t^T] -> H = S^T (in tb), s (in tv)
     {
       save_inputs(ta, tb, tv, kq, col);
-      int bad = d.flags & 1;  // test hook (RTD_BC_FORCE_PIVOT): every elimination takes the pivoted redo
-      if (!bad) GjFastT<T, 0>::run(ta, tb, tv, bad, col);
+      int bad = 0;
+      GjFastT<T, 0>::run(ta, tb, tv, bad, col);
       auto finite = [&]() {
         double chk = 0.0;
 #pragma unroll
@@ -1691,6 +1725,7 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
         return chk < 1e300;
       };
       bad |= finite() ? 0 : 1;  // zero pivot: inf / nan
+      bad |= d.flags & 1;       // test hook (RTD_BC_FORCE_PIVOT): every elimination takes the pivoted redo
       if (__any(bad)) {  // some diagonal pivot was too small: the pivoted elimination from the saved inputs
         const bool ok = pivoted_redo(tb, tv, kq, col);
         if (__any(!ok || !finite())) {
@@ -1700,6 +1735,7 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
       }
     }
     if (l == Lm1) break;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loads of this iteration, before the stores go out
     double* ws = wsb + (long)l * Ws<NP>::SLOT;
 #pragma unroll
     for (int I = 0; I < T; ++I)
@@ -1710,7 +1746,7 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
     if (kq == 0)
 #pragma unroll
       for (int J = 0; J < T; ++J) ws[Ws<NP>::SV + 16 * J + col] = tv.c[J];
-    // ---- particular-solution jump r_l at the interface (:184-205, :242-245) and rho = G_l^-1 r_l:
+    // ---- rho = G_l^-1 r_l for the particular-solution jump r_l at the interface:
     //   rho_t/b = 1/4 [ V^-1 (r_up + r_dn) +- U^-1 (r_up - r_dn) ],  V^-1[j][i] = T_i A[i][j],  U^-1[j][i] = -k_j T_i Y[i][j]
     MatT<T> y0s, a1s;
 #pragma unroll
@@ -1726,26 +1762,14 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
     }
     ColT<T> rt, rb;
     {
-      const double tbnd = ts0[l + 1];
-      const double att = beam ? d.att[(long)c * (L + 1) + l + 1] : 0.0;
-      const RowT<T> t_row = load_row(d.T, kq);
+      const RowT<T> t_row = load_row(&sT[0], kq), ru = load_row(&sPs[r0][0], kq), rd = load_row(&sPs[r0][NP], kq);
       RowT<T> vs, vd;  // T (r_up + r_dn), -T (r_up - r_dn) in row form
 #pragma unroll
       for (int I = 0; I < T; ++I)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int i = 16 * I + 4 * q + kq;
-          double ru = 0.0, rd = 0.0;
-          if (beam) {
-            ru = (Bv[ln * Q + i] - Bv[l * Q + i]) * att;
-            rd = (Bv[ln * Q + NP + i] - Bv[l * Q + NP + i]) * att;
-          }
-          if (iso) {
-            ru += vpoly(l + 1, tbnd, i) - vpoly(l, tbnd, i);
-            rd += vpoly(l + 1, tbnd, NP + i) - vpoly(l, tbnd, NP + i);
-          }
-          vs.r[I][q] = t_row.r[I][q] * (ru + rd);
-          vd.r[I][q] = -t_row.r[I][q] * (ru - rd);
+          vs.r[I][q] = t_row.r[I][q] * (ru.r[I][q] + rd.r[I][q]);
+          vd.r[I][q] = -t_row.r[I][q] * (ru.r[I][q] - rd.r[I][q]);
         }
 #pragma unroll
       for (int J = 0; J < T; ++J) {
@@ -1767,6 +1791,8 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
     // ---- carry of the next layer:  Ta'^T = -(Wq^T H E + Wp^T),  Tb'^T = -E' (Wp^T H E + Wq^T)  with
     //      Wp/Wq = (M1 +- M2s)/2, M1 = A_l^T Y', M2s = diag(k) Y_l^T A' diag(1/k'):  X = M1^T H E, Z = M2s^T H E;
     //      t' = rho_t - E (s - S rho_b).  Products are formed and consumed one after the other (registers).
+    const ColT<T> e0c = load_col(&sEk[r0][0], col);
+    const RowT<T> e1r = load_row(&sEk[r1][0], kq);
     ColT<T> tnew;
     {
       const ColT<T> srb = col_dotT<T>(tb, col_to_rowT<T>(rb, rowbase, kq));
@@ -1822,7 +1848,7 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
   ColT<T> cminus, cplus;
   {
     const int l = Lm1;
-    const RowT<T> eLr = load_row(Ek + l * NP, kq), t_row = load_row(d.T, kq);
+    const RowT<T> eLr = load_row(&sEk[l - wb][0], kq), t_row = load_row(&sT[0], kq);
     const ColT<T> kLc = load_col(kk + l * NP, col);
     const MatT<T> eye = make_eye(kq, col);
     MatT<T> p0, q0, x1 = eye, x2 = eye, rtr;
@@ -1916,8 +1942,8 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
 #pragma unroll
         for (int J = 0; J < T; ++J) none.t[I][J] = v4f64{0.0, 0.0, 0.0, 0.0};
       save_inputs(mt, none, rhs, kq, col);
-      int bad = d.flags & 1;
-      if (!bad) GjFastT<T, 0>::run(mt, none, rhs, bad, col);  // (the updates of the zero block cost 16 T^2 FMAs per step: once per chain)
+      int bad = 0;
+      GjFastT<T, 0>::run(mt, none, rhs, bad, col);  // (the updates of the zero block cost 16 T^2 FMAs per step: once per chain)
       auto finite = [&]() {
         double chk = 0.0;
 #pragma unroll
@@ -1925,6 +1951,7 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
         return chk < 1e300;
       };
       bad |= finite() ? 0 : 1;
+      bad |= d.flags & 1;
       if (__any(bad)) {
         const bool ok = pivoted_redo(none, rhs, kq, col);
         if (__any(!ok || !finite())) {
@@ -1939,55 +1966,105 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
 #pragma unroll
       for (int J = 0; J < T; ++J) cminus.c[J] = tv.c[J] - sc.c[J];
     }
+  }
+  // ---- backward sweep: C+_l = Wq C-' + Wp E' C+' + rho_b ;  C-_l = s_l - S_l C+_l, with W applied through its factors
+  //      Wq x + Wp y = [A_l^T Y' (x + y) + k_l Y_l^T A' ((y - x)/k')] / 2:  the row sums  w1 = Y' (C-' + E' C+'),
+  //      w2 = A' (E' C+' - C-') / k'  of the layer below are carried from step to step, so that a step touches the operands of
+  //      ONE layer only.  Two operand sets rotate (loop unrolled by two: a renaming, not a copy that would wait for the
+  //      load); the coefficients are staged in the (now free) save area of the elimination and leave as full-width
+  //      stores every NSLOT layers -- a store inside the sweep would turn every wait for an operand into a wait for
+  //      that store's acknowledgement.
+  constexpr int NSLOT = (NROW * LDM) / Q;
+  double* const sOut = sM;
+  int nstage = 0, ltop = Lm1;  // slot s holds [C-, C+] of layer ltop - s
+  auto flush = [&]() {
+    __syncthreads();
+#pragma unroll 1
+    for (int s2 = 0; s2 < nstage; ++s2)
+      for (int e = lane; e < Q; e += 64) coef[(long)(ltop - s2) * Q + e] = sOut[s2 * Q + e];
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    ltop -= nstage;
+    nstage = 0;
+  };
+  auto stage = [&](const ColT<T>& cm_, const ColT<T>& cp_, const int kq, const int col) {
+    if (nstage == NSLOT) flush();
     if (kq == 0)
 #pragma unroll
       for (int J = 0; J < T; ++J) {
-        coef[(long)l * Q + 16 * J + col] = cminus.c[J];
-        coef[(long)l * Q + NP + 16 * J + col] = cplus.c[J];
+        sOut[nstage * Q + 16 * J + col] = cm_.c[J];
+        sOut[nstage * Q + NP + 16 * J + col] = cp_.c[J];
       }
-  }
-  // ---- backward sweep: C+_l = Wq C-' + Wp E' C+' + rho_b ;  C-_l = s_l - S_l C+_l, with W applied through its factors
-  //      Wq x + Wp y = [A_l^T Y' (x + y) + k_l Y_l^T A' ((y - x)/k')] / 2
-  a1 = a0;
-  y1 = y0;
-  ColT<T> k1b = load_col(kk + Lm1 * NP, col), e1b = load_col(Ek + Lm1 * NP, col);
-  for (int l = Lm1 - 1; l >= 0; --l) {
-    int lv = lane;
-    asm volatile("" : "+v"(lv));
-    const int kq = lv >> 4, col = lv & 15, rowbase = lv & 48;
-    const double* ws = wsb + (long)l * Ws<NP>::SLOT;
-    a0 = load_d(Am + (long)l * NN, kq, col);
-    y0 = load_d(Ym + (long)l * NN, kq, col);
-    const MatT<T> hl = load_d(ws + Ws<NP>::S, kq, col);
-    const ColT<T> sl = load_col(ws + Ws<NP>::SV, col), rb = load_col(ws + Ws<NP>::RB, col);
-    const ColT<T> k0b = load_col(kk + l * NP, col), e0b = load_col(Ek + l * NP, col);
+    ++nstage;
+  };
+  fill(max(L - W, 0), false);
+  RowT<T> w1, w2;
+  auto row_sums = [&](const MatT<T>& yl, const MatT<T>& al, const ColT<T>& kl, const ColT<T>& el) {
     ColT<T> xpy, ymx;
 #pragma unroll
     for (int J = 0; J < T; ++J) {
-      const double x = cminus.c[J], y = e1b.c[J] * cplus.c[J];
+      const double x = cminus.c[J], y = el.c[J] * cplus.c[J];
       xpy.c[J] = x + y;
-      ymx.c[J] = (y - x) * fast_rcp(k1b.c[J]);
+      ymx.c[J] = (y - x) * fast_rcp(kl.c[J]);
     }
-    const RowT<T> w1 = row_dotT<T>(y1, xpy), w2 = row_dotT<T>(a1, ymx);
-    const ColT<T> t1 = col_dotT<T>(a0, w1), t2 = col_dotT<T>(y0, w2);
+    w1 = row_dotT<T>(yl, xpy);
+    w2 = row_dotT<T>(al, ymx);
+  };
+  stage(cminus, cplus, kq, col);
+  row_sums(y0, a0, load_col(kk + Lm1 * NP, col), load_col(&sEk[Lm1 - wb][0], col));
+  struct BwSet {
+    MatT<T> a, y, h;
+    ColT<T> sl, rb, k;
+  };
+  auto load_set = [&](const int l) {
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const int kq = lv >> 4, col = lv & 15;
+    BwSet s;
+    const double* ws = wsb + (long)l * Ws<NP>::SLOT;
+    s.a = load_d(Am + (long)l * NN, kq, col);
+    s.y = load_d(Ym + (long)l * NN, kq, col);
+    s.h = load_d(ws + Ws<NP>::S, kq, col);
+    s.sl = load_col(ws + Ws<NP>::SV, col);
+    s.rb = load_col(ws + Ws<NP>::RB, col);
+    s.k = load_col(kk + l * NP, col);
+    return s;
+  };
+  auto step = [&](const int l, const BwSet& s) {
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const int kq = lv >> 4, col = lv & 15, rowbase = lv & 48;
+    const ColT<T> t1 = col_dotT<T>(s.a, w1), t2 = col_dotT<T>(s.y, w2);
     ColT<T> cp;
 #pragma unroll
-    for (int J = 0; J < T; ++J) cp.c[J] = rb.c[J] + 0.5 * (t1.c[J] + k0b.c[J] * t2.c[J]);
-    const ColT<T> hc = col_dotT<T>(hl, col_to_rowT<T>(cp, rowbase, kq));
+    for (int J = 0; J < T; ++J) cp.c[J] = s.rb.c[J] + 0.5 * (t1.c[J] + s.k.c[J] * t2.c[J]);
+    const ColT<T> hc = col_dotT<T>(s.h, col_to_rowT<T>(cp, rowbase, kq));
 #pragma unroll
-    for (int J = 0; J < T; ++J) cminus.c[J] = sl.c[J] - hc.c[J];
+    for (int J = 0; J < T; ++J) cminus.c[J] = s.sl.c[J] - hc.c[J];
     cplus = cp;
-    if (kq == 0)
-#pragma unroll
-      for (int J = 0; J < T; ++J) {
-        coef[(long)l * Q + 16 * J + col] = cminus.c[J];
-        coef[(long)l * Q + NP + 16 * J + col] = cplus.c[J];
-      }
-    a1 = a0;
-    y1 = y0;
-    k1b = k0b;
-    e1b = e0b;
+    stage(cminus, cplus, kq, col);
+    if (l > 0) row_sums(s.y, s.a, s.k, load_col(&sEk[l - wb][0], col));
+  };
+  // One pass of the outer loop per window of the small vectors; the requests of the sets are unconditional (past the top
+  // they repeat layer 0) so that the waits stay counted.
+  for (int lhi = Lm1 - 1; lhi >= 0;) {
+    if (lhi < wb) fill(max(lhi - W + 1, 0), false);
+    const int llo = wb;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    BwSet s0 = load_set(lhi);
+    __builtin_amdgcn_sched_barrier(0);
+    BwSet s1 = load_set(max(lhi - 1, 0));
+    __builtin_amdgcn_sched_barrier(0);
+    for (int l = lhi; l >= llo; l -= 2) {
+      step(l, s0);
+      s0 = load_set(max(l - 2, 0));
+      if (l - 1 < llo) break;
+      step(l - 1, s1);
+      s1 = load_set(max(l - 3, 0));
+    }
+    lhi = llo - 1;
   }
+  flush();
   double chk = 0.0;
 #pragma unroll
   for (int J = 0; J < T; ++J) chk += fabs(cminus.c[J]) + fabs(cplus.c[J]);
