@@ -52,7 +52,11 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
   const double* ts0 = d.taus0 + (long)c * (L + 1);
   if (tid == 0) {
     int l = 0;
-    while (l < L - 1 && !(tau <= tau_arr[l])) ++l;  // argmax(tau <= tau_arr)  (:185)
+    // argmax(tau <= tau_arr)  (:185); with the fused evaluation the points are the interfaces [0, tau_arr] (checked by
+    // rtd_plan_set_eval_points): point t lies in layer max(t - 1, 0), no search (a chain of dependent loads) needed
+    if (ev.um_in != nullptr) l = t > 0 ? t - 1 : 0;
+    else
+      while (l < L - 1 && !(tau <= tau_arr[l])) ++l;
     if (!(tau >= 0.0) || !(tau <= tau_arr[L - 1])) atomicOr(d.status, 1);
     s_l = l;
     s_ts = ts0[l + 1] - (tau_arr[l] - tau) * d.scale[(long)c * L + l];  // (:190-195)
@@ -182,6 +186,86 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
   }
 }
 
+// The throughput path: the boundary-condition kernel has left u^m at the points already (the layer interfaces [0, tau_arr],
+// checked by rtd_plan_set_eval_points), only the Fourier sum (:256-262), the zeroth mode and the fluxes (:519, :568-601)
+// remain.  One thread per (point, stream): a workgroup takes FT_T consecutive points of one column, so that every mode's
+// slice is one contiguous read; no layer search, no LDS staging of the modes.  Same arithmetic, in the same order, as the
+// corresponding part of rtd_eval_kernel (which stays the kernel of every other evaluation).
+constexpr int FT_T = 8;
+template <int NP>
+__global__ __launch_bounds__(EVAL_THREADS) void rtd_fourier_kernel(RtdDev d, RtdEval ev) {
+  constexpr int Q = 2 * NP;
+  static_assert(FT_T * Q <= 2 * EVAL_THREADS, "at most two (point, stream) pairs per thread");
+  const int M = d.M, L = d.L, N = d.N, Qr = 2 * N;
+  const int nchunk = (ev.ntau + FT_T - 1) / FT_T;
+  const int c = (int)(blockIdx.x / nchunk), t0 = (int)(blockIdx.x % nchunk) * FT_T;
+  const int nt = min(FT_T, ev.ntau - t0), tid = threadIdx.x;
+  __shared__ double s_um0[FT_T][Q];  // zeroth mode of the chunk's points (fluxes)
+  const double rescale = d.rescale[c];
+  const double phi0 = d.phi0[c];
+  const bool own0 = d.m0 == 0, ownlast = d.m0 + d.mstep * (M - 1) == d.mtot - 1;
+  for (int idx = tid; idx < nt * Qr; idx += EVAL_THREADS) {
+    const int tl = idx / Qr, ir = idx % Qr, t = t0 + tl;
+    const int i2 = ir < N ? ir : NP + (ir - N);
+    const double* um = ev.um_in + ((long)c * M * ev.ntau + t) * Q + i2;  // mode m at um[m * ntau * Q]
+    const long mstride = (long)ev.ntau * Q;
+    const double first = um[0], last = um[(long)(M - 1) * mstride];
+    s_um0[tl][i2] = first;
+    if (ev.u0 != nullptr) ev.u0[((long)c * Qr + ir) * ev.ntau + t] = own0 ? rescale * first : 0.0;
+    if (ev.ulast != nullptr) ev.ulast[((long)c * Qr + ir) * ev.ntau + t] = ownlast ? rescale * last : 0.0;
+    if (ev.u != nullptr) {
+      for (int p0 = 0; p0 < ev.nphi; p0 += 4) {  // four azimuths per pass over the modes
+        double cs[4], ckm1[4], ck[4], acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double dl = phi0 - ev.phi[min(p0 + q, ev.nphi - 1)];
+          // sum_k um[k] cos((m0 + k mstep) dl): Chebyshev recurrence in steps of mstep
+          cs[q] = cos(d.mstep * dl);
+          ckm1[q] = cos((d.m0 - d.mstep) * dl);
+          ck[q] = cos(d.m0 * dl);
+          acc[q] = 0.0;
+        }
+        for (int m = 0; m < M; ++m) {
+          const double v = um[(long)m * mstride];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[q] += v * ck[q];
+            const double cn = 2.0 * cs[q] * ck[q] - ckm1[q];
+            ckm1[q] = ck[q];
+            ck[q] = cn;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (p0 + q < ev.nphi) ev.u[(((long)c * Qr + ir) * ev.ntau + t) * ev.nphi + p0 + q] = rescale * acc[q];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < nt && (ev.fup != nullptr || ev.fdn != nullptr || ev.fdir != nullptr)) {
+    const int t = t0 + tid, l = t > 0 ? t - 1 : 0;
+    double fu = 0.0, fd = 0.0;
+    for (int i = 0; i < N; ++i) {
+      const double mw = d.mu[i] * d.w[i];
+      fu += mw * s_um0[tid][i];
+      fd += mw * s_um0[tid][NP + i];
+    }
+    double direct = 0.0, direct_s = 0.0;
+    if (d.beam != 0) {
+      const double tau = ev.tau[(long)c * ev.ntau + t];
+      const double ts = d.taus0[(long)c * (L + 1) + l + 1] - (d.tau[(long)c * L + l] - tau) * d.scale[(long)c * L + l];  // (:190-195)
+      const double I0 = d.I0[c], mu0 = d.mu0[c];
+      direct = I0 * mu0 * exp(-tau / mu0);
+      direct_s = I0 * mu0 * exp(-ts / mu0);
+    }
+    const long o = (long)c * ev.ntau + t;
+    const double own = (d.m0 == 0) ? 1.0 : 0.0;  // fluxes come from the zeroth mode (mode shards: its owner only)
+    if (ev.fup != nullptr) ev.fup[o] = own * rescale * 2.0 * M_PI * fu;
+    if (ev.fdn != nullptr) ev.fdn[o] = own * rescale * (2.0 * M_PI * fd + direct_s - direct);
+    if (ev.fdir != nullptr) ev.fdir[o] = own * rescale * direct;
+  }
+}
+
 // the reference's tensors of one column, in the reference's layout (unpadded)
 __global__ void rtd_export_kernel(RtdDev d, int col, double* GC, double* K, double* B, double* Gim, double* G) {
   const int N = d.N, NP = d.NP, Qr = 2 * N, Q = 2 * NP, M = d.M, L = d.L;
@@ -213,6 +297,12 @@ __global__ void rtd_export_kernel(RtdDev d, int col, double* GC, double* K, doub
 }  // namespace
 
 void rtd_launch_eval(const RtdDev& d, const RtdEval& e, hipStream_t s) {
+  if (e.um_in != nullptr && e.antider == 0 && (d.NP == 16 || d.NP == 32)) {  // u^m is there already: sums only
+    const dim3 g((unsigned)((long)d.C * ((e.ntau + FT_T - 1) / FT_T)));
+    if (d.NP == 16) hipLaunchKernelGGL(rtd_fourier_kernel<16>, g, dim3(EVAL_THREADS), 0, s, d, e);
+    else hipLaunchKernelGGL(rtd_fourier_kernel<32>, g, dim3(EVAL_THREADS), 0, s, d, e);
+    return;
+  }
   const dim3 grid((unsigned)((long)e.ntau * d.C));  // 1-D: no 65535 limit on the column count
   const size_t shm = (size_t)2 * d.M * 2 * d.NP * sizeof(double);
   switch (d.NP) {
