@@ -818,6 +818,12 @@ def test_fused_interface_evaluation_equals_the_evaluation_kernel(amd):
     full.update(s_poly_coeffs=np.tile(np.array([[0.3, 0.02, 0.001]]), (12, 9, 1)), b_pos=0.2, b_neg=0.1,
                 bdrf_q=np.full((12, 1, 16, 16), 0.4), bdrf_q0=np.full((12, 1, 16), 0.4))
     cases["all_sources"] = full
+    # more layers than the 20-layer window of small vectors the kernel keeps in LDS: refills in both sweeps
+    cases["47_layers"] = synthetic.cfg4_columns(4, L=47)
+    deep = synthetic.cfg4_columns(3, L=45)
+    deep.update(s_poly_coeffs=np.tile(np.array([[0.3, 0.02, 0.001]]), (3, 45, 1)), b_pos=0.2, b_neg=0.1,
+                bdrf_q=np.full((3, 1, 16, 16), 0.4), bdrf_q0=np.full((3, 1, 16), 0.4))
+    cases["all_sources_45_layers"] = deep
     for name, cfg in cases.items():
         C = cfg["tau_arr"].shape[0]
         for shard in (None, (1, 3)):
