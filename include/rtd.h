@@ -190,11 +190,11 @@ int rtd_solve_tensors(const rtd_dims* dims, int32_t device, const rtd_inputs* in
 /* When enabled, rtd_plan_run/solve bracket each kernel with HIP events on the plan's stream. */
 int rtd_plan_enable_timing(rtd_plan* plan, int32_t enable);
 /* accumulated milliseconds per kernel slot since the last reset (slot names as returned by the Python wrapper):
- * [0] "tables" Legendre tables; [2] "jacobi" the fused rtd_eigen_kernel ([1] "asm" and [3] "post" are the empty slots of
- * the earlier three-kernel eigen stage); [4] "iface" rtd_iface_kernel -- or, at 64 streams, the tiled fused
+ * [0] "tables" Legendre tables; [2] "jacobi" the fused rtd_eigen_kernel; [1] "asm" and [3] "post" are the empty slots of
+ * the earlier three-kernel eigen stage; [4] "iface" rtd_iface_kernel -- or, at 64 streams, the tiled fused
  * rtd_bc_tile_kernel; [5] "sweep" rtd_sweep_kernel -- or the fused rtd_bc_mfma_kernel when 16 < NQuad <= 32 (slot 4 is
  * then empty) -- or, at 64 streams, the pivoted kernels' pass over the chains the tiled kernel flagged; [6] "eval"
- * rtd_eval_kernel (+ NT corrections).  Launches counted in nlaunch[7] (one per window of columns).  Synchronises; with timing
+ * rtd_eval_kernel or, with the fused interface evaluation, rtd_fourier_kernel, plus the NT corrections.  Launches counted in nlaunch[7] (one per window of columns).  Synchronises; with timing
  * enabled every window starts with a stream synchronisation: a measurement mode, not the throughput path. */
 int rtd_plan_get_timing(rtd_plan* plan, double ms[7], int64_t nlaunch[7], int32_t reset);
 /* number of (column, mode) chains of the last window solved whose speculative (diagonal-pivot) elimination failed in
