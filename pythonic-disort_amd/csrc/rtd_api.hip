@@ -426,7 +426,7 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
     A(d.Ym, Cw * M * L * NP * NP) A(d.Am, Cw * M * L * NP * NP) A(d.kk, Cw * M * L * NP) A(d.Bv, Cw * M * L * Q2)
     A(d.dq, Cw * L * Ns * Q2) A(d.zneg, Cw * L * NP) A(d.coef, Cw * M * L * Q2)
     A(d.Fws, Cw * M * (L - 1) * Q2 * Q2) A(d.Ek, Cw * M * L * NP) A(d.need_split, Cw * M)
-    A(d.sweeps, 1) A(d.status, 1)
+    A(d.sweeps, 1) A(d.status, 1) A(d.split_any, 1)
 #undef A
     if (pass == 0) {
       void* q = nullptr;
@@ -446,6 +446,7 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   d.spoly = spoly; d.bdrfq = bq; d.bdrfq0 = bq0; d.lperm = lperm;
   HIP_TRY(hipMemsetAsync(d.status, 0, sizeof(int), p->stream));
   HIP_TRY(hipMemsetAsync(d.sweeps, 0, sizeof(int), p->stream));
+  HIP_TRY(hipMemsetAsync(d.split_any, 0, sizeof(int), p->stream));
   HIP_TRY(hipMemsetAsync(d.Bv, 0, (size_t)(Cw * M * L * Q2) * 8, p->stream));
   if (Ns > 0) HIP_TRY(hipMemsetAsync(d.dq, 0, (size_t)(Cw * L * Ns * Q2) * 8, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));

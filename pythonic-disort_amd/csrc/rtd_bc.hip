@@ -1511,7 +1511,10 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
   const bool beam = d.beam != 0;
   const double mu0 = beam ? d.mu0[c] : 1.0;
   if ((d.flags & 2) && cm % 3 == 0) {  // test hook (RTD_BC_FORCE_HANDOVER): every third chain goes to the pivoted kernels
-    if (lane == 0) need_split[cm] = 1;
+    if (lane == 0) {
+      need_split[cm] = 1;
+      *d.split_any = 1;
+    }
     return;
   }
   auto vpoly = [&](int l, double t, int idx) {
@@ -1557,7 +1560,10 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
     return e;
   };
   auto fail_chain = [&]() {  // this chain could not be solved here: hand it to the row-per-lane kernels
-    if (lane == 0) need_split[cm] = 1;
+    if (lane == 0) {
+      need_split[cm] = 1;
+      *d.split_any = 1;  // (they do not evaluate at the interfaces: the evaluation kernel then does it for the window)
+    }
   };
   // The inputs of the running elimination, row-major [2 NP + 1][NP] (+1 padding): read back only when its speculation fails.
   // Then the same elimination is done once more, column-pivoted, straight on this LDS copy: every lane owns a row (rows
@@ -1634,17 +1640,22 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
   constexpr int W = RTD_BCT_WIN;
   __shared__ double sPs[W][Q];
   __shared__ double sEk[W][NP];
-  __shared__ double sT[NP];
+  __shared__ double sT[2][NP];  // T and 1 / T
   int wb = 0;  // the window holds layers [wb, wb + W)
-  auto fill = [&](const int base, const bool with_jump) {
+  // mode 1: the jump r_l (forward sweep); 2: the particular solution at the top of layer l (the fused evaluation of the
+  // backward sweep); 0: exp(-k dtau) only
+  auto fill = [&](const int base, const int mode) {
     __syncthreads();
     wb = base;
     const int nl = min(W, L - base);
-    if (with_jump)
+    if (mode != 0)
       for (int e = lane; e < nl * Q; e += 64) {
         const int l = base + e / Q, i = e % Q;
         double v = 0.0;
-        if (l < Lm1) {
+        if (mode == 2) {
+          if (beam) v = Bv[l * Q + i] * d.att[(long)c * (L + 1) + l];
+          if (iso) v += vpoly(l, ts0[l], i);
+        } else if (l < Lm1) {
           if (beam) v = (Bv[(l + 1) * Q + i] - Bv[l * Q + i]) * d.att[(long)c * (L + 1) + l + 1];
           if (iso) v += vpoly(l + 1, ts0[l + 1], i) - vpoly(l, ts0[l + 1], i);
         }
@@ -1653,8 +1664,12 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
     for (int e = lane; e < nl * NP; e += 64) (&sEk[0][0])[e] = Ek[(long)base * NP + e];
     __syncthreads();
   };
-  if (lane < NP) sT[lane] = d.T[lane];
-  fill(0, true);
+  for (int e = lane; e < NP; e += 64) {
+    const double t = d.T[e];
+    sT[0][e] = t;
+    sT[1][e] = fast_rcp(t);
+  }
+  fill(0, 1);
 
   MatT<T> a0 = load_d(Am, kq, col), y0 = load_d(Ym, kq, col);
   const int lsecond = min(1, Lm1);
@@ -1707,7 +1722,7 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
     const int ln = min(l + 1, Lm1), l2 = min(l + 2, Lm1);
     const MatT<T> a2 = load_d(Am + (long)l2 * NN, kq, col), y2 = load_d(Ym + (long)l2 * NN, kq, col);
     const ColT<T> k2c = load_col(kk + l2 * NP, col);
-    if (ln >= wb + W) fill(l, true);
+    if (ln >= wb + W) fill(l, 1);
     const int r0 = l - wb, r1 = ln - wb;
     // ---- elimination: [Ta^T ; Tb^T ; t^T] -> H = S^T (in tb), s (in tv)
     {
@@ -1762,7 +1777,7 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
     }
     ColT<T> rt, rb;
     {
-      const RowT<T> t_row = load_row(&sT[0], kq), ru = load_row(&sPs[r0][0], kq), rd = load_row(&sPs[r0][NP], kq);
+      const RowT<T> t_row = load_row(&sT[0][0], kq), ru = load_row(&sPs[r0][0], kq), rd = load_row(&sPs[r0][NP], kq);
       RowT<T> vs, vd;  // T (r_up + r_dn), -T (r_up - r_dn) in row form
 #pragma unroll
       for (int I = 0; I < T; ++I)
@@ -1848,7 +1863,7 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
   ColT<T> cminus, cplus;
   {
     const int l = Lm1;
-    const RowT<T> eLr = load_row(&sEk[l - wb][0], kq), t_row = load_row(&sT[0], kq);
+    const RowT<T> eLr = load_row(&sEk[l - wb][0], kq), t_row = load_row(&sT[0][0], kq);
     const ColT<T> kLc = load_col(kk + l * NP, col);
     const MatT<T> eye = make_eye(kq, col);
     MatT<T> p0, q0, x1 = eye, x2 = eye, rtr;
@@ -1974,31 +1989,76 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
   //      load); the coefficients are staged in the (now free) save area of the elimination and leave as full-width
   //      stores every NSLOT layers -- a store inside the sweep would turn every wait for an operand into a wait for
   //      that store's acknowledgement.
-  constexpr int NSLOT = (NROW * LDM) / Q;
+  //      With the fused evaluation (d.um) a slot also takes u^m at the top of the layer: the two row sums ARE those of
+  //      that interface (see rtd_bc_mfma_kernel), plus the particular solution from the window; row L is the bottom of the
+  //      last layer.
+  double* um = d.um ? d.um + cm * (L + 1) * Q : nullptr;
+  constexpr int SLOTW = 2 * Q;  // [C-, C+ | u^m up, down]
+  constexpr int NSLOT = (NROW * LDM) / SLOTW;
   double* const sOut = sM;
-  int nstage = 0, ltop = Lm1;  // slot s holds [C-, C+] of layer ltop - s
+  int nstage = 0, ltop = L;  // slot s holds the rows of layer / interface ltop - s (row L: u^m only)
   auto flush = [&]() {
     __syncthreads();
 #pragma unroll 1
-    for (int s2 = 0; s2 < nstage; ++s2)
-      for (int e = lane; e < Q; e += 64) coef[(long)(ltop - s2) * Q + e] = sOut[s2 * Q + e];
+    for (int s2 = 0; s2 < nstage; ++s2) {
+      const long row = ltop - s2;
+      for (int e = lane; e < SLOTW; e += 64) {
+        const double v = sOut[s2 * SLOTW + e];
+        if (e < Q) {
+          if (row < L) coef[row * Q + e] = v;
+        } else if (um) {
+          um[row * Q + e - Q] = v;
+        }
+      }
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     ltop -= nstage;
     nstage = 0;
   };
-  auto stage = [&](const ColT<T>& cm_, const ColT<T>& cp_, const int kq, const int col) {
+  // the homogeneous part of u^m from the row sums P = Y_l (e- C- + e+ C+), Qs = A_l (e- C- - e+ C+) / k_l: lanes col < 4 T hold
+  // element i = 16 (col >> 2) + 4 (col & 3) + kq of the up- and of the down-streams
+  auto um_values = [&](const RowT<T>& P, const RowT<T>& Qs, const int kq, const int col, double& up, double& dn) {
+    const RowT<T> rT = load_row(&sT[1][0], kq);
+    up = 0.0;
+    dn = 0.0;
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool mine = (col >> 2) == I && (col & 3) == q;
+        const double u_q = (P.r[I][q] - Qs.r[I][q]) * rT.r[I][q], d_q = (P.r[I][q] + Qs.r[I][q]) * rT.r[I][q];
+        up = mine ? u_q : up;
+        dn = mine ? d_q : dn;
+      }
+  };
+  RowT<T> w1, w2;  // w1 = P, w2 = -Qs of the top of the current layer
+  auto stage = [&](const int l, const int kq, const int col) {
     if (nstage == NSLOT) flush();
+    double* o = sOut + nstage * SLOTW;
     if (kq == 0)
 #pragma unroll
       for (int J = 0; J < T; ++J) {
-        sOut[nstage * Q + 16 * J + col] = cm_.c[J];
-        sOut[nstage * Q + NP + 16 * J + col] = cp_.c[J];
+        o[16 * J + col] = cminus.c[J];
+        o[NP + 16 * J + col] = cplus.c[J];
       }
+    if (um) {
+      RowT<T> nw2;
+#pragma unroll
+      for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nw2.r[I][q] = -w2.r[I][q];
+      double up, dn;
+      um_values(w1, nw2, kq, col, up, dn);
+      if (col < 4 * T) {
+        const int i = 16 * (col >> 2) + 4 * (col & 3) + kq;
+        o[Q + i] = up + sPs[l - wb][i];
+        o[Q + NP + i] = dn + sPs[l - wb][NP + i];
+      }
+    }
     ++nstage;
   };
-  fill(max(L - W, 0), false);
-  RowT<T> w1, w2;
+  fill(max(L - W, 0), um ? 2 : 0);
   auto row_sums = [&](const MatT<T>& yl, const MatT<T>& al, const ColT<T>& kl, const ColT<T>& el) {
     ColT<T> xpy, ymx;
 #pragma unroll
@@ -2010,8 +2070,37 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
     w1 = row_dotT<T>(yl, xpy);
     w2 = row_dotT<T>(al, ymx);
   };
-  stage(cminus, cplus, kq, col);
-  row_sums(y0, a0, load_col(kk + Lm1 * NP, col), load_col(&sEk[Lm1 - wb][0], col));
+  {
+    const ColT<T> kL = load_col(kk + Lm1 * NP, col), eL = load_col(&sEk[Lm1 - wb][0], col);
+    nstage = 1;  // slot 0 = row L: u^m at tau_L, the bottom of the last layer (e- = E_L, e+ = 1); no coefficients
+    if (um) {
+      ColT<T> spe, dme;
+#pragma unroll
+      for (int J = 0; J < T; ++J) {
+        const double en = eL.c[J] * cminus.c[J], ep = cplus.c[J];
+        spe.c[J] = en + ep;
+        dme.c[J] = (en - ep) * fast_rcp(kL.c[J]);
+      }
+      double up, dn;
+      um_values(row_dotT<T>(y0, spe), row_dotT<T>(a0, dme), kq, col, up, dn);
+      if (col < 4 * T) {
+        const int i = 16 * (col >> 2) + 4 * (col & 3) + kq;
+        if (beam) {
+          const double attv = d.att[(long)c * (L + 1) + L];
+          up += Bv[Lm1 * Q + i] * attv;
+          dn += Bv[Lm1 * Q + NP + i] * attv;
+        }
+        if (iso) {
+          up += vpoly(Lm1, ts0[L], i);
+          dn += vpoly(Lm1, ts0[L], NP + i);
+        }
+        sOut[Q + i] = up;
+        sOut[Q + NP + i] = dn;
+      }
+    }
+    row_sums(y0, a0, kL, eL);
+    stage(Lm1, kq, col);
+  }
   struct BwSet {
     MatT<T> a, y, h;
     ColT<T> sl, rb, k;
@@ -2042,13 +2131,13 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
 #pragma unroll
     for (int J = 0; J < T; ++J) cminus.c[J] = s.sl.c[J] - hc.c[J];
     cplus = cp;
-    stage(cminus, cplus, kq, col);
-    if (l > 0) row_sums(s.y, s.a, s.k, load_col(&sEk[l - wb][0], col));
+    if (l > 0 || um) row_sums(s.y, s.a, s.k, load_col(&sEk[l - wb][0], col));
+    stage(l, kq, col);
   };
   // One pass of the outer loop per window of the small vectors; the requests of the sets are unconditional (past the top
   // they repeat layer 0) so that the waits stay counted.
   for (int lhi = Lm1 - 1; lhi >= 0;) {
-    if (lhi < wb) fill(max(lhi - W + 1, 0), false);
+    if (lhi < wb) fill(max(lhi - W + 1, 0), um ? 2 : 0);
     const int llo = wb;
     __builtin_amdgcn_s_waitcnt(0x0F70);
     BwSet s0 = load_set(lhi);
@@ -2074,8 +2163,11 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
 }  // namespace
 
 bool rtd_bc_fuses_eval(const RtdDev& d) {
-  static const bool split = getenv("RTD_BC_SPLIT") != nullptr, tiled = getenv("RTD_BC_TILED") != nullptr;
-  return d.NP == 16 && !split && !tiled;
+  // the fused kernels -- rtd_bc_mfma_kernel and the tiled one at 16 or 32 streams per hemisphere -- write u^m at the
+  // interfaces themselves; a window in which the tiled kernel handed a chain to the row-per-lane kernels (d.split_any)
+  // is evaluated by the evaluation kernel instead (rtd_launch_eval)
+  static const bool split = getenv("RTD_BC_SPLIT") != nullptr;
+  return (d.NP == 16 || d.NP == 32) && !split;
 }
 
 void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
@@ -2099,6 +2191,7 @@ void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
 #define RTD_BC_TILED_CASE(NPV, TV)                                                                          \
   if (part == 0) {                                                                                          \
     (void)hipMemsetAsync(d.need_split, 0, sizeof(int) * (size_t)d.C * d.M, s);                              \
+    (void)hipMemsetAsync(d.split_any, 0, sizeof(int), s);                                                   \
     hipLaunchKernelGGL(rtd_bc_tile_kernel<TV>, gc, dim3(64), 0, s, d, d.need_split);                        \
   } else {                                                                                                  \
     if (nif > 0) hipLaunchKernelGGL(rtd_iface_kernel<NPV>, gi, dim3(64), 0, s, d, (const int*)d.need_split); \

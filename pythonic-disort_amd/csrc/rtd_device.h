@@ -47,6 +47,7 @@ struct RtdDev {
   // coefficients are in its registers, the exponentials are E_l or 1 -- and the evaluation kernel only sums over the modes.
   double* um;         // [C][M][L+1][Q2]  u^m at the interfaces (null: not wanted)
   int* need_split;    // [C][M]  chains the tiled fused BC kernel hands to the pivoted row-per-lane kernels (64 streams)
+  int* split_any;     // [1]     set when any chain of the window was handed over (then the fused evaluation is incomplete)
   int* sweeps;        // [1] max Jacobi sweeps (diagnostic)
   int* status;        // [1] device-side status flags (RTD_ST_*)
 };
@@ -66,6 +67,7 @@ struct RtdEval {
   const double* phi;  // [nphi]
   double *u, *u0, *fup, *fdn, *fdir, *ulast;  // device outputs (may be null)
   const double* um_in;  // [C][M][ntau][Q2] Fourier modes already formed by the boundary-condition kernel (else null)
+  const int* run_if_set;  // not null: the evaluation kernel leaves at once unless this flag is set (see rtd_launch_eval)
 };
 
 // Nakajima-Tanaka corrections (rtd_nt.hip)

@@ -558,15 +558,16 @@ def test_alternative_kernel_paths_stay_correct(switch):
     row-per-lane sweep kernel instead of the fused MFMA-layout kernels; RTD_EIG_V1=1: Jacobi sweeps with one column per lane
     instead of the pair layout; RTD_EIG_MFMA=1: the assembly of Pm, Qm as rank-4 MFMA updates (32 streams); RTD_BC_TILED=1: the tiled fused kernel (the 64-stream kernel) with one tile, in place of the
     32-stream kernel it generalises; RTD_BC_FORCE_HANDOVER=1: the tiled kernel hands every third chain to the pivoted
-    row-per-lane kernels (its last resort for singular carry blocks) -- pass the golden replay (it has 40-, 48- and
-    64-stream cases), the synthetic configs incl. cfg5 and the random cases."""
+    row-per-lane kernels (its last resort for singular carry blocks; the window's fused interface evaluation is then
+    replaced by the evaluation kernel) -- pass the golden replay (it has 40-, 48- and 64-stream cases), the synthetic configs
+    incl. cfg5, the random cases and the fused-evaluation comparison."""
     import subprocess
     import sys
     env = dict(os.environ, **{switch: "1"})
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"),
                         os.path.join(os.path.dirname(__file__), "test_gpu_random_parity.py"),
-                        "-k", "reference_golden or synthetic_config or random_many or edge_cases"],
+                        "-k", "reference_golden or synthetic_config or random_many or edge_cases or fused_interface"],
                        env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
@@ -824,6 +825,12 @@ def test_fused_interface_evaluation_equals_the_evaluation_kernel(amd):
     deep.update(s_poly_coeffs=np.tile(np.array([[0.3, 0.02, 0.001]]), (3, 45, 1)), b_pos=0.2, b_neg=0.1,
                 bdrf_q=np.full((3, 1, 16, 16), 0.4), bdrf_q0=np.full((3, 1, 16), 0.4))
     cases["all_sources_45_layers"] = deep
+    # 64 streams: the tiled kernel's fused evaluation (27 layers: more than its 24-layer window), beam only and every source
+    cases["64_streams"] = synthetic.cfg4_columns(3, L=27, NQuad=64)
+    s64 = synthetic.cfg4_columns(2, L=5, NQuad=64)
+    s64.update(s_poly_coeffs=np.tile(np.array([[0.3, 0.02, 0.001]]), (2, 5, 1)), b_pos=0.2, b_neg=0.1,
+               bdrf_q=np.full((2, 1, 32, 32), 0.4), bdrf_q0=np.full((2, 1, 32), 0.4))
+    cases["all_sources_64_streams"] = s64
     for name, cfg in cases.items():
         C = cfg["tau_arr"].shape[0]
         if name == "26_streams":  # more azimuths than the Fourier-sum kernel takes in one pass over the modes (four)
@@ -844,7 +851,9 @@ def test_fused_interface_evaluation_equals_the_evaluation_kernel(amd):
                 scale = max(np.max(np.abs(b)), 1e-300)
                 # (the fused path takes an interface from the layer below it, the evaluation kernel -- like the reference --
                 #  from the layer above: the two agree to the residual of the boundary-condition solve's continuity rows)
-                assert np.max(np.abs(a - b)) <= 2e-12 * scale, (name, shard, k, np.max(np.abs(a - b)) / scale)
+                # (measured: <= 1e-12 at 32 streams, 3.7e-12 at 64 streams x 27 layers)
+                tol = 1e-11 if "64_streams" in name else 2e-12
+                assert np.max(np.abs(a - b)) <= tol * scale, (name, shard, k, np.max(np.abs(a - b)) / scale)
             plan.close()
 
 
