@@ -930,10 +930,16 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       __syncthreads();
     }
   };
+  // Two forms.  `fill` is the plain loop, used for the refills inside the sweeps (chains deeper than the window): it pays
+  // the memory latency once per 64 elements but costs the loops no registers.  `fill_all` issues all loads of a fill before
+  // the first is used (indices clamped, not predicated): one latency instead of ten; it holds ~70 registers and is used
+  // where few others are live -- before the forward loop and at the turn into the backward sweep, i.e. for every fill of a
+  // chain that fits the window.
   auto fill = [&](const int base, const bool backward) {
     __syncthreads();
     wb = base;
     const int nl = min(W, L - base);
+#pragma unroll 1
     for (int e = lane; e < nl * Q; e += 64) {
       const int l = base + (e >> 5), i = e & 31;
       double v = 0.0;
@@ -946,7 +952,43 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       }
       (&sPs[0][0])[e] = v;
     }
+#pragma unroll 1
     for (int e = lane; e < nl * NP; e += 64) (&sEk[0][0])[e] = Ek[(long)base * NP + e];
+    __syncthreads();
+  };
+  auto fill_all = [&](const int base, const bool backward) {
+    __syncthreads();
+    wb = base;
+    const int nl = min(W, L - base);
+    constexpr int NE = W * Q / 64, NK = (W * NP + 63) / 64;
+    static_assert(W * Q % 64 == 0, "whole passes of the wavefront");
+    const double* att = d.att + (long)c * (L + 1);
+    double b1[NE], b0[NE], at[NE], ek[NK];
+#pragma unroll
+    for (int it = 0; it < NE; ++it) {
+      const int e = min(lane + 64 * it, nl * Q - 1), l = base + (e >> 5), i = e & 31;
+      const int lt = backward ? l : min(l + 1, Lm1);  // forward: the jump B_(l+1) - B_l (zero at the last layer)
+      b1[it] = Bv[lt * Q + i];
+      b0[it] = Bv[l * Q + i];
+      at[it] = att[backward ? l : l + 1];
+    }
+#pragma unroll
+    for (int it = 0; it < NK; ++it) ek[it] = Ek[(long)base * NP + min(lane + 64 * it, nl * NP - 1)];
+#pragma unroll
+    for (int it = 0; it < NE; ++it) {
+      const int e = lane + 64 * it, l = base + (e >> 5), i = e & 31;
+      if (e < nl * Q) {
+        double v = beam ? (backward ? b1[it] : b1[it] - b0[it]) * at[it] : 0.0;
+        if (iso) {
+          if (backward) v += vpoly(l, ts0[l], i);
+          else if (l < Lm1) v += vpoly(l + 1, ts0[l + 1], i) - vpoly(l, ts0[l + 1], i);
+        }
+        (&sPs[0][0])[e] = v;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NK; ++it)
+      if (lane + 64 * it < nl * NP) (&sEk[0][0])[lane + 64 * it] = ek[it];
     __syncthreads();
   };
   if (lane < NP) {
@@ -954,7 +996,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     sT[0][lane] = t;
     sT[1][lane] = fast_rcp(t);
   }
-  fill(0, false);
+  fill_all(0, false);
 
   v4f64 a0 = load_d(Am, kq, col), y0 = load_d(Ym, kq, col);
   const int lsecond = min(1, Lm1);
@@ -1245,7 +1287,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
   //      the rotation is a renaming, not a copy that would wait for the load): the operands of layer l - 3 are requested
   //      when layer l has been consumed; a step has no load of its own and no store.
   v4f64 w1, w2;
-  fill(max(L - W, 0), true);
+  fill_all(max(L - W, 0), true);
   {
     const double kL = kk[Lm1 * NP + col], eL = sEk[Lm1 - wb][col], rk = fast_rcp(kL);
     nstage = 1;  // slot 0 = row L: u^m at tau_L, the bottom of the last layer (e- = E_L, e+ = 1); no coefficients
@@ -1648,20 +1690,41 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
     __syncthreads();
     wb = base;
     const int nl = min(W, L - base);
+    // (eight passes of the wavefront at a time, all their loads issued before the first is used -- indices clamped, not
+    //  predicated: a loop of load / wait / write would pay the memory latency once per 64 elements)
+    const double* att = d.att + (long)c * (L + 1);
     if (mode != 0)
-      for (int e = lane; e < nl * Q; e += 64) {
-        const int l = base + e / Q, i = e % Q;
-        double v = 0.0;
-        if (mode == 2) {
-          if (beam) v = Bv[l * Q + i] * d.att[(long)c * (L + 1) + l];
-          if (iso) v += vpoly(l, ts0[l], i);
-        } else if (l < Lm1) {
-          if (beam) v = (Bv[(l + 1) * Q + i] - Bv[l * Q + i]) * d.att[(long)c * (L + 1) + l + 1];
-          if (iso) v += vpoly(l + 1, ts0[l + 1], i) - vpoly(l, ts0[l + 1], i);
+      for (int e0 = 0; e0 < nl * Q; e0 += 8 * 64) {
+        double b1[8], b0[8], at[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int e = min(e0 + lane + 64 * it, nl * Q - 1), l = base + e / Q, i = e % Q;
+          const int lt = mode == 2 ? l : min(l + 1, Lm1);  // forward: the jump B_(l+1) - B_l (zero at the last layer)
+          b1[it] = Bv[lt * Q + i];
+          b0[it] = Bv[l * Q + i];
+          at[it] = att[mode == 2 ? l : l + 1];
         }
-        (&sPs[0][0])[e] = v;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int e = e0 + lane + 64 * it, l = base + e / Q, i = e % Q;
+          if (e < nl * Q) {
+            double v = beam ? (mode == 2 ? b1[it] : b1[it] - b0[it]) * at[it] : 0.0;
+            if (iso) {
+              if (mode == 2) v += vpoly(l, ts0[l], i);
+              else if (l < Lm1) v += vpoly(l + 1, ts0[l + 1], i) - vpoly(l, ts0[l + 1], i);
+            }
+            (&sPs[0][0])[e] = v;
+          }
+        }
       }
-    for (int e = lane; e < nl * NP; e += 64) (&sEk[0][0])[e] = Ek[(long)base * NP + e];
+    for (int e0 = 0; e0 < nl * NP; e0 += 8 * 64) {
+      double ek[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) ek[it] = Ek[(long)base * NP + min(e0 + lane + 64 * it, nl * NP - 1)];
+#pragma unroll
+      for (int it = 0; it < 8; ++it)
+        if (e0 + lane + 64 * it < nl * NP) (&sEk[0][0])[e0 + lane + 64 * it] = ek[it];
+    }
     __syncthreads();
   };
   for (int e = lane; e < NP; e += 64) {
