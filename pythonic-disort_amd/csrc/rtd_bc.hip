@@ -991,17 +991,25 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       if (lane + 64 * it < nl * NP) (&sEk[0][0])[lane + 64 * it] = ek[it];
     __syncthreads();
   };
-  if (lane < NP) {
-    const double t = d.T[lane];
-    sT[0][lane] = t;
-    sT[1][lane] = fast_rcp(t);
-  }
-  fill_all(0, false);
-
+  // (everything the prologue needs from memory is requested here, ahead of the window's fill: one memory latency, the
+  //  fill's, for all of it instead of three in a row)
   v4f64 a0 = load_d(Am, kq, col), y0 = load_d(Ym, kq, col);
   const int lsecond = min(1, Lm1);
   v4f64 a1 = load_d(Am + (long)lsecond * NN, kq, col), y1 = load_d(Ym + (long)lsecond * NN, kq, col);
   double k0c = kk[col], k1c = kk[lsecond * NP + col];
+  const v4f64 k_row = load_row(kk, kq);
+  double tv = d.bneg[cm * NP + col];
+  const double bv_top = beam ? Bv[NP + col] : 0.0, dq_top = iso ? dq[NP + col] : 0.0;
+  {
+    const double t = d.T[col];
+    if (lane < NP) {
+      sT[0][lane] = t;
+      sT[1][lane] = fast_rcp(t);
+    }
+  }
+  fill_all(0, false);
+  tv -= bv_top + dq_top;
+
   // carry rows (transposed): top boundary, down-streams at tau = 0 (:161-179, :284-285):
   //   Ta = Gm_0 = (Y + A/k)/T-rows,  Tb = Gp_0 E_0 = (Y - A/k)/T-rows E_0
   double ta[4], tb[4];
@@ -1009,7 +1017,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     const double rT_col = sT[1][col];
     const v4f64 eye = make_eye(kq, col);
     const v4f64 yt = mm_t(y0, eye), at = mm_t(a0, eye);
-    const v4f64 k_row = load_row(kk, kq), e_row = load_row(&sEk[0][0], kq);
+    const v4f64 e_row = load_row(&sEk[0][0], kq);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const double av = at[q] * fast_rcp(k_row[q]);
@@ -1017,9 +1025,6 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       tb[q] = (yt[q] - av) * rT_col * e_row[q];
     }
   }
-  double tv = d.bneg[cm * NP + col];
-  if (beam) tv -= Bv[NP + col];
-  if (iso) tv -= dq[NP + col];
 
   // One layer per iteration, in this order:
   //   loads     the operands of layer l + 2 (consumed by the NEXT iteration);
@@ -1137,7 +1142,27 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
   double cminus, cplus;
   {
     const int l = Lm1, rL = Lm1 - wb;
-    const double rkLc = fast_rcp(kk[l * NP + col]);
+    // (everything the block needs from memory is requested here, before the first use: one memory latency instead of
+    //  one per group of loads)
+    const bool refl = mg < d.NBDRF;
+    const double kLc = kk[l * NP + col];
+    double br = d.bpos[cm * NP + col];
+    const double att = beam ? d.att[(long)c * (L + 1) + L] : 0.0;
+    const double bvc = beam ? Bv[l * Q + col] : 0.0;
+    v4f64 qr = {0.0, 0.0, 0.0, 0.0}, mur = qr, wr = qr, bdr = qr;
+    double I0c = 0.0, q0c = 0.0;
+    if (refl) {
+      const double* qt = d.bdrfq + (((long)c * d.NBDRF + mg) * NP + col) * NP;  // row j = col of q^m
+      qr = load_row(qt, kq);
+      mur = load_row(d.mu, kq);
+      wr = load_row(d.w, kq);
+      if (beam) {
+        bdr = load_row(Bv + l * Q + NP, kq);
+        I0c = d.I0[c];
+        q0c = d.bdrfq0[((long)c * d.NBDRF + mg) * NP + col];
+      }
+    }
+    const double rkLc = fast_rcp(kLc);
     const v4f64 eLr = load_row(&sEk[rL][0], kq), rT_row = load_row(&sT[1][0], kq), eye = make_eye(kq, col);
     v4f64 p0, q0, x1 = eye, x2 = eye, rtr = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1145,14 +1170,11 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       p0[q] = y0[q] * rT_row[q];
       q0[q] = a0[q] * rT_row[q] * rkLc;
     }
-    const bool refl = mg < d.NBDRF;
     if (refl) {
       const double delta = (mg == 0) ? 2.0 : 1.0;
-      const double* qt = d.bdrfq + (((long)c * d.NBDRF + mg) * NP + col) * NP;  // row j = col of q^m
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int j2 = 4 * q + kq;
-        const double r = delta * qt[j2] * d.mu[j2] * d.w[j2];  // R^T in the D layout: [row j2][col j] = R[j][j2]
+        const double r = delta * qr[q] * mur[q] * wr[q];  // R^T in the D layout: [row j2 = 4 q + kq][col j] = R[j][j2]
         rtr[q] = r;
         x1[q] -= r;
         x2[q] += r;
@@ -1171,14 +1193,12 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     const v4f64 hb = mm_t(sd, bat);       // S^T Ba^T
 #pragma unroll
     for (int q = 0; q < 4; ++q) mt[q] -= hb[q];  // (Bb - Ba S)^T
-    double br = d.bpos[cm * NP + col];
-    const double tL = ts0[L];
-    const double att = beam ? d.att[(long)c * (L + 1) + L] : 0.0;
+    const double tL = iso ? ts0[L] : 0.0;
     if (refl) {
       if (beam) {
-        const double rbm = col_dot(rtr, load_row(Bv + l * Q + NP, kq));
-        const double Xs = mu0 * d.I0[c] / M_PI * d.bdrfq0[((long)c * d.NBDRF + mg) * NP + col];
-        br += (Xs + rbm - Bv[l * Q + col]) * att;
+        const double rbm = col_dot(rtr, bdr);
+        const double Xs = mu0 * I0c / M_PI * q0c;
+        br += (Xs + rbm - bvc) * att;
       }
       if (iso) {
         v4f64 vr;
@@ -1187,7 +1207,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
         br += col_dot(rtr, vr) - vpoly(l, tL, col);
       }
     } else {
-      if (beam) br -= Bv[l * Q + col] * att;
+      br -= bvc * att;
       if (iso) br -= vpoly(l, tL, col);
     }
     double rhs = br - col_dot(bat, col_to_row(tv, rowbase, kq));
@@ -1286,10 +1306,39 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
   //      cycles of latency against ~1 300 of arithmetic).  Three register sets rotate (the loop is unrolled by three so that
   //      the rotation is a renaming, not a copy that would wait for the load): the operands of layer l - 3 are requested
   //      when layer l has been consumed; a step has no load of its own and no store.
+  struct BwSet {
+    v4f64 a, y, h;
+    double sl, rb, k;
+  };
+  auto load_set = [&](const int l) {
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const int kq = lv >> 4, col = lv & 15;
+    BwSet s;
+    const double* w = wsb + (long)l * Ws<NP>::SLOT;
+    s.a = load_d(Am + (long)l * NN, kq, col);
+    s.y = load_d(Ym + (long)l * NN, kq, col);
+    s.h = load_d(w + Ws<NP>::S, kq, col);
+    s.sl = w[Ws<NP>::SV + col];
+    s.rb = w[Ws<NP>::RB + col];
+    s.k = kk[l * NP + col];
+    return s;
+  };
   v4f64 w1, w2;
+  // (what the turn needs from memory -- the first operand set included -- is requested ahead of the window's fill: one
+  //  memory latency for all of it)
+  const double kL = kk[Lm1 * NP + col];
+  double attL = 0.0, buL = 0.0, bdL = 0.0;
+  if (beam && um) {
+    attL = d.att[(long)c * (L + 1) + L];
+    buL = Bv[Lm1 * Q + 4 * (col & 3) + kq];
+    bdL = Bv[Lm1 * Q + NP + 4 * (col & 3) + kq];
+  }
+  BwSet s0 = {};
+  if (Lm1 > 0) s0 = load_set(Lm1 - 1);
   fill_all(max(L - W, 0), true);
   {
-    const double kL = kk[Lm1 * NP + col], eL = sEk[Lm1 - wb][col], rk = fast_rcp(kL);
+    const double eL = sEk[Lm1 - wb][col], rk = fast_rcp(kL);
     nstage = 1;  // slot 0 = row L: u^m at tau_L, the bottom of the last layer (e- = E_L, e+ = 1); no coefficients
     if (um) {
       const double en = eL * cminus, ep = cplus;
@@ -1297,11 +1346,8 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       um_values(row_dot(y0, en + ep), row_dot(a0, (en - ep) * rk), kq, col, up, dn);
       if (col < 4) {
         const int i = 4 * (col & 3) + kq;
-        if (beam) {
-          const double attv = d.att[(long)c * (L + 1) + L];
-          up += Bv[Lm1 * Q + i] * attv;
-          dn += Bv[Lm1 * Q + NP + i] * attv;
-        }
+        up = fma(buL, attL, up);
+        dn = fma(bdL, attL, dn);
         if (iso) {
           up += vpoly(Lm1, ts0[L], i);
           dn += vpoly(Lm1, ts0[L], NP + i);
@@ -1323,24 +1369,6 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     if (!(fabs(cminus) + fabs(cplus) < 1e300)) atomicOr(d.status, RTD_ST_BC);
     return;
   }
-  struct BwSet {
-    v4f64 a, y, h;
-    double sl, rb, k;
-  };
-  auto load_set = [&](const int l) {
-    int lv = lane;
-    asm volatile("" : "+v"(lv));
-    const int kq = lv >> 4, col = lv & 15;
-    BwSet s;
-    const double* w = wsb + (long)l * Ws<NP>::SLOT;
-    s.a = load_d(Am + (long)l * NN, kq, col);
-    s.y = load_d(Ym + (long)l * NN, kq, col);
-    s.h = load_d(w + Ws<NP>::S, kq, col);
-    s.sl = w[Ws<NP>::SV + col];
-    s.rb = w[Ws<NP>::RB + col];
-    s.k = kk[l * NP + col];
-    return s;
-  };
   auto step = [&](const int l, const BwSet& s) {
     int lv = lane;
     asm volatile("" : "+v"(lv));
@@ -1363,9 +1391,8 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     RTD_STAMP();  // backward step: C-, row sums, staging
   };
   __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing pending at the loop's entry (see the forward loop)
-  // (issued in the order of their use: a set requested after a younger one would be waited for with a smaller count)
-  BwSet s0 = load_set(Lm1 - 1);
-  __builtin_amdgcn_sched_barrier(0);
+  // (issued in the order of their use: a set requested after a younger one would be waited for with a smaller count; the
+  //  first set came in with the fill)
   BwSet s1 = load_set(max(Lm1 - 2, 0));
   __builtin_amdgcn_sched_barrier(0);
   BwSet s2 = load_set(max(Lm1 - 3, 0));
