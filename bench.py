@@ -212,6 +212,8 @@ def end_to_end(device, columns=100_000):
     # result arrays are the caller's (a serving loop reuses them): allocated and touched once, outside the timed call
     out = dict(u=np.zeros((columns, NQUAD, NTAU, NPHI)), u0=np.zeros((columns, NQUAD, NTAU)), flux_up=np.zeros((columns, NTAU)),
                flux_down_diffuse=np.zeros((columns, NTAU)), flux_down_direct=np.zeros((columns, NTAU)))
+    for a in out.values():
+        a.fill(0.0)  # (np.zeros maps pages lazily: touch them here, not inside the first timed call)
     calls = []
     for _ in range(3):
         t0 = time.perf_counter()
