@@ -667,9 +667,6 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
 // applies W through its factors:  Wq x + Wp y = [A_l^T Y' (x + y) + k_l Y_l^T A' ((y - x)/k')] / 2.
 // Against the two-kernel path this removes the Wp/Wq round trip through HBM (about 40 % of the stage's traffic).
 // ------------------------------------------------------------------------------------------------
-#ifndef RTD_BCF_WAVES
-#define RTD_BCF_WAVES 3
-#endif
 #ifndef RTD_BCF_WIN
 #define RTD_BCF_WIN 20  // layers of small vectors resident in LDS (12.6 KB per wavefront with the save area: 12 per CU)
 #endif
@@ -799,7 +796,15 @@ struct GjFast<NB, 16> {
   static __device__ __forceinline__ void run(double (&)[4], double (&)[4], double&, int&, const int) {}
 };
 
-__global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
+// WAVES = 4, the default, is the lean form: four wavefronts per SIMD need <= 128 registers and <= 10 KB of LDS each, so it
+// prefetches one layer ahead instead of two, forms the interface products one after the other (one accumulator set live),
+// takes exp(-k dtau) from memory instead of the LDS window, saves t^T once instead of four times and rotates two operand
+// sets in the backward sweep instead of three (128 VGPRs, 29 of them spilled outside the two loops; 9.8 KB).  The kernel is
+// bound by the latency of its dependent chains: LDS padding that leaves 7 / 9 / 12 wavefronts per CU gives 5.46 / 4.82 /
+// 4.33 ms for the three-wavefront form (WAVES = 3: 168 VGPRs, 12.7 KB), 16 per CU with this form 4.1 ms.
+template <int WAVES>
+__global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
+  constexpr bool LEAN = WAVES >= 4;
   constexpr int NP = 16, Q = 32, NN = NP * NP;
   const int lane = threadIdx.x, kq = lane >> 4, col = lane & 15, rowbase = lane & 48;
   const long cm = blockIdx.x;
@@ -862,9 +867,12 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
   //      that is consumed right away (one such load makes the wave wait for everything it has in flight: the counter is
   //      in-order).
   constexpr int W = RTD_BCF_WIN;
-  __shared__ double sSave[9][64];
+  constexpr int NSV = LEAN ? 8 * 64 + 16 : 9 * 64;  // the save area: rows of Ta^T, Tb^T (4 x 64 each) and t^T (lean: one copy)
+  constexpr int NSTG = NSV / 64;                    // result rows it can stage in the backward sweep
+  __shared__ double sSaveFlat[NSV];
+  double (*const sSave)[64] = reinterpret_cast<double (*)[64]>(sSaveFlat);
   __shared__ double sPs[W][Q];  // forward: r_l; backward: p_l(tau_l)
-  __shared__ double sEk[W][NP];
+  __shared__ double sEk[LEAN ? 1 : W][NP];  // (lean: not used, exp(-k dtau) comes from memory)
   __shared__ double sT[2][NP];  // T and 1 / T
   __shared__ double sF[NP];
   // Diagnostic build (-DRTD_BCF_STAMPS): lane 0 of three chains records s_memtime at the phase boundaries and prints the
@@ -952,8 +960,10 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       }
       (&sPs[0][0])[e] = v;
     }
+    if constexpr (!LEAN) {
 #pragma unroll 1
-    for (int e = lane; e < nl * NP; e += 64) (&sEk[0][0])[e] = Ek[(long)base * NP + e];
+      for (int e = lane; e < nl * NP; e += 64) (&sEk[0][0])[e] = Ek[(long)base * NP + e];
+    }
     __syncthreads();
   };
   auto fill_all = [&](const int base, const bool backward) {
@@ -972,8 +982,10 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       b0[it] = Bv[l * Q + i];
       at[it] = att[backward ? l : l + 1];
     }
+    if constexpr (!LEAN) {
 #pragma unroll
-    for (int it = 0; it < NK; ++it) ek[it] = Ek[(long)base * NP + min(lane + 64 * it, nl * NP - 1)];
+      for (int it = 0; it < NK; ++it) ek[it] = Ek[(long)base * NP + min(lane + 64 * it, nl * NP - 1)];
+    }
 #pragma unroll
     for (int it = 0; it < NE; ++it) {
       const int e = lane + 64 * it, l = base + (e >> 5), i = e & 31;
@@ -986,18 +998,27 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
         (&sPs[0][0])[e] = v;
       }
     }
+    if constexpr (!LEAN) {
 #pragma unroll
-    for (int it = 0; it < NK; ++it)
-      if (lane + 64 * it < nl * NP) (&sEk[0][0])[lane + 64 * it] = ek[it];
+      for (int it = 0; it < NK; ++it)
+        if (lane + 64 * it < nl * NP) (&sEk[0][0])[lane + 64 * it] = ek[it];
+    }
     __syncthreads();
   };
   // (everything the prologue needs from memory is requested here, ahead of the window's fill: one memory latency, the
   //  fill's, for all of it instead of three in a row)
   v4f64 a0 = load_d(Am, kq, col), y0 = load_d(Ym, kq, col);
   const int lsecond = min(1, Lm1);
-  v4f64 a1 = load_d(Am + (long)lsecond * NN, kq, col), y1 = load_d(Ym + (long)lsecond * NN, kq, col);
-  double k0c = kk[col], k1c = kk[lsecond * NP + col];
+  v4f64 a1 = a0, y1 = y0;  // (lean: layer l + 1 is requested at the top of iteration l)
+  double k0c = kk[col], k1c = k0c;
+  if constexpr (!LEAN) {
+    a1 = load_d(Am + (long)lsecond * NN, kq, col);
+    y1 = load_d(Ym + (long)lsecond * NN, kq, col);
+    k1c = kk[lsecond * NP + col];
+  }
   const v4f64 k_row = load_row(kk, kq);
+  v4f64 e_row_g = k_row;
+  if constexpr (LEAN) e_row_g = load_row(Ek, kq);
   double tv = d.bneg[cm * NP + col];
   const double bv_top = beam ? Bv[NP + col] : 0.0, dq_top = iso ? dq[NP + col] : 0.0;
   {
@@ -1017,7 +1038,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     const double rT_col = sT[1][col];
     const v4f64 eye = make_eye(kq, col);
     const v4f64 yt = mm_t(y0, eye), at = mm_t(a0, eye);
-    const v4f64 e_row = load_row(&sEk[0][0], kq);
+    const v4f64 e_row = LEAN ? e_row_g : load_row(&sEk[0][0], kq);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const double av = at[q] * fast_rcp(k_row[q]);
@@ -1046,8 +1067,19 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     asm volatile("" : "+v"(lv));
     const int kq = lv >> 4, col = lv & 15, rowbase = lv & 48;
     const int ln = min(l + 1, Lm1), l2 = min(l + 2, Lm1);
-    const v4f64 a2 = load_d(Am + (long)l2 * NN, kq, col), y2 = load_d(Ym + (long)l2 * NN, kq, col);
-    const double k2c = kk[l2 * NP + col];
+    v4f64 a2 = a1, y2 = y1, e1r_g = a1;
+    double k2c = k1c, e0c_g = 0.0;
+    if constexpr (LEAN) {  // one layer ahead: consumed behind this iteration's elimination
+      a1 = load_d(Am + (long)ln * NN, kq, col);
+      y1 = load_d(Ym + (long)ln * NN, kq, col);
+      k1c = kk[ln * NP + col];
+      e0c_g = Ek[l * NP + col];
+      e1r_g = load_row(Ek + ln * NP, kq);
+    } else {
+      a2 = load_d(Am + (long)l2 * NN, kq, col);
+      y2 = load_d(Ym + (long)l2 * NN, kq, col);
+      k2c = kk[l2 * NP + col];
+    }
     if (ln >= wb + W) fill(l, false);
     RTD_STAMP();  // 4 l + 1: loop top (register rotation, loads issued)
     const int r0 = l - wb, r1 = ln - wb;
@@ -1058,7 +1090,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
         sSave[q][lane] = ta[q];
         sSave[4 + q][lane] = tb[q];
       }
-      sSave[8][lane] = tv;
+      if (!LEAN || kq == 0) sSave[8][LEAN ? col : lane] = tv;
       int bad = 0;
       GjFast<4, 0>::run(ta, tb, tv, bad, col);
       bad |= (fabs(tv) + fabs(tb[0]) + fabs(tb[1]) + fabs(tb[2]) + fabs(tb[3]) < 1e300) ? 0 : 1;  // zero pivot: inf / nan
@@ -1079,6 +1111,58 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
 #pragma unroll
     for (int q = 0; q < 4; ++q) ws[Ws<NP>::S + (4 * q + kq) * NP + col] = tb[q];
     if (kq == 0) ws[Ws<NP>::SV + col] = tv;
+    if constexpr (LEAN) {
+      // the same quantities with one accumulator set live at a time (Y_l is scaled in place: it is not used again)
+      v4f64 a1s;
+      {
+        const double rk1c = fast_rcp(k1c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          y0[q] *= k0c;
+          a1s[q] = a1[q] * rk1c;
+        }
+      }
+      double rt = 0.0, rb = 0.0;
+      {
+        const v4f64 t_row = load_row(&sT[0][0], kq);
+        const v4f64 ru = load_row(&sPs[r0][0], kq), rd = load_row(&sPs[r0][NP], kq);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const double pa = t_row[s] * a0[s] * (ru[s] + rd[s]), pb = -t_row[s] * y0[s] * (ru[s] - rd[s]);
+          rt += pa + pb;
+          rb += pa - pb;
+        }
+        rt = 0.25 * sum_kq(rt);
+        rb = 0.25 * sum_kq(rb);
+      }
+      if (kq == 0) ws[Ws<NP>::RB + col] = rb;
+      const double e0c = e0c_g;
+      v4f64 he;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) he[q] = tb[q] * e0c;
+      const v4f64 hcur = {tb[0], tb[1], tb[2], tb[3]};
+      const double tnew = rt - e0c * (tv - col_dot(hcur, col_to_row(rb, rowbase, kq)));  // t' = rho_t - E (s - S rho_b)
+      v4f64 s1;  // X + M1^T
+      {
+        const v4f64 m1 = mm_t(a0, y1);
+        const v4f64 xx = mm_t(m1, he);
+        const v4f64 m1t = mm_t(y1, a0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s1[q] = xx[q] + m1t[q];
+      }
+      {
+        const v4f64 m2s = mm_t(y0, a1s);
+        const v4f64 zz = mm_t(m2s, he);
+        const v4f64 m2st = mm_t(a1s, y0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double dd = zz[q] - m2st[q];
+          ta[q] = -0.5 * (s1[q] - dd);
+          tb[q] = -0.5 * (s1[q] + dd) * e1r_g[q];
+        }
+      }
+      tv = tnew;
+    } else {
     // ---- interface products; the diagonal scalings are column scalings of the operands (at l = L - 1 they are not used)
     v4f64 y0s, a1s;
     {
@@ -1124,16 +1208,19 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
       tb[q] = -0.5 * (xx[q] + zz[q] + m1t[q] - m2st[q]) * e1r[q];
     }
     tv = tnew;
+    }
 #ifdef RTD_BCF_STAMPS
     asm volatile("" ::"v"(ta[0]), "v"(ta[3]), "v"(tb[0]), "v"(tb[3]), "v"(tv));
 #endif
     RTD_STAMP();  // 4 l + 4: carry
     a0 = a1;
     y0 = y1;
-    a1 = a2;
-    y1 = y2;
     k0c = k1c;
-    k1c = k2c;
+    if constexpr (!LEAN) {
+      a1 = a2;
+      y1 = y2;
+      k1c = k2c;
+    }
   }
 
   // ---- bottom boundary (up-streams at tau_L) (:208-232, :248-254, :288-293):  Ba C- + Bb C+ = br,
@@ -1162,8 +1249,11 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
         q0c = d.bdrfq0[((long)c * d.NBDRF + mg) * NP + col];
       }
     }
+    v4f64 eLr_g = qr;
+    if constexpr (LEAN) eLr_g = load_row(Ek + l * NP, kq);
     const double rkLc = fast_rcp(kLc);
-    const v4f64 eLr = load_row(&sEk[rL][0], kq), rT_row = load_row(&sT[1][0], kq), eye = make_eye(kq, col);
+    const v4f64 eLr = LEAN ? eLr_g : load_row(&sEk[LEAN ? 0 : rL][0], kq);
+    const v4f64 rT_row = load_row(&sT[1][0], kq), eye = make_eye(kq, col);
     v4f64 p0, q0, x1 = eye, x2 = eye, rtr = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1215,7 +1305,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     {
 #pragma unroll
       for (int q = 0; q < 4; ++q) sSave[q][lane] = mt[q];
-      sSave[8][lane] = rhs;
+      if (!LEAN || kq == 0) sSave[8][LEAN ? col : lane] = rhs;
       int bad = 0;
       GjFast<0, 0>::run(mt, none, rhs, bad, col);
       bad |= (fabs(rhs) < 1e300) ? 0 : 1;
@@ -1277,7 +1367,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
   };
   // C-_l, C+_l and (with the fused evaluation) u^m at the top of layer l into the next slot
   auto stage = [&](const int l, const double cmn, const double cp, const v4f64& P, const v4f64& Qs, const int kq, const int col) {
-    if (nstage == 9) flush();
+    if (nstage == NSTG) flush();
     double* o = sOut + nstage * 64;
     if (kq == 0) {
       o[col] = cmn;
@@ -1308,7 +1398,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
   //      when layer l has been consumed; a step has no load of its own and no store.
   struct BwSet {
     v4f64 a, y, h;
-    double sl, rb, k;
+    double sl, rb, k, e;  // (e: exp(-k dtau) of the layer, lean form only)
   };
   auto load_set = [&](const int l) {
     int lv = lane;
@@ -1322,12 +1412,16 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     s.sl = w[Ws<NP>::SV + col];
     s.rb = w[Ws<NP>::RB + col];
     s.k = kk[l * NP + col];
+    s.e = 0.0;
+    if constexpr (LEAN) s.e = Ek[l * NP + col];
     return s;
   };
   v4f64 w1, w2;
   // (what the turn needs from memory -- the first operand set included -- is requested ahead of the window's fill: one
   //  memory latency for all of it)
   const double kL = kk[Lm1 * NP + col];
+  double eL_g = 0.0;
+  if constexpr (LEAN) eL_g = Ek[Lm1 * NP + col];
   double attL = 0.0, buL = 0.0, bdL = 0.0;
   if (beam && um) {
     attL = d.att[(long)c * (L + 1) + L];
@@ -1338,7 +1432,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
   if (Lm1 > 0) s0 = load_set(Lm1 - 1);
   fill_all(max(L - W, 0), true);
   {
-    const double eL = sEk[Lm1 - wb][col], rk = fast_rcp(kL);
+    const double eL = LEAN ? eL_g : sEk[LEAN ? 0 : Lm1 - wb][col], rk = fast_rcp(kL);
     nstage = 1;  // slot 0 = row L: u^m at tau_L, the bottom of the last layer (e- = E_L, e+ = 1); no coefficients
     if (um) {
       const double en = eL * cminus, ep = cplus;
@@ -1381,7 +1475,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     cplus = cp;
     v4f64 nw2 = {0.0, 0.0, 0.0, 0.0};
     if (l > 0 || um) {
-      const double x = cmn, y = sEk[l - wb][col] * cp;
+      const double x = cmn, y = (LEAN ? s.e : sEk[LEAN ? 0 : l - wb][col]) * cp;
       w1 = row_dot(s.y, x + y);
       w2 = row_dot(s.a, (y - x) * fast_rcp(s.k));
 #pragma unroll
@@ -1393,6 +1487,7 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
   __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing pending at the loop's entry (see the forward loop)
   // (issued in the order of their use: a set requested after a younger one would be waited for with a smaller count; the
   //  first set came in with the fill)
+  if constexpr (!LEAN) {
   BwSet s1 = load_set(max(Lm1 - 2, 0));
   __builtin_amdgcn_sched_barrier(0);
   BwSet s2 = load_set(max(Lm1 - 3, 0));
@@ -1408,6 +1503,17 @@ __global__ __launch_bounds__(64, RTD_BCF_WAVES) void rtd_bc_mfma_kernel(RtdDev d
     if (l < 2) break;
     step(l - 2, s2);
     s2 = load_set(max(l - 5, 0));
+  }
+  } else {  // two sets, unrolled by two
+    BwSet s1 = load_set(max(Lm1 - 2, 0));
+    __builtin_amdgcn_sched_barrier(0);
+    for (int l = Lm1 - 1; l >= 0; l -= 2) {
+      step(l, s0);
+      s0 = load_set(max(l - 2, 0));
+      if (l < 1) break;
+      step(l - 1, s1);
+      s1 = load_set(max(l - 3, 0));
+    }
   }
   flush();
   RTD_STAMP();
@@ -2297,7 +2403,13 @@ void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
         break;
       }
       if (!split) {
-        if (part == 1) hipLaunchKernelGGL(rtd_bc_mfma_kernel, gc, dim3(64), 0, s, d);
+        // default: the lean form, four wavefronts per SIMD (4.08-4.11 ms per 2 048 cfg4 columns against 4.19-4.25 ms of the
+        // three-wavefront form on the same boxes); RTD_BCF_WAVES3=1: the latter (A/B runs and a regression test)
+        static const bool waves3 = getenv("RTD_BCF_WAVES3") != nullptr;
+        if (part == 1) {
+          if (waves3) hipLaunchKernelGGL(rtd_bc_mfma_kernel<3>, gc, dim3(64), 0, s, d);
+          else hipLaunchKernelGGL(rtd_bc_mfma_kernel<4>, gc, dim3(64), 0, s, d);
+        }
         break;
       }
       if (part == 0 && nif > 0)

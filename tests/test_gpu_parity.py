@@ -552,12 +552,15 @@ def test_fused_bc_kernel_pivoted_path_on_goldens():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["RTD_BC_SPLIT", "RTD_EIG_V1", "RTD_EIG_MFMA", "RTD_BC_TILED", "RTD_BC_FORCE_HANDOVER"])
+@pytest.mark.parametrize("switch", ["RTD_BC_SPLIT", "RTD_EIG_V1", "RTD_EIG_MFMA", "RTD_BC_TILED", "RTD_BC_FORCE_HANDOVER",
+                                    "RTD_BCF_WAVES3"])
 def test_alternative_kernel_paths_stay_correct(switch):
     """The runtime switches that select an alternative kernel path -- RTD_BC_SPLIT=1: interface operators through HBM +
     row-per-lane sweep kernel instead of the fused MFMA-layout kernels; RTD_EIG_V1=1: Jacobi sweeps with one column per lane
     instead of the pair layout; RTD_EIG_MFMA=1: the assembly of Pm, Qm as rank-4 MFMA updates (32 streams); RTD_BC_TILED=1: the tiled fused kernel (the 64-stream kernel) with one tile, in place of the
-    32-stream kernel it generalises; RTD_BC_FORCE_HANDOVER=1: the tiled kernel hands every third chain to the pivoted
+    32-stream kernel it generalises; RTD_BCF_WAVES3=1: the three-wavefronts-per-SIMD form of the 32-stream fused kernel (two layers of prefetch, the
+    interface products side by side, three operand sets in the backward sweep) in place of the lean four-wavefront form;
+    RTD_BC_FORCE_HANDOVER=1: the tiled kernel hands every third chain to the pivoted
     row-per-lane kernels (its last resort for singular carry blocks; the window's fused interface evaluation is then
     replaced by the evaluation kernel) -- pass the golden replay (it has 40-, 48- and 64-stream cases), the synthetic configs
     incl. cfg5, the random cases and the fused-evaluation comparison."""
