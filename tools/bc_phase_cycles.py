@@ -29,7 +29,10 @@ plan.run(); plan.synchronize()
 
 if __name__ == "__main__":
     C = sys.argv[1] if len(sys.argv) > 1 else "2048"
-    out = subprocess.run([sys.executable, "-c", CHILD, C], capture_output=True, text=True).stdout
+    # (the phase stamps sit in the three-wavefront instance of the kernel: the lean default forms its products in one block
+    #  with the carry and has no boundary between them)
+    out = subprocess.run([sys.executable, "-c", CHILD, C], capture_output=True, text=True,
+                         env=dict(os.environ, RTD_BCF_WAVES3="1")).stdout
     d = collections.defaultdict(dict)
     for ln in out.splitlines():
         if ln.startswith("ST "):
