@@ -228,15 +228,23 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_fourier_kernel(RtdDev d, Rtd
           ck[q] = cos(d.m0 * dl);
           acc[q] = 0.0;
         }
-        for (int m = 0; m < M; ++m) {
-          const double v = um[(long)m * mstride];
+        // (sixteen modes per pass: their loads are independent of the recurrence and go out together -- one load per trip
+        //  made the kernel a chain of M memory latencies)
+        for (int m0 = 0; m0 < M; m0 += 16) {
+          double v[16];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            acc[q] += v * ck[q];
-            const double cn = 2.0 * cs[q] * ck[q] - ckm1[q];
-            ckm1[q] = ck[q];
-            ck[q] = cn;
-          }
+          for (int k = 0; k < 16; ++k) v[k] = um[(long)min(m0 + k, M - 1) * mstride];
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            if (m0 + k < M) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                acc[q] += v[k] * ck[q];
+                const double cn = 2.0 * cs[q] * ck[q] - ckm1[q];
+                ckm1[q] = ck[q];
+                ck[q] = cn;
+              }
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
