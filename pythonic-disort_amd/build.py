@@ -33,17 +33,36 @@ def _compile(src):
     obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
     path = os.path.join(CSRC, src)
     if _stale(obj, [path] + HEADERS):
-        subprocess.run([HIPCC] + FLAGS + ["-c", path, "-o", obj], check=True, cwd=OBJ_DIR)
-        # the kernels update registers with v_fmac_f64_dpp from inline asm: the compiler's hazard recogniser cannot see
-        # those writes, so the generated ISA is scanned for a DPP read that follows one too closely
-        dev_asm = [os.path.join(OBJ_DIR, f) for f in os.listdir(OBJ_DIR)
-                   if f.startswith(src.replace(".hip", "-hip-amdgcn")) and f.endswith(".s")]
-        if dev_asm:
-            subprocess.run([sys.executable, HAZARD_CHECK] + dev_asm, check=True, stdout=subprocess.DEVNULL)
+        # compile to a temporary name: the object only takes its final name once the hazard check has passed, so a
+        # failed check can never leave an object behind that the next run would take for up to date
+        tmp = obj + ".unchecked"
         stem = src.replace(".hip", "")
-        for f in os.listdir(OBJ_DIR):  # -save-temps leaves ~10 MB of intermediates per source
-            if f.startswith(stem + "-h") or f.startswith(stem + ".hip-"):
-                os.remove(os.path.join(OBJ_DIR, f))
+
+        def cleanup():
+            for f in os.listdir(OBJ_DIR):  # -save-temps leaves ~10 MB of intermediates per source
+                if f.startswith(stem + "-h") or f.startswith(stem + ".hip-") or f.startswith(stem + ".o.unchecked-"):
+                    os.remove(os.path.join(OBJ_DIR, f))
+
+        try:
+            subprocess.run([HIPCC] + FLAGS + ["-c", path, "-o", tmp], check=True, cwd=OBJ_DIR)
+            # the kernels update registers with v_fmac_f64_dpp from inline asm: the compiler's hazard recogniser cannot
+            # see those writes, so the generated ISA is scanned for a DPP read that follows one too closely
+            dev_asm = [os.path.join(OBJ_DIR, f) for f in os.listdir(OBJ_DIR)
+                       if "amdgcn" in f and f.endswith(".s") and (f.startswith(stem + "-hip-") or f.startswith(stem + ".o.unchecked-hip-"))]
+            if not dev_asm:
+                raise RuntimeError(f"{src}: no device assembly (*-hip-amdgcn*.s) found among the -save-temps outputs in "
+                                   f"{OBJ_DIR}: the DPP hazard check cannot run (did the toolchain rename them?)")
+            chk = subprocess.run([sys.executable, HAZARD_CHECK] + dev_asm, capture_output=True, text=True)
+            if chk.returncode != 0:
+                sys.stderr.write(chk.stdout + chk.stderr)
+                raise RuntimeError(f"{src}: DPP read-after-write hazard in the generated ISA (see above)")
+            os.replace(tmp, obj)
+        except BaseException:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise
+        finally:
+            cleanup()
     return obj
 
 

@@ -257,6 +257,9 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
   bool nt_tables_done = false;
   if (with_solve) {
     hipError_t e = hipMemsetAsync(p->d.sweeps, 0, sizeof(int), s);
+    // the device status word too: bits raised by an earlier solve whose results were never fetched must not be
+    // reported against this one (this solve's own evaluation, queued behind the memset, raises the tau bit again)
+    if (e == hipSuccess) e = hipMemsetAsync(p->d.status, 0, sizeof(int), s);
     if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
     p->numeric_status = 0;  // a new solve starts clean
   }
@@ -655,8 +658,11 @@ int rtd_plan_set_columns_raw(rtd_plan* p, const double* tau_arr, const double* o
   // one temporary device block for the raw arrays
   const int64_t n_cl = C * L, n_leg = C * L * nleg_all, n_b = C * M * N, n_sp = C * L * Ns;
   const int64_t total = 3 * n_cl + n_leg + 3 * C + (b_pos ? n_b : 0) + (b_neg ? n_b : 0) + n_sp;
-  double* raw = nullptr;
-  HIP_TRY(hipMalloc(&raw, (size_t)total * 8));
+  // staging block from the process-wide pool (a raw hipMalloc / hipFree pair synchronises the whole device per call)
+  void* raw_v = nullptr;
+  size_t raw_got = 0;
+  HIP_TRY(pooled_malloc(&raw_v, (size_t)total * 8, p->device, &raw_got));
+  double* raw = (double*)raw_v;
   RtdRaw r{};
   r.nleg_all = nleg_all;
   double* q = raw;
@@ -688,7 +694,8 @@ int rtd_plan_set_columns_raw(rtd_plan* p, const double* tau_arr, const double* o
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(raw);
+  else (void)hipStreamSynchronize(s);  // nothing may still read the block when it goes back to the pool
+  pooled_free(raw, raw_got, p->device);
   if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("set_columns_raw: ") + hipGetErrorString(e));
   p->h_tau.assign(tau_arr, tau_arr + C * L);
   p->ev_iface = false;
@@ -1225,6 +1232,7 @@ int rtd_plan_solve_layers(rtd_plan* p, int32_t first, int32_t count) {
   d.ln = count;
   d.um = nullptr;
   HIP_TRY(hipMemsetAsync(d.sweeps, 0, sizeof(int), p->stream));
+  HIP_TRY(hipMemsetAsync(d.status, 0, sizeof(int), p->stream));  // as launch_windows: a new solve starts clean
   p->numeric_status = 0;
   rtd_launch_tables(d, p->stream, true);
   rtd_launch_eig(d, p->stream, 1);

@@ -1685,7 +1685,8 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
   const bool iso = d.Ns > 0 && mg == 0;
   const bool beam = d.beam != 0;
   const double mu0 = beam ? d.mu0[c] : 1.0;
-  if ((d.flags & 2) && cm % 3 == 0) {  // test hook (RTD_BC_FORCE_HANDOVER): every third chain goes to the pivoted kernels
+  if ((d.flags & 2) && m % 3 == 0) {  // test hook (RTD_BC_FORCE_HANDOVER): every third Fourier mode's chain goes to the pivoted
+    //                                    kernels (by mode, not by chain index: the choice must not depend on the windowing)
     if (lane == 0) {
       need_split[cm] = 1;
       *d.split_any = 1;

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
     typedef double v4d __attribute__((ext_vector_type(4)));
     typedef unsigned int u2 __attribute__((ext_vector_type(2)));
     const int tx = threadIdx.x, i16 = tx & 15, k4 = tx >> 4;
-    const int chunk = (int)((long)blockIdx.x % ((d.L + GPW - 1) / GPW));
+    const int chunk = (int)((long)blockIdx.x % ((d.ln + GPW - 1) / GPW));  // as locate(): layer shards decompose [l0, l0 + ln)
     // "shortcut" (:119): per problem, multiple scattering is switched off when max_l |omega w_l / 2| <= 1e-8
     double cm_ = 0.0;
     for (int ell = id.mg + j; ell < P; ell += NP) cm_ = fmax(cm_, fabs(0.5 * om * wl[ell]));
@@ -496,7 +496,8 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
 #pragma unroll
     for (int g = 0; g < GPW; ++g) {  // wave-uniform: the layers of the four problems (scalar loads)
       const int slot = chunk * GPW + g;
-      const int lg = d.lperm[(long)c * d.L + (slot < d.L ? slot : d.L - 1)];
+      const int sl = slot < d.ln ? slot : d.ln - 1;
+      const int lg = d.ln == d.L ? d.lperm[(long)c * d.L + sl] : d.l0 + sl;
       wlg[g] = d.wleg + ((long)c * d.L + lg) * P;
       omg[g] = ((livemask >> (NP * g)) & 0xffffull) ? -d.omega[(long)c * d.L + lg] : 0.0;
     }

@@ -26,10 +26,12 @@ __global__ void rtd_prepare_columns_kernel(RtdDev d, RtdRaw r) {
   // delta-M scaling (:316-329; with f = 0 it is the identity, :331-338)
   double top = 0.0, acc = 0.0;
   ts0[0] = 0.0;
+  bool scaled = false;  // "if np.any(f_arr > 0)" (:316); otherwise the scaled optical depth IS tau_arr (:331-338), to the bit
+  for (int l = 0; l < L; ++l) scaled |= f[l] > 0.0;
   for (int l = 0; l < L; ++l) {
     const double fl = f[l], sc = 1.0 - om[l] * fl;
     const double shift = acc - sc * top;  // tau* = sc tau + shift inside layer l
-    acc += sc * (tau[l] - top);
+    acc = scaled ? acc + sc * (tau[l] - top) : tau[l];
     ts0[l + 1] = acc;
     scale[l] = sc;
     omega_s[l] = (1.0 - fl) / sc * om[l];

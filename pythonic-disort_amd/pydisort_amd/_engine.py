@@ -63,15 +63,37 @@ class Plan:
     def set_columns_raw(self, raw):
         """Upload a batch as the user gave it; delta-M scaling and source rescaling run on the device
         (include/rtd.h: rtd_plan_set_columns_raw).  raw: dict(tau_arr, omega_arr, f_arr [C, L], leg [C, L, nleg_all],
-        mu0, I0, phi0 [C], b_pos / b_neg [C, M, N] or None, s_poly [C, L, Ns] or None, bdrf_q, bdrf_q0 or None)."""
-        keys = ("tau_arr", "omega_arr", "leg")
-        a = {k: _f64(raw.get(k)) for k in ("tau_arr", "omega_arr", "leg", "f_arr", "mu0", "I0", "phi0", "b_pos", "b_neg",
-                                           "s_poly", "bdrf_q", "bdrf_q0")}
-        if a["leg"].shape[:2] != (self.C, self.L) or a["tau_arr"].shape != (self.C, self.L):
-            raise ValueError("raw batch does not match the plan's column / layer counts")
+        mu0, I0, phi0 [C], b_pos / b_neg [C, M, N] or None, s_poly [C, L, Ns] or None, bdrf_q [C, NBDRF, N, N],
+        bdrf_q0 [C, NBDRF, N] or None).  The C ABI takes bare pointers whose extents the plan implies, so every
+        array's shape is checked here."""
+        names = ("tau_arr", "omega_arr", "leg", "f_arr", "mu0", "I0", "phi0", "b_pos", "b_neg", "s_poly", "bdrf_q", "bdrf_q0")
+        a = {k: _f64(raw.get(k)) for k in names}
+        p = self.prep
+        Cn, L, N, M, Ns, NB = p["C"], p["L"], p["N"], p["M"], p["Ns"], p["NBDRF"]
+        want = {"tau_arr": (Cn, L), "omega_arr": (Cn, L), "f_arr": (Cn, L), "mu0": (Cn,), "I0": (Cn,), "phi0": (Cn,),
+                "b_pos": (Cn, M, N), "b_neg": (Cn, M, N), "s_poly": (Cn, L, Ns), "bdrf_q": (Cn, NB, N, N),
+                "bdrf_q0": (Cn, NB, N)}
+        required = {"tau_arr", "omega_arr", "f_arr", "mu0", "I0", "phi0"} | ({"s_poly"} if Ns > 0 else set()) \
+            | ({"bdrf_q", "bdrf_q0"} if NB > 0 else set())
+        if a["leg"] is None or a["leg"].ndim != 3 or a["leg"].shape[:2] != (Cn, L) or a["leg"].shape[2] < p["P"]:
+            raise ValueError(f"raw batch does not match the plan: leg must be [C = {Cn}, L = {L}, nleg_all >= {p['P']}]")
+        for k, shape in want.items():
+            if a[k] is None:
+                if k in required:
+                    raise ValueError(f"raw batch does not match the plan: {k} is required")
+                continue
+            if (k == "s_poly" and Ns == 0) or (k.startswith("bdrf") and NB == 0):
+                a[k] = None  # the plan has no such term; the library ignores the pointer
+                continue
+            if a[k].shape != shape:
+                raise ValueError(f"raw batch does not match the plan: {k} has the shape {a[k].shape}, expected {shape}")
+        if not p["beam"] and np.any(a["I0"] > 0):
+            raise ValueError("raw batch has a beam source but the plan was created without one")
         _lib.check(self._lib.rtd_plan_set_columns_raw(
             self._h, _lib.dptr(a["tau_arr"]), _lib.dptr(a["omega_arr"]), _lib.dptr(a["leg"]), a["leg"].shape[2],
             *[_lib.dptr(a[k]) for k in ("f_arr", "mu0", "I0", "phi0", "b_pos", "b_neg", "s_poly", "bdrf_q", "bdrf_q0")]))
+        # what later checks (set_columns, the closures' tau range, beam terms) compare against follows the new batch
+        self.prep = dict(p, tau=a["tau_arr"], mu0=a["mu0"], phi0=a["phi0"], raw=raw)
         self.solved = False
 
     def close(self):

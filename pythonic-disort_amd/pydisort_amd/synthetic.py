@@ -3,8 +3,8 @@ and for the parity tests.  Deterministic: column c of a config is always the sam
 import numpy as np
 
 
-def cfg4_columns(C, first=0, L=20, NQuad=32, seed=4):
-    """Henyey-Greenstein atmospheres: dtau ~ U(0.05,0.5), omega ~ U(0.5,0.99), g ~ U(0.6,0.85),
+def cfg4_columns(C, first=0, L=20, NQuad=32, seed=4, g_hi=0.85):
+    """Henyey-Greenstein atmospheres: dtau ~ U(0.05,0.5), omega ~ U(0.5,0.99), g ~ U(0.6,g_hi) (0.85: SURVEY 8(d) cfg4),
     Leg[l,k] = g_l^k (NQuad+1 moments), f = g^NQuad (delta-M on), mu0 ~ U(0.2,1), I0 = pi, phi0 = 0,
     black surface, no thermal source.  Column index c uses its own generator default_rng([seed, c])."""
     tau = np.empty((C, L))
@@ -15,7 +15,7 @@ def cfg4_columns(C, first=0, L=20, NQuad=32, seed=4):
         rng = np.random.default_rng([seed, first + i])
         tau[i] = np.cumsum(rng.uniform(0.05, 0.5, L))
         omega[i] = rng.uniform(0.5, 0.99, L)
-        g[i] = rng.uniform(0.6, 0.85, L)
+        g[i] = rng.uniform(0.6, g_hi, L)
         mu0[i] = rng.uniform(0.2, 1.0)
     k = np.arange(NQuad + 1)
     Leg = g[:, :, None] ** k[None, None, :]
@@ -57,8 +57,9 @@ def cfg3_columns(C, first=0, big=True, seed=9):
 
 
 def cfg5_columns(C, first=0, L=50, NQuad=64, seed=5):
-    """Stress config: 64 streams, 50 layers, 64 Fourier modes, 2-mode BDRF surface, linear thermal source."""
-    base = cfg4_columns(C, first, L, NQuad, seed)
+    """Stress config: 64 streams, 50 layers, 64 Fourier modes, the per-layer distributions of cfg4 with
+    g ~ U(0.6, 0.9), f = g^64, 2-mode BDRF surface, linear thermal source."""
+    base = cfg4_columns(C, first, L, NQuad, seed, g_hi=0.9)
     N = NQuad // 2
     x, _ = np.polynomial.legendre.leggauss(N)
     mu = 0.5 * (x + 1)

@@ -25,9 +25,15 @@ def pytest_sessionstart(session):
 PARITY = {}
 
 
-def record_parity(name, scale_err, pointwise_err, tol_scale=None, tol_pointwise=None):
+def record_parity(name, scale_err, pointwise_err, tol_scale=None, tol_pointwise=None, against="oracle", **extra):
+    """Records both metrics of a parity case AND asserts them against the tolerances given (None = this metric is not
+    held for this case and the report says null): the report cannot print a tolerance that was not enforced."""
     PARITY[name] = dict(scale_rel=float(scale_err), pointwise_rel=float(pointwise_err), tol_scale_rel=tol_scale,
-                        tol_pointwise_rel=tol_pointwise)
+                        tol_pointwise_rel=tol_pointwise, against=against, **{k: float(v) for k, v in extra.items()})
+    if tol_scale is not None:
+        assert scale_err < tol_scale, (name, "scale-relative", scale_err, tol_scale)
+    if tol_pointwise is not None:
+        assert pointwise_err < tol_pointwise, (name, "pointwise", pointwise_err, tol_pointwise)
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -39,6 +45,10 @@ def pytest_sessionfinish(session, exitstatus):
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, "parity_report.json"), "w") as f:
             json.dump(dict(metric="scale_rel = max|d| / max|ref| over a call; pointwise_rel = max |d| / |ref| over points "
-                                  "with |ref| > 1e-8 max|ref| (SURVEY 8(d))", cases=PARITY), f, indent=1, sort_keys=True)
+                                  "with |ref| > 1e-8 max|ref| (SURVEY 8(d)); every tolerance printed was asserted "
+                                  "(tests/conftest.py: record_parity), null = not held; against = what 'ref' is: the "
+                                  "reference's goldens, the CPU oracle pinned to them, or a 40-digit solution "
+                                  "(tools/hp_truth_case.py) where the reference's float64 algorithm is the one that is off",
+                           cases=PARITY), f, indent=1, sort_keys=True)
     except OSError:
         pass

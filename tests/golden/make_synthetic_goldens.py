@@ -99,12 +99,15 @@ def run_cloud(name, kw, tau_pts):
 
 if __name__ == "__main__":
     os.makedirs(os.path.join(HERE, "synth"), exist_ok=True)
+    if "--cfg5-only" in sys.argv:  # after a change of synthetic.cfg5_columns
+        run("cfg5", synthetic.cfg5_columns(8), 8)
+        sys.exit(0)
     for name, (kw, tau_pts) in synthetic.literal_cases().items():
         run_single(name, kw, tau_pts)
     for name, (kw, tau_pts) in cloud_c1_cases().items():
         run_cloud(name, kw, tau_pts)
-    # column counts of SURVEY section 8(d): cfg4 64, cfg5 4
+    # column counts: cfg4 64, cfg5 8 (twice the survey's 4)
     run("cfg4", synthetic.cfg4_columns(64), 64)
     run("cfg3_big", synthetic.cfg3_columns(4, big=True), 4)
     run("cfg3_small", synthetic.cfg3_columns(4, big=False), 4)
-    run("cfg5", synthetic.cfg5_columns(4), 4)
+    run("cfg5", synthetic.cfg5_columns(8), 8)

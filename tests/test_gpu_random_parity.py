@@ -7,7 +7,62 @@ import warnings
 import numpy as np
 import pytest
 
+import os
+
 pytestmark = pytest.mark.gpu
+HP_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hp")
+
+# Seeds whose random input the oracle refuses (raises) or solves to a non-finite / wildly ill-conditioned field: none at
+# present.  A seed listed here is skipped by name; any OTHER seed that the oracle cannot solve fails the test -- coverage
+# cannot shrink silently.
+ORACLE_REJECTS = {"random": set(), "random32": set(), "random64": set()}
+
+
+def eval_points(family, seed, kw):
+    """The optical depths and azimuths a random case is compared at (tools/hp_truth_case.py builds its 40-digit
+    fixtures at the same points)."""
+    tau_arr = np.atleast_1d(kw["tau_arr"])
+    rng = np.random.default_rng(seed)
+    extra = 3 if family == "random64" else 5
+    tau = np.sort(np.concatenate(([0.0, tau_arr[-1]], tau_arr[:-1], rng.uniform(0, tau_arr[-1], extra))))
+    phi = np.array([0.0, 0.7, 3.0]) if family == "random64" else np.array([0.0, 0.7, 3.0, 5.5])
+    return tau, phi
+
+
+def oracle_solution(family, seed, kw, tau):
+    """The oracle's callables for a random case; a seed the oracle cannot solve must be listed in ORACLE_REJECTS."""
+    from oracle import disort_oracle as O
+    listed = seed in ORACLE_REJECTS[family]
+    try:
+        ref = O.pydisort(**kw)
+        scale = float(np.max(np.abs(ref[3](tau))))
+        ok = np.isfinite(scale) and np.max(np.abs(ref[1](tau))) <= 1e8 * max(scale, 1e-300)
+    except Exception:
+        ref, ok = None, False
+    if listed:
+        assert not ok, f"{family}/{seed} is listed in ORACLE_REJECTS but the oracle solves it"
+        pytest.skip("listed in ORACLE_REJECTS: the oracle cannot solve this input")
+    assert ok, f"the oracle cannot solve {family}/{seed}: list the seed in ORACLE_REJECTS (with the reason) or change the generator"
+    return ref
+
+
+def arbitrated(family, seed, got_u, oracle_u, tol_scale=1e-9, tol_pw=1e-6):
+    """A case with an omega > 1 - 1e-5 layer: there the reference's algorithm in float64 (the oracle) loses up to ~1e6 ulp
+    and is itself beyond the north star's 1e-6 on some atmospheres, so the case is judged against its committed 40-digit
+    solution (tools/hp_truth_case.py): the HIP path within tol_scale / tol_pw of the truth -- the tolerances every
+    well-conditioned case is held to against the oracle -- AND the disagreement between HIP and oracle is the oracle's:
+    |oracle - truth| >= |HIP - oracle| - tol_scale."""
+    from conftest import record_parity
+    import goldens
+    path = os.path.join(HP_DIR, f"{family}_{seed}.npz")
+    assert os.path.exists(path), f"no 40-digit fixture for the near-conservative case {family}/{seed}: run tools/hp_truth_case.py {family} {seed}"
+    z = np.load(path)
+    a, b = goldens.max_rel_err(got_u, z["u"])
+    oa, ob = goldens.max_rel_err(oracle_u, z["u"])
+    ha, hb = goldens.max_rel_err(got_u, oracle_u)
+    record_parity(f"{family}/{seed}", a, b, tol_scale, tol_pw, against="40-digit truth", oracle_vs_truth_scale_rel=oa,
+                  oracle_vs_truth_pointwise_rel=ob, hip_vs_oracle_scale_rel=ha, hip_vs_oracle_pointwise_rel=hb)
+    assert oa >= ha - tol_scale, (family, seed, "the oracle is closer to the truth than to the HIP path", oa, ha)
 
 
 def make_case(seed):
@@ -59,23 +114,14 @@ def make_case(seed):
 @pytest.mark.parametrize("seed", range(60))
 def test_random_case_matches_oracle(seed):
     import pydisort_amd
-    from oracle import disort_oracle as O
     kw = make_case(seed)
+    tau, phi = eval_points("random", seed, kw)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        try:
-            ref = O.pydisort(**kw)
-        except Exception:
-            pytest.skip("oracle rejects this random input")
+        ref = oracle_solution("random", seed, kw, tau)
         got = pydisort_amd.pydisort(**kw)
-    tau_arr = kw["tau_arr"]
-    rng = np.random.default_rng(seed)
-    tau = np.sort(np.concatenate(([0.0, tau_arr[-1]], tau_arr[:-1], rng.uniform(0, tau_arr[-1], 5))))
-    phi = np.array([0.0, 0.7, 3.0, 5.5])
     want0 = ref[3](tau)
     scale = max(float(np.max(np.abs(want0))), 1e-300)
-    if not np.isfinite(scale) or np.max(np.abs(ref[1](tau))) > 1e8 * scale:
-        pytest.skip("oracle result is not finite / ill-conditioned")
     assert np.max(np.abs(got[3](tau) - want0)) / scale < 1e-8
     assert np.allclose(got[1](tau), ref[1](tau), rtol=1e-7, atol=1e-9 * scale)
     for a, b in zip(got[2](tau), ref[2](tau)):
@@ -127,39 +173,29 @@ def make_case_many_streams(seed):
 
 @pytest.mark.parametrize("seed", range(40))
 def test_random_many_stream_case_matches_oracle(seed):
+    """Both metrics of SURVEY 8(d), both asserted: 1e-9 of the field scale (what two float64 implementations reach) and the
+    north star's 1e-6 pointwise -- against the oracle, or, for the cases with a near-conservative layer, against their
+    40-digit solution (see ``arbitrated``)."""
     import pydisort_amd
-    from oracle import disort_oracle as O
-    kw = make_case_many_streams(seed)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        try:
-            ref = O.pydisort(**kw)
-        except Exception:
-            pytest.skip("oracle rejects this random input")
-        got = pydisort_amd.pydisort(**kw)
-    tau_arr = kw["tau_arr"]
-    rng = np.random.default_rng(seed)
-    tau = np.sort(np.concatenate(([0.0, tau_arr[-1]], tau_arr[:-1], rng.uniform(0, tau_arr[-1], 5))))
-    phi = np.array([0.0, 0.7, 3.0, 5.5])
-    want = ref[4](tau, phi)
-    scale = max(float(np.max(np.abs(want))), 1e-300)
-    if not np.isfinite(scale) or np.max(np.abs(ref[1](tau))) > 1e8 * scale:
-        pytest.skip("oracle result is not finite / ill-conditioned")
-    # Layers with omega = 1 - 1e-6 limit the ORACLE, not the HIP path: against a 40-digit solution of a 20-layer,
-    # 32-stream atmosphere with four such layers the reference's algorithm in float64 is off by 6.4e-8 (Fourier mode 0;
-    # 1e-12 for the other modes) while the HIP path is below 1e-11 (tools/hp_truth_q32.py,
-    # test_high_precision_truth_32_streams); random mixes reach 3e-7.  So: the north star's 1e-6 for those, and what two
-    # float64 implementations reach (1e-9 of the field scale) for everything else.  Both metrics of SURVEY 8(d).
     from conftest import record_parity
     import goldens
+    kw = make_case_many_streams(seed)
+    tau, phi = eval_points("random32", seed, kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = oracle_solution("random32", seed, kw, tau)
+        got = pydisort_amd.pydisort(**kw)
+    want, gotu = ref[4](tau, phi), got[4](tau, phi)
+    scale = max(float(np.max(np.abs(want))), 1e-300)
     near_conservative = bool(np.any(kw["omega_arr"] > 1 - 1e-5))
-    tol = 1e-6 if near_conservative else 1e-9
-    a, b = goldens.max_rel_err(got[4](tau, phi), want)
-    record_parity("random32/%d" % seed, a, b, tol, 1e-6 if near_conservative else 1e-6)
-    assert a < tol
-    if not near_conservative:
-        assert b < 1e-6  # pointwise relative over |I| > 1e-8 max |I|
-    assert np.allclose(got[1](tau), ref[1](tau), rtol=10 * tol, atol=tol * scale)
+    if near_conservative:
+        arbitrated("random32", seed, gotu, want)
+        z = np.load(os.path.join(HP_DIR, f"random32_{seed}.npz"))
+        assert np.allclose(got[1](tau), z["flux_up"], rtol=1e-8, atol=1e-9 * scale)
+    else:
+        a, b = goldens.max_rel_err(gotu, want)
+        record_parity("random32/%d" % seed, a, b, 1e-9, 1e-6)
+        assert np.allclose(got[1](tau), ref[1](tau), rtol=1e-8, atol=1e-9 * scale)
 
 
 def make_case_64_streams(seed):
@@ -185,34 +221,26 @@ def make_case_64_streams(seed):
 
 @pytest.mark.parametrize("seed", range(12))
 def test_random_64_stream_case_matches_oracle(seed):
+    """As the 32-stream cases; against the oracle the scale tolerance is 2e-9 (64 streams: the reference's own roundoff is
+    ~1e-9, see the cfg5 goldens).  Seed 5 is the atmosphere where the reference's algorithm is 3.4e-6 off the truth
+    (tools/hp_truth_q32.py --q56); every near-conservative seed is now judged against its own 40-digit solution."""
     import pydisort_amd
     from conftest import record_parity
     import goldens
-    from oracle import disort_oracle as O
     kw = make_case_64_streams(seed)
+    tau, phi = eval_points("random64", seed, kw)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        try:
-            ref = O.pydisort(**kw)
-        except Exception:
-            pytest.skip("oracle rejects this random input")
+        ref = oracle_solution("random64", seed, kw, tau)
         got = pydisort_amd.pydisort(**kw)
-    tau_arr = kw["tau_arr"]
-    rng = np.random.default_rng(seed)
-    tau = np.sort(np.concatenate(([0.0, tau_arr[-1]], tau_arr[:-1], rng.uniform(0, tau_arr[-1], 3))))
-    phi = np.array([0.0, 0.7, 3.0])
-    want = ref[4](tau, phi)
+    want, gotu = ref[4](tau, phi), got[4](tau, phi)
     scale = max(float(np.max(np.abs(want))), 1e-300)
-    if not np.isfinite(scale) or np.max(np.abs(ref[1](tau))) > 1e8 * scale:
-        pytest.skip("oracle result is not finite / ill-conditioned")
-    # Near-conservative layers at these stream counts: the ORACLE (the reference's algorithm in float64) is the one that is
-    # off -- 3.4e-6 of the field scale against a 40-digit solution on seed 5's atmosphere (56 streams, one thin
-    # omega = 1 - 1e-6 layer), where the HIP path is within 1e-11 (tools/hp_truth_q32.py --q56,
-    # test_high_precision_truth_56_streams).  Such cases are held to 2e-5 against the oracle; the others to 2e-9
-    # (64 streams: the reference's own roundoff is ~1e-9, see the cfg5 goldens).
     near_conservative = bool(np.any(kw["omega_arr"] > 1 - 1e-5))
-    tol = 2e-5 if near_conservative else 2e-9
-    a, b = goldens.max_rel_err(got[4](tau, phi), want)
-    record_parity("random64/%d" % seed, a, b, tol, 1e-6)
-    assert a < tol
-    assert np.allclose(got[1](tau), ref[1](tau), rtol=10 * tol, atol=tol * scale)
+    if near_conservative:
+        arbitrated("random64", seed, gotu, want, tol_scale=2e-9)
+        z = np.load(os.path.join(HP_DIR, f"random64_{seed}.npz"))
+        assert np.allclose(got[1](tau), z["flux_up"], rtol=2e-8, atol=2e-9 * scale)
+    else:
+        a, b = goldens.max_rel_err(gotu, want)
+        record_parity("random64/%d" % seed, a, b, 2e-9, 1e-6)
+        assert np.allclose(got[1](tau), ref[1](tau), rtol=2e-8, atol=2e-9 * scale)

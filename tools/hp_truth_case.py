@@ -1,0 +1,364 @@
+#!/usr/bin/env python3
+"""High-precision (mpmath, 40 digits) arbitration of ANY parity case: when the HIP path and the float64 oracle (= the
+reference's algorithm) differ by more than the north star's 1e-6, somebody has to say who is right.
+
+This is the reference's mathematics -- SURVEY Appendix A, i.e. the equations oracle/disort_oracle.py restates -- carried
+out in 40-digit arithmetic for every Fourier mode of one column and evaluated at the very points the parity test uses:
+
+  * per (mode, layer) the reference's non-symmetric eigenproblem (alpha - beta)(alpha + beta) V = V k^2
+    (_solve_for_gen_and_part_sols.py:179-198) with mpmath's general eigensolver, G = [[V+U, V-U],[V-U, V+U]],
+    U = (alpha + beta) V / k; the reference's shortcut for layers without multiple scattering (:119, :162-168) is part of
+    the model (decided on the float64 inputs exactly as the reference decides it) and is replicated;
+  * the beam particular solution from the 2N x 2N system (A + I/mu0) B = X (:226-231);
+  * the thermal particular solution v(tau) = G (sum_q b_q(K) tau^q) (G^-1 M^-1 1) (subroutines.py:746-862);
+  * the reference's boundary-condition system, with BDRF surface terms and the Stamnes-Conklin scaling
+    (_solve_for_coeffs.py:121-323), by Gaussian elimination with partial pivoting inside the band;
+  * the evaluators (_assemble_intensity_and_fluxes.py:170-613): u^m(tau), the Fourier sum, u0, flux_up.
+
+Nothing of the device's algorithm (symmetrisation, Cholesky, one-sided Jacobi, structured block elimination) is used.
+The inputs of the hot path (delta-M scaling, quadrature, source rescale: oracle.prepare, float64) are common to all
+three parties.  Nakajima-Tanaka corrections are post-processing and are left out (the cases are solved with NT_cor off).
+
+Fixtures: tests/golden/hp/<family>_<seed>.npz = the evaluation points, u [Q, ntau, nphi], u0, flux_up of the truth and,
+for the record, the oracle's distance to it.  Families: random32 / random64 / random (the seeded generators of
+tests/test_gpu_random_parity.py) and golden (a reference-captured case of tests/golden/ref by name).
+
+Usage (build container; minutes per case on 6 processes):
+    python3 tools/hp_truth_case.py random32 9 25          # family, seeds ...
+    python3 tools/hp_truth_case.py random64 11
+    python3 tools/hp_truth_case.py golden 8ARTS_A
+    python3 tools/hp_truth_case.py --near-conservative    # every random32 / random64 seed with an omega > 1 - 1e-5 layer
+"""
+import multiprocessing
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+import mpmath as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+from oracle import disort_oracle as O  # noqa: E402  (host-side preparation only: delta-M scaling, quadrature, tables)
+
+mp.mp.dps = 40
+OUT = os.path.join(ROOT, "tests", "golden", "hp")
+WORKERS = int(os.environ.get("HP_WORKERS", "6"))
+
+
+def mpf(x):
+    return mp.mpf(float(x))
+
+
+def banded_solve(rows, rhs, kl):
+    """Gaussian elimination with partial pivoting on a banded system in mpmath numbers.  rows[i] is a dict
+    {column: value} of row i; fill stays inside [i - kl, i + 2 kl] as in LAPACK's dgbsv."""
+    n = len(rows)
+    zero = mp.mpf(0)
+    for c in range(n):
+        piv, best = c, abs(rows[c].get(c, zero))
+        for r in range(c + 1, min(n, c + kl + 1)):
+            v = abs(rows[r].get(c, zero))
+            if v > best:
+                piv, best = r, v
+        if piv != c:
+            rows[c], rows[piv] = rows[piv], rows[c]
+            rhs[c], rhs[piv] = rhs[piv], rhs[c]
+        prow, pv = rows[c], rows[c][c]
+        tail = [(k, a) for k, a in prow.items() if k > c]
+        for r in range(c + 1, min(n, c + kl + 1)):
+            v = rows[r].pop(c, None)
+            if v is None or v == 0:
+                continue
+            f = v / pv
+            rr = rows[r]
+            for k, a in tail:
+                rr[k] = rr.get(k, zero) - f * a
+            rhs[r] -= f * rhs[c]
+    x = [zero] * n
+    for c in range(n - 1, -1, -1):
+        s = rhs[c]
+        for k, a in rows[c].items():
+            if k > c:
+                s -= a * x[k]
+        x[c] = s / rows[c][c]
+    return x
+
+
+def solve_mode(args):
+    """u^m at the points (ts_pts: delta-scaled optical depths, l_pts: their layers) -> float64 [Q, npts], BEFORE the
+    rescale factor.  Mirrors oracle.gen_and_part_sols / solve_for_coeffs / Solution._um, in 40 digits."""
+    p, m, ts_pts, l_pts = args
+    mp.mp.dps = 40
+    L, N, P = p["L"], p["N"], p["P"]
+    Q = 2 * N
+    mu = [mpf(x) for x in p["mu"]]
+    w = [mpf(x) for x in p["W"]]
+    beam, iso = bool(p["beam"]), bool(p["iso"]) and m == 0
+    mu0 = mpf(p["mu0"])
+    ts = [mpf(x) for x in p["tau_s0"]]
+    one, zero = mp.mpf(1), mp.mpf(0)
+
+    def leg(x):  # sqrt((l-m)!/(l+m)!) P_l^m(x): the reference's poch factor (:96) split over both factors of each product
+        return [zero if ell < m else mp.legenp(ell, m, x, type=2) * mp.sqrt(mp.factorial(ell - m) / mp.factorial(ell + m))
+                for ell in range(P)]
+    Y = [leg(x) for x in mu]
+    Y0 = leg(-mu0) if beam else None
+    Gs, Ks, Bs, Zs = [], [], [], []
+    for l in range(L):
+        c64 = 0.5 * p["omega_s"][l] * p["wleg"][l, m:]
+        if not np.any(np.abs(c64) > 1e-8):  # the reference's shortcut (:119, :162-168), decided on the float64 inputs
+            G = mp.zeros(Q)
+            for i in range(N):
+                G[i, N + i] = G[N + i, i] = one
+            Gs.append(G)
+            Ks.append([-1 / x for x in mu] + [1 / x for x in mu])
+            Bs.append([zero] * Q)
+            if iso:  # G_inv = trivial (:168): z = trivial [1/mu; -1/mu]
+                Zs.append([-1 / x for x in mu] + [1 / x for x in mu])
+            continue
+        om = mpf(p["omega_s"][l])
+        wl = [mpf(x) for x in p["wleg"][l]]
+        sgn = [(-1) ** (ell - m) for ell in range(P)]
+        al, be = mp.zeros(N), mp.zeros(N)
+        for i in range(N):
+            for j in range(N):
+                sp = sm = zero
+                for ell in range(m, P):
+                    t = om / 2 * wl[ell] * Y[i][ell] * Y[j][ell]
+                    sp += t
+                    sm += t * sgn[ell]
+                al[i, j] = (sp * w[j] - (1 if i == j else 0)) / mu[i]
+                be[i, j] = sm * w[j] / mu[i]
+        ev, V = mp.eig((al - be) * (al + be))
+        k = [mp.sqrt(mp.re(e)) for e in ev]
+        V = V.apply(mp.re)
+        U = (al + be) * V
+        for j in range(N):
+            for i in range(N):
+                U[i, j] /= k[j]
+        G = mp.zeros(Q)
+        for i in range(N):
+            for j in range(N):
+                G[i, j] = G[N + i, N + j] = V[i, j] + U[i, j]
+                G[i, N + j] = G[N + i, j] = V[i, j] - U[i, j]
+        Gs.append(G)
+        Ks.append([-x for x in k] + k)
+        if beam:
+            A = mp.zeros(Q)
+            for i in range(N):
+                for j in range(N):
+                    A[i, j], A[i, N + j], A[N + i, j], A[N + i, N + j] = -al[i, j], -be[i, j], be[i, j], al[i, j]
+            X = mp.zeros(Q, 1)
+            for i in range(N):
+                xp = xm = zero
+                for ell in range(m, P):
+                    t = mpf(p["I0_4pi"]) * (1 if m == 0 else 2) * om * wl[ell] * Y0[ell] * Y[i][ell]
+                    xp += t
+                    xm += t * sgn[ell]
+                X[i], X[N + i] = xp / mu[i], -xm / mu[i]
+            Bs.append(list(mp.lu_solve(A + mp.eye(Q) / mu0, X)))
+        else:
+            Bs.append([zero] * Q)
+        if iso:  # z = G^-1 [1/mu; -1/mu]  (_assemble_intensity_and_fluxes.py:124)
+            rhs = mp.matrix([1 / x for x in mu] + [-1 / x for x in mu])
+            Zs.append(list(mp.lu_solve(G, rhs)))
+
+    Ns = p["Ns"]
+
+    def vth(l, t):  # thermal particular solution at delta-scaled tau t in layer l (subroutines.py:822-862)
+        s_row = [mpf(x) for x in p["s_s"][l]]
+        poly = [zero] * Q
+        for j in range(Q):
+            kk = Ks[l][j]
+            acc = zero
+            for q in range(Ns):
+                bq = zero
+                for jj in range(q, Ns):
+                    bq += mp.factorial(jj) / mp.factorial(q) * s_row[jj] / kk ** (jj - q + 1)
+                acc += bq * t**q
+            poly[j] = acc * Zs[l][j]
+        return [sum(Gs[l][i, j] * poly[j] for j in range(Q)) for i in range(Q)]
+
+    def expo(l, j, t):  # every exponential referenced to the boundary of its layer where it is <= 1
+        kk = Ks[l][j]
+        return mp.e ** (kk * (t - (ts[l + 1] if kk > 0 else ts[l])))
+
+    has_bdrf = len(p["bdrf"]) > m
+    if has_bdrf:  # _solve_for_coeffs.py:121-134
+        R = [[(2 if m == 0 else 1) * mpf(p["bdrf"][m][0][i, j]) * mu[j] * w[j] for j in range(N)] for i in range(N)]
+        Xs = [mu0 * mpf(p["I0_4pi"]) * 4 * mpf(p["bdrf"][m][1][i]) for i in range(N)]
+    n = Q * L
+    rows, rhs = [dict() for _ in range(n)], [zero] * n
+    r = 0
+    v_top = vth(0, ts[0]) if iso else None
+    for i in range(N):  # top boundary: downward streams
+        for j in range(Q):
+            rows[r][j] = Gs[0][N + i, j] * expo(0, j, ts[0])
+        rhs[r] = mpf(p["b_neg"][i, m]) - Bs[0][N + i] * mp.e ** (-ts[0] / mu0)
+        if iso:
+            rhs[r] -= v_top[N + i]
+        r += 1
+    for l in range(L - 1):
+        t = ts[l + 1]
+        if iso:
+            va, vb = vth(l, t), vth(l + 1, t)
+        for i in range(Q):
+            for j in range(Q):
+                rows[r][l * Q + j] = Gs[l][i, j] * expo(l, j, t)
+                rows[r][(l + 1) * Q + j] = -Gs[l + 1][i, j] * expo(l + 1, j, t)
+            rhs[r] = (Bs[l + 1][i] - Bs[l][i]) * mp.e ** (-t / mu0)
+            if iso:
+                rhs[r] += vb[i] - va[i]
+            r += 1
+    tb = ts[L]
+    vb = vth(L - 1, tb) if iso else [zero] * Q
+    att = mp.e ** (-tb / mu0) if beam else zero
+    GL, BL = Gs[L - 1], Bs[L - 1]
+    for i in range(N):  # bottom boundary: upward streams; surface reflection (:288-293, :232, :246-252)
+        for j in range(Q):
+            g = GL[i, j]
+            if has_bdrf:
+                g = g - sum(R[i][q] * GL[N + q, j] for q in range(N))
+            rows[r][(L - 1) * Q + j] = g * expo(L - 1, j, tb)
+        v = mpf(p["b_pos"][i, m]) - BL[i] * att - vb[i]
+        if has_bdrf:
+            v += sum(R[i][q] * (BL[N + q] * att + vb[N + q]) for q in range(N))
+            if beam:
+                v += Xs[i] * att
+        rhs[r] = v
+        r += 1
+    Cc = banded_solve(rows, rhs, 3 * N - 1)
+    out = np.zeros((Q, len(ts_pts)))
+    for ti, (t64, l) in enumerate(zip(ts_pts, l_pts)):
+        t = mpf(t64)
+        l = int(l)
+        ex = [expo(l, j, t) * Cc[l * Q + j] for j in range(Q)]
+        bt = mp.e ** (-t / mu0) if beam else zero
+        vv = vth(l, t) if iso else None
+        for i in range(Q):
+            v = Bs[l][i] * bt
+            for j in range(Q):
+                v += Gs[l][i, j] * ex[j]
+            if iso:
+                v += vv[i]
+            out[i, ti] = float(v)
+    return out
+
+
+def truth(kw, tau, phi, parallel=True):
+    """(u [Q, ntau, nphi] or None when only_flux, u0 [Q, ntau], flux_up [ntau]) of the 40-digit solution at optical depths
+    tau and azimuths phi, in the units of the inputs.  parallel: one process per Fourier mode."""
+    kw = dict(kw)
+    kw.pop("NT_cor", None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        p = O.prepare(**kw)
+    if not p["beam"]:
+        p["mu0"] = 1.0  # no beam: every beam term carries the factor I0 = 0
+    _, l_pts, ts_pts = O.Solution._locate(type("S", (), {"p": p})(), tau)
+    jobs = [(p, m, ts_pts, l_pts) for m in range(p["M"])]
+    if parallel and p["M"] > 1:
+        with multiprocessing.Pool(min(WORKERS, p["M"])) as pool:
+            um = pool.map(solve_mode, jobs, chunksize=1)
+    else:
+        um = [solve_mode(j) for j in jobs]
+    um = np.stack(um)  # [M, Q, ntau]
+    u0 = p["rescale"] * um[0]
+    fup = p["rescale"] * 2 * np.pi * (p["mu"] * p["W"]) @ um[0][:p["N"]]
+    if p["only_flux"]:
+        return None, u0, fup
+    cosm = np.cos(np.arange(p["M"])[:, None] * (p["phi0"] - np.atleast_1d(np.asarray(phi, float)))[None, :])
+    return p["rescale"] * np.einsum("mit,mp->itp", um, cosm), u0, fup
+
+
+def case_of(family, key):
+    """(kwargs, tau, phi) of a random case exactly as its parity test builds them."""
+    import test_gpu_random_parity as T
+    seed = int(key)
+    kw = {"random": T.make_case, "random32": T.make_case_many_streams, "random64": T.make_case_64_streams}[family](seed)
+    tau, phi = T.eval_points(family, seed, kw)
+    return kw, tau, phi
+
+
+def _golden_call(job):
+    kw, tau, phi = job
+    return truth(kw, tau, phi, parallel=False)[0]
+
+
+def run_golden(test_id):
+    """A reference-captured case (tests/golden/ref/<test_id>.npz): the truth of the FIRST plain `u(tau, phi)` evaluation
+    of every captured pydisort call, stored as c<i>.u with the shape the reference returned (squeezed axes)."""
+    import goldens
+    calls = goldens.load(test_id)
+    jobs, meta = [], []
+    for ci, call in enumerate(calls):
+        for ev in call["evals"]:
+            if ev["name"] == "u" and not ev["kwargs"] and len(ev["args"]) == 2:
+                kw = {k: v for k, v in call["kwargs"].items() if k != "autograd_compatible"}
+                jobs.append((kw, np.atleast_1d(ev["args"][0]), np.atleast_1d(ev["args"][1])))
+                meta.append((ci, np.shape(ev["out"]), ev["out"]))
+                break
+    t0 = time.time()
+    with multiprocessing.Pool(WORKERS) as pool:
+        us = pool.map(_golden_call, jobs, chunksize=1)
+    res, worst = {}, 0.0
+    for (ci, shape, ref_out), u in zip(meta, us):
+        u = u.reshape(shape)
+        res[f"c{ci}.u"] = u
+        big = np.abs(u) > 1e-8 * np.max(np.abs(u))
+        worst = max(worst, float(np.max(np.abs(ref_out - u)[big] / np.abs(u)[big])))
+    res["reference_u_pointwise_rel"] = worst
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, f"golden_{test_id}.npz"), **res)
+    print(f"golden/{test_id}: {len(jobs)} calls, {time.time() - t0:.0f} s; the reference's own float64 result vs truth, "
+          f"pointwise: {worst:.2e}", flush=True)
+
+
+def run(family, key):
+    kw, tau, phi = case_of(family, key)
+    t0 = time.time()
+    u, u0, fup = truth(kw, tau, phi)
+    kwo = dict(kw)
+    kwo.pop("NT_cor", None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = O.pydisort(**kwo)
+    res = dict(tau=tau, phi=phi, u0=u0, flux_up=fup, oracle_u0_scale_rel=np.max(np.abs(ref[3](tau) - u0)) / np.max(np.abs(u0)))
+    if u is not None:
+        ou = ref[4](tau, phi)
+        res.update(u=u, oracle_u_scale_rel=np.max(np.abs(ou - u)) / np.max(np.abs(u)))
+        big = np.abs(u) > 1e-8 * np.max(np.abs(u))
+        res["oracle_u_pointwise_rel"] = np.max(np.abs(ou - u)[big] / np.abs(u)[big])
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, f"{family}_{key}.npz"), **res)
+    print(f"{family}/{key}: NQuad {kw['NQuad']}, {len(np.atleast_1d(kw['tau_arr']))} layers, {time.time() - t0:.0f} s; oracle vs truth: "
+          + ", ".join(f"{k[7:]} {float(v):.2e}" for k, v in res.items() if k.startswith("oracle_")), flush=True)
+
+
+def near_conservative_seeds():
+    import test_gpu_random_parity as T
+    out = []
+    for family, make, n in (("random32", T.make_case_many_streams, 40), ("random64", T.make_case_64_streams, 12)):
+        for seed in range(n):
+            if np.any(make(seed)["omega_arr"] > 1 - 1e-5):
+                out.append((family, str(seed)))
+    return out
+
+
+if __name__ == "__main__":
+    if "--near-conservative" in sys.argv:
+        todo = near_conservative_seeds()
+        if "--list" in sys.argv:
+            print(todo)
+            sys.exit(0)
+    else:
+        todo = [(sys.argv[1], k) for k in sys.argv[2:] if not k.startswith("--")]
+    for family, key in todo:
+        if family == "golden":
+            run_golden(key)
+            continue
+        if "--skip-existing" in sys.argv and os.path.exists(os.path.join(OUT, f"{family}_{key}.npz")):
+            continue
+        run(family, key)
