@@ -9,8 +9,11 @@ _solve_for_gen_and_part_sols.py:88-91 and _solve_for_coeffs.py:110-111 carry no 
 them with no exchange during the solve; one RCCL all-gather of u and the fluxes per step stitches the
 outputs of all ranks, on its own stream so that it overlaps the next step.
 
-  weak scaling (default)  : every GPU solves --columns columns per step
-  strong scaling          : --total-columns T splits T columns over the GPUs (BASELINE's literal 10^5)
+  strong scaling (default): --total-columns T (default 100000: BASELINE's literal batch) is split over the GPUs and
+                            solved in windows of --columns columns (2048): a step = the whole batch, 100000/N per GPU
+  weak scaling            : --total-columns 0: every GPU solves --columns columns per step
+  --gather all|root|none  : what happens to the results of a step when N > 1 -- ncclAllGather to every rank (default),
+                            ncclSend/ncclRecv to rank 0 only, or nothing (compute scaling alone)
 
 Launch: `python bench.py --gpus N ...` starts N fresh rank processes itself (one per GPU, before anything in
 this process has touched a GPU) unless it already runs under torch.distributed.run (RANK / WORLD_SIZE set),
@@ -38,14 +41,16 @@ L, NQUAD, NTAU, NPHI = 20, 32, 21, 3
 EXIT_RANKS, EXIT_RCCL, EXIT_TIMEOUT = 2, 3, 124
 
 
-def algorithmic_flops():
+def algorithmic_flops(nlayers=L, nquad=NQUAD, nmodes=None, ntau=NTAU):
     """Per-column algorithmic FLOPs per kernel (F_col = L[2N^2 P(P+1) + 70.3 N^3 M] = 195 MFLOP
     for cfg4; per (m, l): assembly 4N^2(P-m), product 2N^3, eigen-decomposition 25N^3, U = (alpha+beta)V/k 2N^3,
     particular solve 5.33N^3, BC solve 36N^3 per layer)."""
-    N, P, M = NQUAD // 2, NQUAD, NQUAD
-    ml = L * M
-    fl = dict(asm=L * 2 * N * N * P * (P + 1) + 2 * N**3 * ml, jacobi=25.0 * N**3 * ml, post=(2 + 5.33) * N**3 * ml,
-              bc=36.0 * N**3 * ml, eval=NTAU * M * (2 * N) * (2 * N) * 2.0)
+    N, P = nquad // 2, nquad
+    M = nquad if nmodes is None else nmodes
+    ml = nlayers * M
+    asm_gemm = nlayers * sum(4 * N * N * (P - m) for m in range(M))  # = L 2N^2 P(P+1) when M = P
+    fl = dict(asm=asm_gemm + 2 * N**3 * ml, jacobi=25.0 * N**3 * ml, post=(2 + 5.33) * N**3 * ml,
+              bc=36.0 * N**3 * ml, eval=ntau * M * (2 * N) * (2 * N) * 2.0)
     fl["total"] = fl["asm"] + fl["jacobi"] + fl["post"] + fl["bc"]
     return fl
 
@@ -53,7 +58,7 @@ def algorithmic_flops():
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json, else
     the round-1 file; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as read), or None."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
@@ -159,9 +164,91 @@ def cpu_baseline_subprocess():
 # ---------------------------------------------------------------------------------------------------------
 # secondary measurements on rank 0 at N = 1
 # ---------------------------------------------------------------------------------------------------------
-def extra_measurements(device):
+def roofline_of(stage, fl, cols_per_launch, kernel_names):
+    """roofline sub-object of one workload from the plan's HIP-event stage times (ms, launches) per slot."""
+    ms = {k: (v[0] / max(v[1], 1)) for k, v in stage.items()}  # per launch = per window
+    ms["bc"] = ms["iface"] + ms["sweep"]
+    ms["eigen"] = ms["asm"] + ms["jacobi"] + ms["post"]  # one fused kernel (timed in the jacobi slot)
+    dom = "eigen" if ms["eigen"] >= ms["bc"] else "bc"
+    dom_flops = fl["bc"] if dom == "bc" else fl["asm"] + fl["jacobi"] + fl["post"]
+    achieved = dom_flops * cols_per_launch / (ms[dom] * 1e-3) / 1e12
+    return {"bound": "fp64-valu", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP64_PEAK_TFLOPS, "kernel": kernel_names[dom], "kernel_ms_per_launch": ms,
+            "columns_per_launch": cols_per_launch}, ms
+
+
+def golden_parity(name, maker, kwargs, device):
+    """max scale-relative / pointwise error of the HIP path on the reference-computed golden columns of a synthetic config
+    (tests/golden/synth/<name>.npz: outputs of PythonicDISORT itself, generated in the build container)."""
+    import pydisort_amd
+    from pydisort_amd import synthetic
+    z = np.load(os.path.join(ROOT, "tests", "golden", "synth", name + ".npz"))
+    ncol = int(z["ncol"])
+    cfg = getattr(synthetic, maker)(ncol, **kwargs)
+    _, sol = pydisort_amd.pydisort_batch(device=device, **cfg)
+    tau = np.stack([z[f"c{i}.tau_pts"] for i in range(ncol)])
+    u = sol.u(tau, z["phi"])
+    worst = worst_pw = 0.0
+    for i in range(ncol):
+        want = z[f"c{i}.u"]
+        diff = np.abs(u[i] - want)
+        sig = np.abs(want) > 1e-8 * np.max(np.abs(want))
+        worst = max(worst, float(diff.max() / np.max(np.abs(want))))
+        worst_pw = max(worst_pw, float((diff[sig] / np.abs(want[sig])).max()))
+    sol.plan.close()
+    return {"max_scale_rel": worst, "max_rel_dI": worst_pw, "columns_checked": ncol,
+            "against": f"reference-computed goldens tests/golden/synth/{name}.npz"}
+
+
+def config_leg(name, golden, maker, kwargs, columns, window, device, passes):
+    """One of BASELINE's other configs through the same path: resident rate (plan.run over all windows), host-to-host
+    rate (run_fetch: D2H of a window overlapped with the next window's kernels), HIP-event kernel times -> roofline,
+    parity of the first columns against the reference-computed goldens."""
+    import pydisort_amd
+    from pydisort_amd import synthetic
+    cfg = getattr(synthetic, maker)(columns, **kwargs)
+    nl, nq = cfg["tau_arr"].shape[1], cfg["NQuad"]
+    tau = np.concatenate((np.zeros((columns, 1)), cfg["tau_arr"]), axis=1)
+    phi = np.array([0.0, np.pi / 2, np.pi])
+    _, sol = pydisort_amd.pydisort_batch(device=device, work_columns=window, _defer_solve=True, **cfg)
+    plan = sol.plan
+    plan.set_eval_points(tau, phi)
+    plan.run()
+    plan.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        plan.run()
+    plan.synchronize()
+    rate = passes * columns / (time.perf_counter() - t0)
+    out_arrays = plan.run_fetch()  # warm (pinned staging)
+    t0 = time.perf_counter()
+    out_arrays = plan.run_fetch()
+    e2e = columns / (time.perf_counter() - t0)
+    assert np.all(np.isfinite(out_arrays["flux_up"]))
+    plan.enable_timing(True)
+    plan.timing(reset=True)
+    for _ in range(2):
+        plan.run()
+    stage = plan.timing(reset=True)
+    plan.enable_timing(False)
+    cw, nwin = plan.windows()
+    fl = algorithmic_flops(nl, nq, nq, nl + 1)
+    np_ = 4 if nq <= 8 else 8 if nq <= 16 else 16 if nq <= 32 else 32
+    names = {"eigen": f"rtd_eigen_kernel<{np_}, 2>",
+             "bc": "rtd_bc_tile_kernel<2>" if np_ == 32 else "rtd_bc_mfma_kernel<4>" if np_ == 16 else f"rtd_iface_kernel<{np_}> + rtd_sweep_kernel<{np_}>"}
+    roof, ms = roofline_of(stage, fl, columns / nwin, names)
+    roof["whole_path_tflops"] = fl["total"] * rate / 1e12
+    roof["whole_path_frac"] = roof["whole_path_tflops"] / FP64_PEAK_TFLOPS
+    roof["traffic"] = None
+    plan.close()
+    return {"value": rate, "unit": "column-solves/sec", "workload": name, "columns": columns, "columns_per_window": cw,
+            "windows": nwin, "host_to_host": e2e, "mflop_per_column": fl["total"] / 1e6, "roofline": roof,
+            "parity": golden_parity(golden, maker, kwargs, device)}
+
+
+def extra_measurements(device, main_cfg=None, window=2048):
     """max |dI| of the HIP path against the oracle on the sample columns of the cpu_baseline leg, the only_flux
-    throughput, and the host-to-host rate on 10^5 columns."""
+    throughput, the host-to-host rate of the main batch, and BASELINE's other configs."""
     import pydisort_amd
     from pydisort_amd import synthetic
     out = {}
@@ -180,8 +267,9 @@ def extra_measurements(device):
             sol.plan.close()
         out["parity"] = {"max_abs_dI": worst_abs, "max_rel_dI": worst_rel, "columns_checked": len(_ORACLE_SAMPLES),
                          "against": "CPU oracle (pinned to the reference) on the same seeded cfg4 columns"}
+    out["parity_goldens"] = golden_parity("cfg4", "cfg4_columns", {}, device)
     C = 16384
-    cfg = synthetic.cfg4_columns(C, first=50_000)
+    cfg = synthetic.cfg4_columns_block(C, first=50_000)
     _, sol = pydisort_amd.pydisort_batch(only_flux=True, device=device, **cfg)
     plan = sol.plan
     tau = np.concatenate((np.zeros((C, 1)), cfg["tau_arr"]), axis=1)
@@ -195,20 +283,32 @@ def extra_measurements(device):
     out["only_flux"] = {"value": 5 * C / (time.perf_counter() - t0), "unit": "column-solves/sec",
                         "workload": "cfg4 with only_flux=True (one Fourier mode), 16384 columns per pass"}
     plan.close()
-    out["e2e"] = end_to_end(device)
+    out["e2e"] = end_to_end(device, main_cfg, window)
+    out["other_configs"] = {
+        "cfg3_L6_Q8_x1024": config_leg("cfg3: Test Problem 9c (6 layers, 8 streams, thermal + beam + Lambertian surface) x 1024 perturbed columns",
+                                       "cfg3_small", "cfg3_columns", {"big": False}, 1024, 0, device, 50),
+        "cfg3_L8_Q16_x1024": config_leg("cfg3 at BASELINE's size (8 layers, 16 streams) x 1024 perturbed columns",
+                                        "cfg3_big", "cfg3_columns", {"big": True}, 1024, 0, device, 50),
+        "cfg5_L50_Q64_x1024": config_leg("cfg5: 50 layers, 64 streams, 64 Fourier modes, 2-mode BDRF surface, thermal source; 1024 columns in windows",
+                                         "cfg5", "cfg5_columns", {}, 1024, 128, device, 2),
+    }
     return out
 
 
-def end_to_end(device, columns=100_000):
-    """Host arrays in -> host arrays out for BASELINE's literal cfg4 batch: preparation of the prepared arguments,
-    upload, windowed solve, evaluation, and the device-to-host copies overlapped with the next window's kernels."""
+def end_to_end(device, cfg=None, window=2048):
+    """Host arrays in -> host arrays out for the main batch (BASELINE's literal 10^5 cfg4 columns by default): input
+    checks, upload of the raw inputs, delta-M scaling on the device, windowed solve, evaluation, and the device-to-host
+    copies overlapped with the next window's kernels."""
     import pydisort_amd
     from pydisort_amd import synthetic
-    cfg = synthetic.cfg4_columns_block(columns, first=200_000)
+    if cfg is None:
+        cfg = synthetic.cfg4_columns_block(100_000, first=0)
+    columns = cfg["tau_arr"].shape[0]
     tau = np.concatenate((np.zeros((columns, 1)), cfg["tau_arr"]), axis=1)
     phi = np.array([0.0, np.pi / 2, np.pi])
-    pydisort_amd.solve_columns_streamed({k: (v[:4096] if isinstance(v, np.ndarray) else v) for k, v in cfg.items()},
-                                        tau[:4096], phi, chunk_columns=2048, device=device)  # warm-up
+    nwarm = min(columns, 2 * window)
+    pydisort_amd.solve_columns_streamed({k: (v[:nwarm] if isinstance(v, np.ndarray) else v) for k, v in cfg.items()},
+                                        tau[:nwarm], phi, chunk_columns=window, device=device)  # warm-up
     # result arrays are the caller's (a serving loop reuses them): allocated and touched once, outside the timed call
     out = dict(u=np.zeros((columns, NQUAD, NTAU, NPHI)), u0=np.zeros((columns, NQUAD, NTAU)), flux_up=np.zeros((columns, NTAU)),
                flux_down_diffuse=np.zeros((columns, NTAU)), flux_down_direct=np.zeros((columns, NTAU)))
@@ -217,7 +317,7 @@ def end_to_end(device, columns=100_000):
     calls = []
     for _ in range(3):
         t0 = time.perf_counter()
-        res = pydisort_amd.solve_columns_streamed(cfg, tau, phi, chunk_columns=2048, device=device, out=out)
+        res = pydisort_amd.solve_columns_streamed(cfg, tau, phi, chunk_columns=window, device=device, out=out)
         calls.append(time.perf_counter() - t0)
     best = min(calls)
     assert np.all(np.isfinite(res["flux_up"])) and res["u"] is out["u"]
@@ -225,11 +325,12 @@ def end_to_end(device, columns=100_000):
     #  box's CPU cores and memory bus with whatever else runs there: calls of 1.45 s next to the usual 0.53 s have been seen
     #  on a busy host, hence every call's time is reported)
     return {"value": columns / best, "unit": "column-solves/sec", "columns": columns, "seconds": best,
-            "seconds_per_call": [round(x, 4) for x in calls],
-            "what": "host NumPy inputs (raw: tau, omega, 33 moments, f, mu0, I0, phi0) -> host NumPy u [C,32,21,3], u0, fluxes, "
-                    "one call: input checks, plan creation, H2D of the raw inputs, delta-M scaling / rescaling on the device, "
-                    "windowed solve + evaluation (2048 columns per window), D2H through pinned staging overlapped with the next "
-                    "window; result arrays preallocated by the caller; best of 3 calls"}
+            "seconds_per_call": [round(x, 4) for x in calls], "median": columns / sorted(calls)[1],
+            "what": "the SAME batch as `value`, host to host: NumPy inputs (raw: tau, omega, 33 moments, f, mu0, I0, phi0) -> "
+                    "NumPy u [C,32,21,3], u0, fluxes, one call: input checks, plan creation, H2D of the raw inputs, delta-M "
+                    f"scaling / rescaling on the device, windowed solve + evaluation ({window} columns per window), D2H through "
+                    "pinned staging overlapped with the next window; result arrays preallocated by the caller; best of 3 calls "
+                    "(every call's time listed)"}
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -345,14 +446,22 @@ def run_rank(a, rank, world, local):
     strong = a.total_columns > 0
     multi = world > 1 or a.force_dist
     plan = None
+    cfg = None
     if not stub:
         from pydisort_amd import synthetic
+        from pydisort_amd import _engine
         from pydisort_amd._engine import Plan
         from pydisort_amd._prepare import prepare_columns
+        ndev = _engine.device_count()  # hipGetDeviceCount: does not initialise a device
+        if ndev <= local:
+            print(f"[bench] rank {rank}: LOCAL_RANK {local} but only {ndev} HIP device(s) visible: one rank per GPU is the "
+                  "contract (check ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES and --gpus)", file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(EXIT_RANKS)
         cfg = synthetic.cfg4_columns_block(C, first=first) if strong else synthetic.cfg4_columns(C, first=first)
         N = NQUAD // 2
         prep = prepare_columns(cfg["tau_arr"], cfg["omega_arr"], NQUAD, cfg["Leg_coeffs_all"], cfg["mu0"], cfg["I0"],
-                               cfg["phi0"], NQUAD, NQUAD, np.zeros((C, N, NQUAD)), np.zeros((C, N, NQUAD)),
+                               cfg["phi0"], NQUAD, NQUAD, None, None,  # no Dirichlet sources: nothing to allocate or upload
                                cfg["f_arr"], np.zeros((C, L, 0)), np.zeros((C, 0, N, N)), np.zeros((C, 0, N)))
         if multi:
             Plan.comm_preload()  # bind RCCL to librtd's HIP runtime before torch (gloo control plane) is imported
@@ -393,10 +502,12 @@ def run_rank(a, rank, world, local):
             dist.broadcast_object_list(uid, src=0)
             ok = uid[0] is not None
             if ok:
+                gather_call = {"all": plan.allgather_results, "root": lambda: plan.gather_results(0), "none": None}[a.gather]
                 try:
                     plan.comm_init(uid[0], rank, world)
                     plan.run()
-                    plan.allgather_results()
+                    if gather_call:
+                        gather_call()
                     plan.synchronize()
                 except Exception as e:
                     ok, err = False, e
@@ -407,8 +518,11 @@ def run_rank(a, rank, world, local):
             if not everyone:
                 sys.stderr.flush()
                 os._exit(EXIT_RCCL)  # no clean-up through a communicator that may be half-built
-            gather = plan.allgather_results
-            collective = f"rccl ncclAllGather of u + fluxes per step, nranks = {world}, on its own stream (overlaps the next step)"
+            gather = gather_call
+            collective = {
+                "all": f"rccl ncclAllGather of u + fluxes per step, nranks = {world}, on its own stream (overlaps the next step)",
+                "root": f"rccl ncclSend/ncclRecv of u + fluxes to rank 0 per step, nranks = {world}, on its own stream",
+                "none": f"rccl communicator of {world} ranks initialised, no data-path collective (--gather none)"}[a.gather]
 
     def barrier():
         if plan is not None:
@@ -464,46 +578,44 @@ def run_rank(a, rank, world, local):
 
     extras = {}
     if rank == 0 and world == 1 and not a.no_extras and not stub:
-        extras = extra_measurements(local)
+        plan.close()  # the extras build their own plans: give the arena back first
+        plan = None
+        extras = extra_measurements(local, cfg if strong else None, a.columns)
     if rank == 0:
         value = total_cols * a.steps / elapsed
         out = {
             "metric": "column-solves/sec (32 streams, 20 layers)", "value": value, "unit": "column-solves/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64",
+            "timed_seconds": elapsed,
             "data": "synthetic",
             "config": {"workload": "cfg4: synthetic Henyey-Greenstein, 20 layers, 32 streams, 32 Fourier modes, "
                                    "delta-M on, beam source, u at 21 interfaces x 3 azimuths + fluxes",
                        "columns_per_gpu_per_step": C, "global_columns_per_step": total_cols,
                        "columns_per_window": a.columns, "ranks_joined": joined,
+                       "total_columns": a.total_columns if strong else None,
                        "parallelism": f"column-sharded x{world}", "collective": collective,
                        "max_jacobi_sweeps": sweeps},
         }
         if stage is not None:
             fl = algorithmic_flops()
             nwin = max(1, -(-C // a.columns))
-            ms = {k: (v[0] / max(v[1], 1)) for k, v in stage.items()}  # per launch = per window of a.columns columns
-            ms["bc"] = ms["iface"] + ms["sweep"]
-            ms["eigen"] = ms["asm"] + ms["jacobi"] + ms["post"]  # one fused kernel at NQuad = 32 (timed in the jacobi slot)
-            dom = max(("eigen", "iface", "sweep"), key=lambda k: ms[k])
-            dom_flops = fl["bc"] if dom in ("iface", "sweep") else fl["asm"] + fl["jacobi"] + fl["post"]
-            dom_ms = ms["bc"] if dom in ("iface", "sweep") else ms["eigen"]
-            fused_bc = ms["iface"] < 0.05 * ms["sweep"]  # NQuad = 32: one fused kernel, timed in the sweep slot
-            kname = ("rtd_eigen_kernel<16>" if dom == "eigen" else
-                     "rtd_bc_mfma_kernel" if fused_bc else "rtd_iface_mfma_kernel+rtd_sweep_kernel<16>")
-            cols_per_launch = min(C, a.columns)
-            achieved = dom_flops * cols_per_launch / (dom_ms * 1e-3) / 1e12
-            traffic = measured_traffic(kname.split("+")[-1].split("<")[0]) if cols_per_launch == 2048 else None
-            out["roofline"] = {
-                "bound": "fp64-valu", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "kernel": kname,
-                "note": "FP64 path (SURVEY 8(d): compute-bound, not HBM-bound); the dominant kernel issues FP64 vector "
-                        "instructions (the matrix pipe has the same FP64 peak): peak = MI355X FP64 vector = matrix peak; "
-                        "achieved = algorithmic FLOPs of the kernel x columns per launch / its HIP-event duration (separate "
-                        "timing pass after the timed region); traffic = measured HBM bytes per launch of that kernel (profiles/)",
-                "kernel_ms_per_launch": ms, "columns_per_launch": cols_per_launch, "launches_per_step": nwin,
-                "whole_path_tflops": fl["total"] * value / world / 1e12,
-                "whole_path_frac": fl["total"] * value / world / 1e12 / FP64_PEAK_TFLOPS}
+            fused_bc = stage["iface"][0] < 0.05 * stage["sweep"][0]  # NQuad = 32: one fused kernel, timed in the sweep slot
+            names = {"eigen": "rtd_eigen_kernel<16, 2>",
+                     "bc": "rtd_bc_mfma_kernel<4>" if fused_bc else "rtd_iface_mfma_kernel+rtd_sweep_kernel<16>"}
+            cols_per_launch = C / nwin  # average over the windows of a step (the last one may be short)
+            roof, ms = roofline_of(stage, fl, cols_per_launch, names)
+            tkey = {"rtd_eigen_kernel<16, 2>": "rtd_eigen_kernel", "rtd_bc_mfma_kernel<4>": "rtd_bc_mfma_kernel"}.get(roof["kernel"], "rtd_sweep_kernel")
+            roof["traffic"] = measured_traffic(tkey) if a.columns == 2048 else None
+            roof["launches_per_step"] = nwin
+            roof["whole_path_tflops"] = fl["total"] * value / world / 1e12
+            roof["whole_path_frac"] = fl["total"] * value / world / 1e12 / FP64_PEAK_TFLOPS
+            roof["note"] = ("FP64 path (SURVEY 8(d): compute-bound, not HBM-bound); the dominant kernel issues FP64 vector "
+                            "instructions (the matrix pipe has the same FP64 peak): peak = MI355X FP64 vector = matrix peak; "
+                            "achieved = algorithmic FLOPs of the kernel x columns per launch / its HIP-event duration (separate "
+                            "timing pass after the timed region); traffic = HBM bytes per launch of that kernel at 2048 columns, "
+                            "from the committed rocprofv3 --pmc passes (profiles/), not measured in this run")
+            out["roofline"] = roof
         out["cpu_baseline"] = cpu
         out.update(extras)
         sys.stdout.flush()
@@ -522,8 +634,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--columns", type=int, default=2048,
                     help="columns per GPU per step (weak scaling); with --total-columns: columns per window")
-    ap.add_argument("--total-columns", type=int, default=0,
-                    help="strong scaling: this many columns in total, split over the GPUs (BASELINE: 100000)")
+    ap.add_argument("--total-columns", type=int, default=100_000,
+                    help="strong scaling (default, BASELINE's literal batch: 100000): this many columns in total per step, "
+                         "split over the GPUs; 0 = weak scaling, --columns per GPU per step")
+    ap.add_argument("--gather", choices=("all", "root", "none"), default="all",
+                    help="N > 1: results of a step to every rank (ncclAllGather), to rank 0 only (ncclSend/ncclRecv), or nowhere")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the parity, only_flux and end-to-end legs (profiling runs: every kernel launch is then the workload)")

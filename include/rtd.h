@@ -220,6 +220,11 @@ int rtd_comm_fetch_gathered(rtd_plan* plan, double* out);    /* host [nranks][3]
  * an event, so that the next rtd_plan_run overlaps them (its evaluation kernel, which overwrites the results, waits for
  * the gather).  rtd_plan_synchronize waits for both streams. */
 int rtd_comm_allgather_results(rtd_plan* plan);
+/* The same results gathered on ONE rank only ("if only rank 0 needs results"): the other ranks
+ * ncclSend their u and fluxes, `root` ncclRecv's them into the layout of rtd_comm_allgather_results (one group call on
+ * the communication stream, overlapped with the next run like the all-gather).  Every rank of the communicator calls
+ * it; rtd_comm_fetch_gathered_results is then valid on the root. */
+int rtd_comm_gather_results(rtd_plan* plan, int32_t root);
 /* host copies of the gathered results: u [nranks][C][NQuad][ntau][nphi] (= all nranks * C columns in rank order),
  * fluxes [nranks][3][C][ntau]; either may be NULL */
 int rtd_comm_fetch_gathered_results(rtd_plan* plan, double* u, double* fluxes);

@@ -1082,6 +1082,10 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -1100,6 +1104,10 @@ RcclApi* rccl() {
       api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");
       api.AllGather = (decltype(api.AllGather))dlsym(api.h, "ncclAllGather");
       api.AllReduce = (decltype(api.AllReduce))dlsym(api.h, "ncclAllReduce");
+      api.Send = (decltype(api.Send))dlsym(api.h, "ncclSend");
+      api.Recv = (decltype(api.Recv))dlsym(api.h, "ncclRecv");
+      api.GroupStart = (decltype(api.GroupStart))dlsym(api.h, "ncclGroupStart");
+      api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.h, "ncclGroupEnd");
       api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
       api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
       if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy || !api.GetErrorString) api.h = nullptr;
@@ -1174,6 +1182,50 @@ int rtd_comm_allgather_results(rtd_plan* p) {
   if (nr != ncclSuccess) return fail(RTD_ERR_HIP, std::string("ncclAllGather: ") + r->GetErrorString(nr));
   HIP_TRY(hipEventRecord(p->ev_gathered, p->comm_stream));
   p->gather_inflight = true;
+  return 0;
+}
+
+int rtd_comm_gather_results(rtd_plan* p, int32_t root) {
+  if (!p || !p->comm) return fail(RTD_ERR_STATE, "communicator not initialised");
+  if (p->ev_ntau < 1 || !p->solved) return fail(RTD_ERR_STATE, "no evaluation results to gather");
+  if (root < 0 || root >= p->comm_size) return fail(RTD_ERR_ARG, "root outside the communicator");
+  RcclApi* r = rccl();
+  if (!r->Send || !r->Recv || !r->GroupStart || !r->GroupEnd) return fail(RTD_ERR_HIP, "this RCCL has no ncclSend / ncclRecv");
+  HIP_TRY(hipSetDevice(p->device));
+  const int64_t C = p->d.C, Qr = 2 * p->d.N, nt = p->ev_ntau, np = p->ev_nphi;
+  const int64_t nu = np > 0 ? C * Qr * nt * np : 0, nfl = 3 * C * nt;
+  const bool is_root = p->comm_rank == root;
+  int rc;
+  if (is_root) {  // only the root holds the gathered arrays
+    if ((rc = grow(p, &p->gathered_u, &p->cap_gathered_u, std::max<int64_t>(nu, 1) * p->comm_size))) return rc;
+    if ((rc = grow(p, &p->gathered_fl, &p->cap_gathered_fl, nfl * p->comm_size))) return rc;
+  }
+  if (!p->comm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking));
+  if (!p->ev_results) HIP_TRY(hipEventCreateWithFlags(&p->ev_results, hipEventDisableTiming));
+  if (!p->ev_gathered) HIP_TRY(hipEventCreateWithFlags(&p->ev_gathered, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(p->ev_results, p->stream));
+  HIP_TRY(hipStreamWaitEvent(p->comm_stream, p->ev_results, 0));
+  hipStream_t cs = p->comm_stream;
+  ncclResult_t nr = r->GroupStart();
+  if (is_root) {
+    for (int q = 0; q < p->comm_size && nr == ncclSuccess; ++q) {
+      if (q == root) continue;
+      if (nu > 0) nr = r->Recv(p->gathered_u + q * nu, (size_t)nu, ncclDouble, q, p->comm, cs);
+      if (nr == ncclSuccess) nr = r->Recv(p->gathered_fl + q * nfl, (size_t)nfl, ncclDouble, q, p->comm, cs);
+    }
+  } else {
+    if (nu > 0) nr = r->Send(p->ev_u, (size_t)nu, ncclDouble, root, p->comm, cs);
+    if (nr == ncclSuccess) nr = r->Send(p->ev_fl, (size_t)nfl, ncclDouble, root, p->comm, cs);
+  }
+  ncclResult_t ne = r->GroupEnd();
+  if (nr == ncclSuccess) nr = ne;
+  if (nr != ncclSuccess) return fail(RTD_ERR_HIP, std::string("ncclSend / ncclRecv: ") + r->GetErrorString(nr));
+  if (is_root) {  // the root's own shard: a device copy on the same stream
+    if (nu > 0) HIP_TRY(hipMemcpyAsync(p->gathered_u + root * nu, p->ev_u, (size_t)nu * 8, hipMemcpyDeviceToDevice, cs));
+    HIP_TRY(hipMemcpyAsync(p->gathered_fl + root * nfl, p->ev_fl, (size_t)nfl * 8, hipMemcpyDeviceToDevice, cs));
+  }
+  HIP_TRY(hipEventRecord(p->ev_gathered, cs));
+  p->gather_inflight = true;  // the next run's evaluation kernel, which overwrites the results, waits for this
   return 0;
 }
 

@@ -257,6 +257,11 @@ class Plan:
         (overlaps the next run(); include/rtd.h: rtd_comm_allgather_results)."""
         _lib.check(self._lib.rtd_comm_allgather_results(self._h))
 
+    def gather_results(self, root=0):
+        """The results of the last run() gathered on rank `root` only (ncclSend / ncclRecv; include/rtd.h:
+        rtd_comm_gather_results); every rank calls it."""
+        _lib.check(self._lib.rtd_comm_gather_results(self._h, int(root)))
+
     def fetch_gathered_results(self, want_u=True):
         """-> (u [nranks * C, Q, ntau, nphi] or None, fluxes [nranks, 3, C, ntau]) of the last allgather_results()."""
         ntau, nphi = self._ev_shape

@@ -77,7 +77,7 @@ def _bench(args, **env_over):
 
 
 def test_bench_gpus_2_starts_two_ranks_that_both_contribute():
-    r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--columns", "3"])
+    r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--columns", "3", "--total-columns", "0"])
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                             # ONE JSON line, from rank 0
@@ -97,9 +97,18 @@ def test_bench_strong_scaling_splits_the_total():
 
 
 def test_bench_fails_loudly_when_a_rank_dies():
-    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--columns", "3"], RTD_BENCH_STUB_FAIL_RANK="1")
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--columns", "3", "--total-columns", "0"], RTD_BENCH_STUB_FAIL_RANK="1")
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]   # no result line from a broken run
+
+
+def test_bench_defaults_to_baselines_literal_batch():
+    """No flags: BASELINE's 10^5 columns, strong scaling -- 50 000 per rank at two ranks, windows of 2 048."""
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["config"]["global_columns_per_step"] == 100_000
+    assert out["config"]["columns_per_gpu_per_step"] == 50_000 and out["config"]["columns_per_window"] == 2048
 
 
 def test_bench_refuses_world_size_mismatch():
