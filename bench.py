@@ -10,7 +10,8 @@ them with no exchange during the solve; one RCCL all-gather of u and the fluxes 
 outputs of all ranks, on its own stream so that it overlaps the next step.
 
   strong scaling (default): --total-columns T (default 100000: BASELINE's literal batch) is split over the GPUs and
-                            solved in windows of --columns columns (2048): a step = the whole batch, 100000/N per GPU
+                            solved in windows of --columns columns (256; the eigen kernel of window w + 1 runs beside the boundary-
+                            condition kernel of window w on two streams): a step = the whole batch, 100000/N per GPU
   weak scaling            : --total-columns 0: every GPU solves --columns columns per step
   --gather all|root|none  : what happens to the results of a step when N > 1 -- ncclAllGather to every rank (default),
                             ncclSend/ncclRecv to rank 0 only, or nothing (compute scaling alone)
@@ -55,16 +56,18 @@ def algorithmic_flops(nlayers=L, nquad=NQUAD, nmodes=None, ntau=NTAU):
     return fl
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json, else
-    the round-1 file; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as read), or None."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
-        except Exception:
-            continue
-    return None
+def measured_traffic(kernel, columns_per_launch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this round (profiles/r03_pmc_traffic.json:
+    FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as read; separate passes), or None when that file was taken at
+    another window size than this run's."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+            rec = json.load(f)
+        if int(rec.get("columns_per_launch", 0)) != int(columns_per_launch):
+            return None
+        return rec["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -606,15 +609,17 @@ def run_rank(a, rank, world, local):
             cols_per_launch = C / nwin  # average over the windows of a step (the last one may be short)
             roof, ms = roofline_of(stage, fl, cols_per_launch, names)
             tkey = {"rtd_eigen_kernel<16, 2>": "rtd_eigen_kernel", "rtd_bc_mfma_kernel<4>": "rtd_bc_mfma_kernel"}.get(roof["kernel"], "rtd_sweep_kernel")
-            roof["traffic"] = measured_traffic(tkey) if a.columns == 2048 else None
+            roof["traffic"] = measured_traffic(tkey, a.columns)
             roof["launches_per_step"] = nwin
             roof["whole_path_tflops"] = fl["total"] * value / world / 1e12
             roof["whole_path_frac"] = fl["total"] * value / world / 1e12 / FP64_PEAK_TFLOPS
             roof["note"] = ("FP64 path (SURVEY 8(d): compute-bound, not HBM-bound); the dominant kernel issues FP64 vector "
                             "instructions (the matrix pipe has the same FP64 peak): peak = MI355X FP64 vector = matrix peak; "
                             "achieved = algorithmic FLOPs of the kernel x columns per launch / its HIP-event duration (separate "
-                            "timing pass after the timed region); traffic = HBM bytes per launch of that kernel at 2048 columns, "
-                            "from the committed rocprofv3 --pmc passes (profiles/), not measured in this run")
+                            "timing pass after the timed region, windows one after the other; the timed region itself runs the "
+                            "eigen kernel of window w + 1 beside the boundary-condition kernel of window w on two streams); "
+                            "traffic = HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes at this "
+                            "window size (profiles/r03_pmc_traffic.json), not measured in this run")
             out["roofline"] = roof
         out["cpu_baseline"] = cpu
         out.update(extras)
@@ -632,7 +637,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--columns", type=int, default=2048,
+    ap.add_argument("--columns", type=int, default=256,
                     help="columns per GPU per step (weak scaling); with --total-columns: columns per window")
     ap.add_argument("--total-columns", type=int, default=100_000,
                     help="strong scaling (default, BASELINE's literal batch: 100000): this many columns in total per step, "

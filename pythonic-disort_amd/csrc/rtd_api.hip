@@ -116,6 +116,16 @@ struct rtd_plan {
   // kk, Ek, Bv, dq, zneg, coef, Fws) cover one window of Cw columns: launch_windows runs window after window.
   RtdDev d{};
   int Cw = 0, nwin = 1;
+  // Window pipeline (plans of more than one window): the hand-off buffers of the eigen stage exist twice, and the tables +
+  // eigen kernel of window w + 1 run on eig_stream while the boundary-condition + evaluation kernels of window w run on
+  // `stream`.  The eigen kernel is bound by vector-instruction issue, the boundary-condition kernel by the latency of its
+  // dependent chains: wavefronts of both kinds resident on a SIMD fill each other's bubbles (profiles/r03_window_pipeline.json).
+  struct HandOff { double *Y0, *att, *Ym, *Am, *kk, *Bv, *dq, *zneg, *Ek; } slot1{};
+  bool pipelined = false;
+  bool fork_needed = true;               // inputs were (re)uploaded on `stream` since the last solve: the eigen stream must wait for them
+  bool bc_recorded[2] = {false, false};  // ev_bc[slot] has been recorded by some earlier window (possibly of an earlier run)
+  hipStream_t eig_stream = nullptr;
+  hipEvent_t ev_eig[2] = {nullptr, nullptr}, ev_bc[2] = {nullptr, nullptr}, ev_fork = nullptr;
   std::vector<void*> allocs;
   std::vector<size_t> alloc_bytes;
   int64_t bytes = 0;
@@ -215,8 +225,12 @@ void harvest(rtd_plan* p) {
 }
 
 // the plan's device view restricted to the columns [c0, c0 + cnt): input pointers advanced, intermediates shared
-RtdDev window_dev(const rtd_plan* p, int64_t c0, int cnt) {
+RtdDev window_dev(const rtd_plan* p, int64_t c0, int cnt, int slot = 0) {
   RtdDev w = p->d;
+  if (slot == 1) {
+    const rtd_plan::HandOff& h = p->slot1;
+    w.Y0 = h.Y0; w.att = h.att; w.Ym = h.Ym; w.Am = h.Am; w.kk = h.kk; w.Bv = h.Bv; w.dq = h.dq; w.zneg = h.zneg; w.Ek = h.Ek;
+  }
   const int64_t L = w.L, M = w.M, P = w.P, NP = w.NP, Ns = w.Ns, NB = w.NBDRF;
   w.C = cnt;
   w.omega += c0 * L; w.tau += c0 * L; w.taus0 += c0 * (L + 1); w.scale += c0 * L; w.wleg += c0 * L * P;
@@ -254,19 +268,41 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
   auto mark = [&](int k) {
     if (tm) (void)hipEventRecord(p->evt[k], s);
   };
+  // two-stream window pipeline: not while the stages are being timed one by one (the HIP-event pass wants them alone)
+  const bool pipe = p->pipelined && with_solve && !tm && p->nwin > 1;
+  hipStream_t se = pipe ? p->eig_stream : s;
   bool nt_tables_done = false;
+  if (pipe && p->fork_needed) {  // the eigen stream starts behind the uploads queued on the plan's stream; without new inputs
+    //                              it only waits, slot by slot, for the consumers of the previous run (ev_bc below), so that
+    //                              back-to-back runs keep the pipeline full
+    HIP_TRY(hipEventRecord(p->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(se, p->ev_fork, 0));
+    p->fork_needed = false;
+  }
   if (with_solve) {
-    hipError_t e = hipMemsetAsync(p->d.sweeps, 0, sizeof(int), s);
+    // (on the stream the first eigen kernel of this solve runs on: it raises bits and sweep counts behind these)
+    hipError_t e = hipMemsetAsync(p->d.sweeps, 0, sizeof(int), se);
     // the device status word too: bits raised by an earlier solve whose results were never fetched must not be
     // reported against this one (this solve's own evaluation, queued behind the memset, raises the tau bit again)
-    if (e == hipSuccess) e = hipMemsetAsync(p->d.status, 0, sizeof(int), s);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d.status, 0, sizeof(int), se);
     if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
     p->numeric_status = 0;  // a new solve starts clean
   }
+  auto eigen_stage = [&](int w) {  // tables + eigen kernel of window w into hand-off slot w & 1, on the eigen stream
+    const int64_t c0 = (int64_t)w * p->Cw;
+    const int cnt = (int)std::min<int64_t>(p->Cw, p->d.C - c0);
+    const int slot = w & 1;
+    RtdDev d = window_dev(p, c0, cnt, slot);
+    if (p->bc_recorded[slot]) (void)hipStreamWaitEvent(se, p->ev_bc[slot], 0);  // the slot's previous tenant has been consumed
+    rtd_launch_tables(d, se, w == 0);
+    rtd_launch_eig(d, se, 1);
+    (void)hipEventRecord(p->ev_eig[slot], se);
+  };
+  if (pipe) eigen_stage(0);
   for (int w = 0; w < p->nwin; ++w) {
     const int64_t c0 = (int64_t)w * p->Cw;
     const int cnt = (int)std::min<int64_t>(p->Cw, p->d.C - c0);
-    RtdDev d = window_dev(p, c0, cnt);
+    RtdDev d = window_dev(p, c0, cnt, pipe ? (w & 1) : 0);
     // run-path points at the layer interfaces: the boundary-condition kernel evaluates the Fourier modes there itself
     // (rtd_plan_evaluate -- the closures -- always takes the evaluation kernel, whatever the window count: a column's
     // closure values must not depend on the batch it was solved in)
@@ -276,7 +312,12 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
       (void)hipStreamSynchronize(s);
       harvest(p);
     }
-    if (with_solve) {
+    if (pipe) {
+      if (w + 1 < p->nwin) eigen_stage(w + 1);  // queued before this window's boundary-condition kernel: they run side by side
+      (void)hipStreamWaitEvent(s, p->ev_eig[w & 1], 0);
+      rtd_launch_bc(d, s, 0);
+      rtd_launch_bc(d, s, 1);
+    } else if (with_solve) {
       mark(0);
       rtd_launch_tables(d, s, w == 0);
       mark(1);
@@ -309,6 +350,10 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
       }
       mark(7);
     }
+    if (pipe) {  // slot w & 1 may be filled again
+      (void)hipEventRecord(p->ev_bc[w & 1], s);
+      p->bc_recorded[w & 1] = true;
+    }
     if (tm) {
       for (int k = 0; k < 6; ++k) p->pending[k] = with_solve;
       p->pending[6] = ev != nullptr;
@@ -320,6 +365,7 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
   }
   if (nt_tables_done) p->nt_tables_ready = true;  // every window's tables were made in this pass
   if (with_solve) p->solved = true;
+  if (with_solve && !pipe) p->fork_needed = true;  // slot 0 was filled on the plan's own stream
   return 0;
 }
 
@@ -382,11 +428,12 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   d.C = (int)C; d.L = (int)L; d.N = N; d.NP = (int)NP; d.P = (int)P; d.M = (int)M; d.Ns = (int)Ns;
   d.NBDRF = (int)NB; d.beam = dims->beam ? 1 : 0;
   d.flags = (getenv("RTD_BC_FORCE_PIVOT") ? 1 : 0) | (getenv("RTD_BC_FORCE_HANDOVER") ? 2 : 0);
+  if (const char* al = getenv("RTD_BC_ALIAS")) d.flags |= (atoi(al) & 3) << 2;  // timing experiment only (rtd_bc.hip)
   d.m0 = 0; d.mstep = 1; d.mtot = (int)M;
   d.l0 = 0; d.ln = (int)L;
   // window of columns whose intermediates are resident: bytes of intermediates per column
-  const int64_t per_col = 8 * (M * P + (L + 1) + 2 * M * L * NP * NP + 2 * M * L * NP + 2 * M * L * Q2 + L * Ns * Q2 + L * NP +
-                               M * (L - 1) * Q2 * Q2);
+  const int64_t handoff_col = 8 * (M * P + (L + 1) + 2 * M * L * NP * NP + 2 * M * L * NP + M * L * Q2 + L * Ns * Q2 + L * NP);
+  const int64_t per_col = 2 * handoff_col + 8 * (M * L * Q2 + M * (L - 1) * Q2 * Q2);  // (hand-off buffers twice: window pipeline)
   int64_t Cw = C;
   if (work_columns > 0) {
     Cw = std::min<int64_t>(C, work_columns);
@@ -400,6 +447,8 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   }
   p->Cw = (int)Cw;
   p->nwin = (int)((C + Cw - 1) / Cw);
+  p->pipelined = p->nwin > 1 && !getenv("RTD_NO_PIPELINE");
+  rtd_plan::HandOff& h1 = p->slot1;
   double *mu = nullptr, *w = nullptr, *invmu = nullptr, *S = nullptr, *T = nullptr, *omega = nullptr, *tau = nullptr,
          *taus0 = nullptr, *scale = nullptr, *wleg = nullptr, *mu0 = nullptr, *I0 = nullptr, *phi0 = nullptr,
          *rescale = nullptr, *bpos = nullptr, *bneg = nullptr, *spoly = nullptr, *bq = nullptr, *bq0 = nullptr;
@@ -430,6 +479,10 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
     A(d.dq, Cw * L * Ns * Q2) A(d.zneg, Cw * L * NP) A(d.coef, Cw * M * L * Q2)
     A(d.Fws, Cw * M * (L - 1) * Q2 * Q2) A(d.Ek, Cw * M * L * NP) A(d.need_split, Cw * M)
     A(d.sweeps, 1) A(d.status, 1) A(d.split_any, 1)
+    if (p->pipelined) {
+      A(h1.Y0, Cw * M * P) A(h1.att, Cw * (L + 1)) A(h1.Ym, Cw * M * L * NP * NP) A(h1.Am, Cw * M * L * NP * NP)
+      A(h1.kk, Cw * M * L * NP) A(h1.Bv, Cw * M * L * Q2) A(h1.dq, Cw * L * Ns * Q2) A(h1.zneg, Cw * L * NP) A(h1.Ek, Cw * M * L * NP)
+    }
 #undef A
     if (pass == 0) {
       void* q = nullptr;
@@ -452,6 +505,20 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   HIP_TRY(hipMemsetAsync(d.split_any, 0, sizeof(int), p->stream));
   HIP_TRY(hipMemsetAsync(d.Bv, 0, (size_t)(Cw * M * L * Q2) * 8, p->stream));
   if (Ns > 0) HIP_TRY(hipMemsetAsync(d.dq, 0, (size_t)(Cw * L * Ns * Q2) * 8, p->stream));
+  if (p->pipelined) {
+    HIP_TRY(hipMemsetAsync(h1.Bv, 0, (size_t)(Cw * M * L * Q2) * 8, p->stream));
+    if (Ns > 0) HIP_TRY(hipMemsetAsync(h1.dq, 0, (size_t)(Cw * L * Ns * Q2) * 8, p->stream));
+    {  // RTD_PIPE_PRIO=eig | bc: give that stage's stream the higher dispatch priority (experiments; default: equal)
+      const char* pr = getenv("RTD_PIPE_PRIO");
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent (numerically largest), hi = most urgent
+      if (pr && pr[0] == 'e') HIP_TRY(hipStreamCreateWithPriority(&p->eig_stream, hipStreamNonBlocking, hi));
+      else if (pr && pr[0] == 'b') HIP_TRY(hipStreamCreateWithPriority(&p->eig_stream, hipStreamNonBlocking, lo));
+      else HIP_TRY(hipStreamCreateWithFlags(&p->eig_stream, hipStreamNonBlocking));
+    }
+    for (hipEvent_t* e : {&p->ev_eig[0], &p->ev_eig[1], &p->ev_bc[0], &p->ev_bc[1], &p->ev_fork})
+      HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
   HIP_TRY(hipStreamSynchronize(p->stream));
   return 0;
 }
@@ -500,13 +567,16 @@ int rtd_plan_destroy(rtd_plan* p) {
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   if (p->comm_stream) (void)hipStreamSynchronize(p->comm_stream);
   if (p->copy_stream) (void)hipStreamSynchronize(p->copy_stream);
+  if (p->eig_stream) (void)hipStreamSynchronize(p->eig_stream);
   rtd_comm_destroy(p);
   for (size_t i = 0; i < p->allocs.size(); ++i)
     if (p->allocs[i]) pooled_free(p->allocs[i], p->alloc_bytes[i], p->device);
   for (auto& e : p->evt)
     if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : {p->ev_results, p->ev_gathered, p->ev_win[0], p->ev_win[1], p->ev_copied[0], p->ev_copied[1]})
+  for (hipEvent_t e : {p->ev_results, p->ev_gathered, p->ev_win[0], p->ev_win[1], p->ev_copied[0], p->ev_copied[1], p->ev_eig[0],
+                       p->ev_eig[1], p->ev_bc[0], p->ev_bc[1], p->ev_fork})
     if (e) (void)hipEventDestroy(e);
+  if (p->eig_stream) (void)hipStreamDestroy(p->eig_stream);
   for (char* st : p->stage)
     if (st) (void)hipHostFree(st);
   if (p->comm_stream) (void)hipStreamDestroy(p->comm_stream);
@@ -552,6 +622,7 @@ int rtd_plan_set_quadrature(rtd_plan* p, const double* mu_pos, const double* wei
   HIP_TRY(hipMemcpyAsync((void*)p->d.T, T.data(), nb, hipMemcpyHostToDevice, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   p->have_quad = true;
+  p->fork_needed = true;
   p->solved = false;
   return 0;
 }
@@ -636,6 +707,7 @@ int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* 
   p->h_tau.assign(tau, tau + C * L);
   p->ev_iface = false;  // stored evaluation points, if any, are no longer known to be this batch's interfaces
   p->have_cols = true;
+  p->fork_needed = true;
   p->solved = false;
   return 0;
 }
@@ -700,12 +772,14 @@ int rtd_plan_set_columns_raw(rtd_plan* p, const double* tau_arr, const double* o
   p->h_tau.assign(tau_arr, tau_arr + C * L);
   p->ev_iface = false;
   p->have_cols = true;
+  p->fork_needed = true;
   p->solved = false;
   return 0;
 }
 
 int rtd_plan_set_bdrf_samples(rtd_plan* p, int32_t nphi, const double* rho_qq, const double* rho_q0) {
   if (!p) return fail(RTD_ERR_ARG, "null plan");
+  p->fork_needed = true;  // works on the hand-off buffers from the plan's own stream
   if (!p->have_cols) return fail(RTD_ERR_STATE, "set_columns must precede set_bdrf_samples");
   const RtdDev& d = p->d;
   if (d.NBDRF <= 0) return fail(RTD_ERR_ARG, "the plan was created with nbdrf = 0");
@@ -943,6 +1017,7 @@ int rtd_plan_set_nt(rtd_plan* p, int32_t nleg_all, const double* weighted_leg_al
 
 int rtd_plan_get_tensors(rtd_plan* p, int32_t column, double* GC, double* K, double* B, double* Gim, double* G) {
   if (!p) return fail(RTD_ERR_ARG, "null plan");
+  p->fork_needed = true;  // works on the hand-off buffers from the plan's own stream
   if (!p->solved) return fail(RTD_ERR_STATE, "get_tensors before solve");
   if (column < 0 || column >= p->d.C) return fail(RTD_ERR_ARG, "column out of range");
   HIP_TRY(hipSetDevice(p->device));
@@ -1275,6 +1350,7 @@ int layer_segments(rtd_plan* p, LayerSeg seg[7]) {
 
 int rtd_plan_solve_layers(rtd_plan* p, int32_t first, int32_t count) {
   if (!p) return fail(RTD_ERR_ARG, "null plan");
+  p->fork_needed = true;  // works on the hand-off buffers from the plan's own stream
   if (!p->have_quad || !p->have_cols) return fail(RTD_ERR_STATE, "set_quadrature and set_columns must precede solve");
   if (p->nwin != 1) return fail(RTD_ERR_STATE, "layer shards need a plan of one window");
   if (first < 0 || count < 1 || first + count > p->d.L) return fail(RTD_ERR_ARG, "layer range outside the atmosphere");

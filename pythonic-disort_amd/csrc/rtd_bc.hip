@@ -810,14 +810,20 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
   const long cm = blockIdx.x;
   const int m = (int)(cm % d.M), c = (int)(cm / d.M);
   const int L = d.L, Lm1 = L - 1;
-  const double* Ym = d.Ym + cm * L * NN;
-  const double* Am = d.Am + cm * L * NN;
-  const double* kk = d.kk + cm * L * NP;
-  const double* Ek = d.Ek + cm * L * NP;
-  const double* Bv = d.Bv + cm * L * Q;
+  // Timing experiment (RTD_BC_ALIAS=1 | 2 | 3, results are garbage): the chains read the eigen stage's hand-off of only 32
+  // chains (bit 0: 2.6 MB, served by the L2s) or of 2 048 chains (bit 1: 168 MB, served by the Infinity Cache); with both
+  // bits the factors H, s, rho_b of the forward sweep are aliased to 32 chains as well.  What the kernel takes then is
+  // the floor that any scheme for cutting its HBM traffic can approach (profiles/r03_bc_traffic_floor.json).
+  const long cmr = (d.flags & 4) ? cm % 32 : (d.flags & 8) ? cm % 2048 : cm;
+  const long cmw = ((d.flags & 12) == 12) ? cm % 32 : cm;
+  const double* Ym = d.Ym + cmr * L * NN;
+  const double* Am = d.Am + cmr * L * NN;
+  const double* kk = d.kk + cmr * L * NP;
+  const double* Ek = d.Ek + cmr * L * NP;
+  const double* Bv = d.Bv + cmr * L * Q;
   const double* ts0 = d.taus0 + (long)c * (L + 1);
   const double* dq = d.dq + (long)c * L * d.Ns * Q;
-  double* wsb = d.Fws + cm * Lm1 * Ws<NP>::SLOT;
+  double* wsb = d.Fws + cmw * Lm1 * Ws<NP>::SLOT;
   double* coef = d.coef + cm * L * Q;
   const int mg = d.m0 + d.mstep * m;  // the Fourier mode this local index stands for (mode shards)
   const bool iso = d.Ns > 0 && mg == 0;

@@ -89,10 +89,6 @@ __device__ __forceinline__ double approx_rcp(double x) {
 #define RTD_CHOL_FMAC_DPP 1  /* Cholesky trailing updates as ONE v_fmac_f64_dpp (row_newbcast) per element, NP = 16 */
 #endif
 
-#ifndef RTD_EIG_SEQ_ASSEMBLY
-#define RTD_EIG_SEQ_ASSEMBLY 0  /* 1: the one-parity-at-a-time assembly (always used at NP = 32) for every stream count */
-#endif
-
 #ifndef RTD_EIGEN32_WAVES
 #define RTD_EIGEN32_WAVES 2  /* waves per SIMD of the 64-stream eigen kernel (256 VGPRs, 23 spilled dwords; 1: 278 VGPRs) */
 #endif
@@ -218,21 +214,30 @@ __device__ __forceinline__ double bcast_lane(double v) {
 // symmetric so that A^(K)[j][K] is available in the lane's own registers, and the scaling of a finished column by
 // 1/sqrt(pivot) is deferred to the end: a step is one broadcast and one FMA per element,
 //   col_j[i] -= A^(K)[i][K] * A^(K)[j][K] / A^(K)[K][K]   for j > K (factor 0 for the finished columns j <= K).
-template <int NP, int K, int I>
+template <int NP, int K, int I, bool ORDERED = false>
 struct CholRowDpp {  // col[i] -= bcast_K(col[i]) * f for i = I .. NP - 1, one v_fmac_f64_dpp each
   static __device__ __forceinline__ void run(double (&col)[NP], const double f) {
     // The compiler's hazard recogniser does not see a VALU write inside inline asm, and the next step broadcasts
     // col[K + 1] (its pivot) with a DPP move of its own: the two wait states a DPP read needs after a VALU write of the
     // same VGPR are spent here, behind the rows that DPP reads next (the first and the last of the step).
-    if constexpr (I == K + 1 || I == NP - 1)
-      asm("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(col[I]) : "v"(f), "n"(K));
-    else
-      asm("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(col[I]) : "v"(f), "n"(K));
-    CholRowDpp<NP, K, I + 1>::run(col, f);
+    // ORDERED (NP = 32): the statements keep their program order (asm volatile) -- left free, the scheduler put the updates
+    // of one element by consecutive steps next to each other (the ISA scan of build.py caught it).
+    if constexpr (ORDERED) {
+      if constexpr (I == K + 1 || I == NP - 1)
+        asm volatile("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(col[I]) : "v"(f), "n"(K % 16));
+      else
+        asm volatile("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(col[I]) : "v"(f), "n"(K % 16));
+    } else {
+      if constexpr (I == K + 1 || I == NP - 1)
+        asm("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(col[I]) : "v"(f), "n"(K % 16));
+      else
+        asm("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(col[I]) : "v"(f), "n"(K % 16));
+    }
+    CholRowDpp<NP, K, I + 1, ORDERED>::run(col, f);
   }
 };
-template <int NP, int K>
-struct CholRowDpp<NP, K, NP> {
+template <int NP, int K, bool ORDERED>
+struct CholRowDpp<NP, K, NP, ORDERED> {
   static __device__ __forceinline__ void run(double (&)[NP], const double) {}
 };
 
@@ -258,6 +263,97 @@ template <int NP>
 struct CholStep<NP, NP> {
   static __device__ __forceinline__ void run(double (&)[NP], double&, const int) {}
 };
+// acc[I] += bcast_I(y0) * coef and acc[16 + I] += bcast_I(y1) * coef for I = 0..15: lane I of the caller's DPP row supplies the
+// multiplier (row_newbcast), one v_fmac_f64_dpp per term
+template <int I>
+struct RowFmacDpp {
+  static __device__ __forceinline__ void run(double (&acc)[32], const double y0, const double y1, const double coef) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc[I]) : "v"(y0), "v"(coef), "n"(I));
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc[16 + I]) : "v"(y1), "v"(coef), "n"(I));
+    if constexpr (I + 1 < 16) RowFmacDpp<I + 1>::run(acc, y0, y1, coef);
+  }
+};
+
+// ---- NP = 32: blocked (2 x 2 blocks of 16) in the same one-column-per-lane layout.  A problem is two DPP rows of 16 lanes:
+// row 0 holds the columns 0..15, row 1 the columns 16..31, every lane all 32 rows of its column.  The pivot column of a
+// step lives in ONE of the two rows, and v_fmac_f64_dpp row_newbcast reaches exactly the lanes of that row:
+//   panel A (steps 0..15):  the row-0 lanes eliminate inside their 16 columns, all 32 rows (A11 and A21);
+//   block update:           A22 -= sum_K X[.][K] X[.][K]^T / a_KK with X = the finished A21 (16 x 16) -- the only place where
+//                           the two rows of lanes exchange data: X goes through LDS once into the operand layout of
+//                           v_mfma_f64_16x16x4_f64 (4 MFMA per problem) and the product comes back once;
+//   panel B (steps 16..31): the row-1 lanes eliminate inside A22.
+// The unblocked form took every multiplier of every step across the two rows with ds_bpermute: 1 056 LDS-crossbar
+// instructions per factorisation, 32 dependent LDS round trips (26-50 k cycles per factorisation at two wavefronts per
+// SIMD, s_memtime stamps); this form has four.
+template <int K>
+__device__ __forceinline__ double row_bcast16(double v) {  // lane K of the caller's own 16-lane DPP row
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int K, int KEND>
+struct CholPanel32 {  // steps K .. KEND - 1 with their pivot columns in DPP row PR = K / 16 of every problem
+  static __device__ __forceinline__ void run(double (&col)[32], double& diag, double& dmine, const int row, const int jj) {
+    constexpr int PR = K / 16, KL = K % 16;
+    const double akk = row_bcast16<KL>(col[K]);
+    const double r = fast_rcp(akk);
+    const bool mine = row == PR;
+    const double f = (mine && jj > KL) ? col[K] * r : 0.0;
+    diag = (mine && jj == KL) ? akk : diag;
+    dmine = (mine && jj == KL) ? r : dmine;
+    CholRowDpp<32, K, K + 1, true>::run(col, f);
+    if constexpr (K + 1 < KEND) CholPanel32<K + 1, KEND>::run(col, diag, dmine, row, jj);
+  }
+};
+// scratch: 1 024 doubles of LDS (the staging area of the assembly, free while the factorisation runs)
+__device__ __forceinline__ double cholesky_columns32(double (&col)[32], const int j, double* scratch) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x, g = lane >> 5, row = (lane >> 4) & 1, jj = lane & 15;
+  double diag = 1.0, dmine = 0.0;
+  CholPanel32<0, 16>::run(col, diag, dmine, row, jj);
+  // X[i][K] = col[16 + i] of lane (row 0, K); scaled copy X d_K next to it
+  double* sX = scratch;         // [2 problems][16 K][16 i]
+  double* sXd = scratch + 512;  // the same times 1 / a_KK
+  __syncthreads();
+  if (row == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      sX[(g * 16 + jj) * 16 + i] = col[16 + i];
+      sXd[(g * 16 + jj) * 16 + i] = col[16 + i] * dmine;
+    }
+  }
+  __syncthreads();
+  v4d acc[2];
+#pragma unroll
+  for (int pg = 0; pg < 2; ++pg) {
+    acc[pg] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {  // lane (k, i): A[i][k] = X[i][4 t + k] d, B[k][j] = X[j][4 t + k]: the same element
+      const int e = (pg * 16 + 4 * t + (lane >> 4)) * 16 + (lane & 15);
+      acc[pg] = __builtin_amdgcn_mfma_f64_16x16x4f64(sXd[e], sX[e], acc[pg], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  // the products back: lane (k, c) holds S[4 q + k][c]; the row-1 lane of column c wants all 16 rows
+  double* sS = scratch;  // [2 problems][16 rows][16 columns]
+#pragma unroll
+  for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sS[(pg * 16 + 4 * q + (lane >> 4)) * 16 + (lane & 15)] = acc[pg][q];
+  __syncthreads();
+  if (row == 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) col[16 + i] -= sS[(g * 16 + i) * 16 + jj];
+  }
+  CholPanel32<16, 32>::run(col, diag, dmine, row, jj);
+  const double rinv = fast_rsqrt(diag);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) col[i] = (i >= j) ? col[i] * rinv : 0.0;
+  __syncthreads();  // the scratch area goes back to its owner
+  return rinv;
+}
+
 template <int NP>
 __device__ __forceinline__ double cholesky_columns(double (&col)[NP], const int j) {
   double diag = 1.0;
@@ -429,6 +525,19 @@ struct PairStep<NP, NP - 1> {  // the last step of a sweep is step NP - 2
 // packed lower triangle: element (r, c), r >= c
 __host__ __device__ constexpr int tri(int r, int c) { return r * (r + 1) / 2 + c; }
 
+// Diagnostic build (-DRTD_EIG_STAMPS, never shipped): lane 0 of a few wavefronts records s_memtime at the phase boundaries of
+// the fused eigen kernel and prints the differences (cycles) with its sweep count; tools/eig_phase_cycles.py formats them.
+#ifdef RTD_EIG_STAMPS
+#define RTD_ESTAMP(k)                                      \
+  {                                                        \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    est[k] = (long long)__builtin_amdgcn_s_memtime();      \
+    __builtin_amdgcn_sched_barrier(0);                     \
+  }
+#else
+#define RTD_ESTAMP(k)
+#endif
+
 template <int NP, int JV>  // JV: 2 = Jacobi sweeps in the pair layout (default), 1 = one column per lane (RTD_EIG_V1),
 //                             3 = 2 with the assembly of Pm, Qm on the matrix cores (RTD_EIG_MFMA, NP = 16)
 __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES)) void rtd_eigen_kernel(RtdDev d) {
@@ -442,10 +551,25 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
   __shared__ double sL[GPW][LSIZE];
   auto lix = [](const int r, const int c) { return PACKED ? tri(r, c) : r * LD + c; };  // element (r, c) of L, r >= c
   __shared__ double sV[GPW][4][NP];
+  // NP = 32: the table rows one parity of the assembly needs ((P - m) / 2 rows of Ybar^m at the quadrature nodes, shared by
+  // the wavefront's two problems), their coefficients and the beam factors, staged by coalesced loads that are all in
+  // flight together.  Read as scalar loads inside the loop (the form that suits 3 wavefronts per SIMD at NP <= 16) every
+  // row cost a full memory latency at 2 wavefronts per SIMD: the two assembly loops were 35 % of the kernel's time at
+  // low Fourier modes (s_memtime stamps, -DRTD_EIG_STAMPS, profiles/r03_eigen32_phases.txt).
+  constexpr int TROWS = NP == 32 ? 32 : 1;
+  __shared__ double sTab[NP == 32 ? TROWS * NP : 1];
+  __shared__ double sCoef[NP == 32 ? GPW * TROWS : 1];
+  __shared__ double sY0[NP == 32 ? TROWS : 1];
   double w[NP];  // column j of F = L^T R, then of k Z
   // beam source terms of this lane's stream, sum_l (omega w_l Y_l[j]) Ybar_l(-mu0) over the even / odd l - m: they fall out of
   // the assembly loop for one FMA per term (the second pass over the moments that stage 2 used to make is gone)
   double xe_sum = 0.0, xo_sum = 0.0;
+#ifdef RTD_EIG_STAMPS
+  long long est[12];
+  for (int k = 0; k < 12; ++k) est[k] = 0;
+  int est_sweeps = 0;
+#endif
+  RTD_ESTAMP(0);
   {  // ---- stage 1: assembly, Cholesky factors, F, Jacobi.  Only w, the two sums (and the LDS tile of L) leave this block.
   const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
   const ProbId id = locate<NP>(d);
@@ -555,40 +679,77 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
       for (int r = i; r < NP; ++r) a += L_[lix(r, i)] * qcol[r];
       w[i] = a;
     }
-  } else if constexpr (RTD_EIG_SEQ_ASSEMBLY || NP == 32) {
+  } else if constexpr (NP == 32) {
     // One parity at a time: Pm is assembled, factorised and parked in LDS before Qm is touched, so that the accumulator
     // and the Cholesky column of only ONE of the two matrices are alive at once (NP = 32: 128 VGPRs less).
-    double cmax = 0.0;
-    for (int ell = id.mg; ell < P; ++ell) cmax = fmax(cmax, fabs(0.5 * om * wl[ell]));
+    // this lane's two moments of the layer (terms id.mg + 2 j and id.mg + 2 j + 1): one load each, then LDS
+    const int le = id.mg + 2 * j, lo = le + 1;
+    const double wle = le < P ? wl[le] : 0.0, wlo = lo < P ? wl[lo] : 0.0;
+    const double* Y0b = d.Y0 + ((long)c * d.M + m) * P;  // Ybar_l^m(-mu0): read only with a beam
+    const double y0e = (d.beam && le < P) ? Y0b[le] : 0.0, y0o = (d.beam && lo < P) ? Y0b[lo] : 0.0;
+    double cmax = fmax(fabs(0.5 * om * wle), fabs(0.5 * om * wlo));
+    cmax = fmax(cmax, xor_lane<1>(cmax));
+    cmax = fmax(cmax, xor_lane<2>(cmax));
+    cmax = fmax(cmax, xor_lane<4>(cmax));
+    cmax = fmax(cmax, xor_lane<8>(cmax));
+    cmax = fmax(cmax, xor_lane<16>(cmax));
     // "shortcut" of the reference when multiple scattering is insignificant (:119, :162-168): the layer
     // is treated as non-scattering; the general path then gives G = [[0,D],[D,0]], k = 1/mu, B = 0.
     const double live = (cmax > 1e-8) ? 1.0 : 0.0;
-    const double* Y0b = d.Y0 + ((long)c * d.M + m) * P;  // Ybar_l^m(-mu0): wave-uniform; read only with a beam
-    auto assemble = [&](const int first, double (&col)[NP], double& beam_sum) {  // M^-1 - S (2 sum_{l = first, first + 2, ...} c_l Y_l Y_l^T) S
+    auto assemble = [&](const int first, const double wmine, const double y0mine, double (&col)[NP], double& beam_sum) {
+      // M^-1 - S (2 sum_{l = first, first + 2, ...} c_l Y_l Y_l^T) S
+      const int nrows = (P - first + 1) / 2;  // rows first, first + 2, ... < P (P <= 2 NP = 64: at most TROWS of them)
+      __syncthreads();  // the previous parity's readers are done with the staging area
+      {
+        constexpr int TRIPS = TROWS * (NP / 2) / 64;  // 16 bytes per lane and trip, rows back to back; every load issued
+        double2 v[TRIPS];                             // before the first is stored (indices clamped, not predicated)
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+          const int idx = t * 64 + (int)threadIdx.x, row = idx / (NP / 2), q = idx % (NP / 2);
+          const int ell = first + 2 * row < P ? first + 2 * row : P - 1;
+          v[t] = *reinterpret_cast<const double2*>(Ym + (long)ell * NP + 2 * q);
+        }
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+          const int idx = t * 64 + (int)threadIdx.x;
+          if (idx < nrows * (NP / 2)) *reinterpret_cast<double2*>(&sTab[idx * 2]) = v[t];
+        }
+      }
+      sCoef[grp * TROWS + j] = om * wmine;
+      if (grp == 0) sY0[j] = y0mine;
+      __syncthreads();
+      // acc[i] += coef Yr[i] with the table row spread over the lanes of every DPP row (lane jj holds Yr[jj] and Yr[16 + jj]):
+      // the multiplier reaches the FMA as a DPP row broadcast -- one v_fmac_f64_dpp per term and two 8-byte LDS reads per
+      // row.  (Broadcast LDS reads of the row, 16 x ds_read_b128 per wavefront and row, made the loop LDS-bandwidth-bound:
+      // 8 wavefronts per CU x 1 KiB per read against 128 B per clock.)
       double acc[NP];
 #pragma unroll
       for (int i = 0; i < NP; ++i) acc[i] = 0.0;
-      for (int ell = first; ell < P; ell += 2) {
-        const double* Yr = Ym + (long)ell * NP;
-        const double coef = om * wl[ell] * Yr[j];
-        if (d.beam) beam_sum = fma(live * coef, Y0b[ell], beam_sum);
-#pragma unroll
-        for (int i = 0; i < NP; ++i) acc[i] += coef * Yr[i];
+      const int jj = j & 15;
+      for (int k = 0; k < nrows; ++k) {
+        const double y0 = sTab[k * NP + jj], y1 = sTab[k * NP + 16 + jj];
+        const double coef = sCoef[grp * TROWS + k] * (j < 16 ? y0 : y1);
+        beam_sum = fma(live * coef, sY0[k], beam_sum);
+        RowFmacDpp<0>::run(acc, y0, y1, coef);
       }
 #pragma unroll
       for (int i = 0; i < NP; ++i) col[i] = (i == j ? invmu_j : 0.0) - d.S[i] * (live * acc[i]) * S_j;
     };
     {
       double pcol[NP];
-      assemble(id.mg, pcol, xe_sum);            // Pm = M^-1 - S Ae S  (D+/D- split by parity of l - m, :123-125)
-      dinv[j] = cholesky_columns<NP>(pcol, j);  // Pm = L L^T
+      assemble(id.mg, wle, y0e, pcol, xe_sum);  // Pm = M^-1 - S Ae S  (D+/D- split by parity of l - m, :123-125)
+      RTD_ESTAMP(1);
+      dinv[j] = cholesky_columns32(pcol, j, sTab);  // Pm = L L^T
+      RTD_ESTAMP(2);
 #pragma unroll
       for (int i = 0; i < NP; ++i)
         if (!PACKED || j <= i) L_[lix(i, 0) + j] = pcol[i];
     }
     double qcol[NP];
-    assemble(id.mg + 1, qcol, xo_sum);  // Qm = M^-1 - S Ao S
-    cholesky_columns<NP>(qcol, j);   // Qm = R R^T
+    assemble(id.mg + 1, wlo, y0o, qcol, xo_sum);  // Qm = M^-1 - S Ao S
+    RTD_ESTAMP(3);
+    cholesky_columns32(qcol, j, sTab);  // Qm = R R^T
+    RTD_ESTAMP(4);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -639,8 +800,12 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
       pcol[i] = (i == j ? invmu_j : 0.0) - Si * acc_e[i] * S_j;  // Pm = M^-1 - S Ae S
       qcol[i] = (i == j ? invmu_j : 0.0) - Si * acc_o[i] * S_j;  // Qm = M^-1 - S Ao S
     }
+    RTD_ESTAMP(1);
     dinv[j] = cholesky_columns<NP>(pcol, j);  // Pm = L L^T
+    RTD_ESTAMP(2);
+    RTD_ESTAMP(3);
     cholesky_columns<NP>(qcol, j);  // Qm = R R^T
+    RTD_ESTAMP(4);
 #pragma unroll
     for (int i = 0; i < NP; ++i)
         if (!PACKED || j <= i) L_[lix(i, 0) + j] = pcol[i];
@@ -654,6 +819,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
     }
   }
   }
+  RTD_ESTAMP(5);
   // one-sided Jacobi on the columns of F
   int nsweep = 0;
   bool converged = false;
@@ -714,6 +880,10 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
     for (int i = 0; i < NP; ++i) w[i] = __shfl(w[i], src, NP);
     __syncthreads();
   }
+  RTD_ESTAMP(6);
+#ifdef RTD_EIG_STAMPS
+  est_sweeps = nsweep;
+#endif
   if (threadIdx.x == 0 && nsweep > *(volatile int*)d.sweeps) atomicMax(d.sweeps, nsweep);
   if (!converged && threadIdx.x == 0) atomicOr(d.status, RTD_ST_JACOBI);  // NaN input (failed Cholesky) also ends here
   }
@@ -759,6 +929,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
     ya[i] = a * dinv[i];
     RTD_FENCE();
   }
+  RTD_ESTAMP(7);
   if (valid) {
     double* Ym = d.Ym + base * NP * NP;
 #pragma unroll
@@ -833,6 +1004,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
     }
   }
   __syncthreads();
+  RTD_ESTAMP(8);
   // A = L Z after the beam stage: its 2 NP registers are not live while that stage runs
   double aa[NP];
 #pragma unroll
@@ -893,6 +1065,13 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
     }
     __syncthreads();
   }
+  RTD_ESTAMP(9);
+#ifdef RTD_EIG_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x % 4099 == 7)
+    printf("EIGSTAMP np %d m %d sweeps %d : asmP %lld cholP %lld asmQ %lld cholQ %lld F %lld jacobi %lld order+Y %lld beam %lld A+thermal %lld total %lld\n",
+           NP, id.mg, est_sweeps, est[1] - est[0], est[2] - est[1], est[3] - est[2], est[4] - est[3], est[5] - est[4], est[6] - est[5],
+           est[7] - est[6], est[8] - est[7], est[9] - est[8], est[9] - est[0]);
+#endif
 
 }
 

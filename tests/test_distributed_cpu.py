@@ -103,12 +103,12 @@ def test_bench_fails_loudly_when_a_rank_dies():
 
 
 def test_bench_defaults_to_baselines_literal_batch():
-    """No flags: BASELINE's 10^5 columns, strong scaling -- 50 000 per rank at two ranks, windows of 2 048."""
+    """No flags: BASELINE's 10^5 columns, strong scaling -- 50 000 per rank at two ranks, windows of 256."""
     r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["scaling"] == "strong" and out["config"]["global_columns_per_step"] == 100_000
-    assert out["config"]["columns_per_gpu_per_step"] == 50_000 and out["config"]["columns_per_window"] == 2048
+    assert out["config"]["columns_per_gpu_per_step"] == 50_000 and out["config"]["columns_per_window"] == 256
 
 
 def test_bench_refuses_world_size_mismatch():

@@ -32,7 +32,7 @@ def test_bench_force_dist_runs_the_rccl_path_with_one_rank(gather, prefix):
     assert out["n_gpus"] == 1 and out["config"]["ranks_joined"] == 1
     assert out["config"]["collective"].startswith(prefix), out["config"]["collective"]
     assert out["scaling"] == "strong" and out["config"]["global_columns_per_step"] == 6000
-    assert out["config"]["columns_per_window"] == 2048 and out["roofline"]["launches_per_step"] == 3
+    assert out["config"]["columns_per_window"] == 256 and out["roofline"]["launches_per_step"] == 24
     assert out["value"] > 1e4 and 0.05 < out["roofline"]["frac"] < 1.0
 
 

@@ -100,9 +100,23 @@ def solve_mode(args):
     ts = [mpf(x) for x in p["tau_s0"]]
     one, zero = mp.mpf(1), mp.mpf(0)
 
-    def leg(x):  # sqrt((l-m)!/(l+m)!) P_l^m(x): the reference's poch factor (:96) split over both factors of each product
-        return [zero if ell < m else mp.legenp(ell, m, x, type=2) * mp.sqrt(mp.factorial(ell - m) / mp.factorial(ell + m))
-                for ell in range(P)]
+    def leg(x):
+        # sqrt((l-m)!/(l+m)!) P_l^m(x) up to the common sign (-1)^m, which cancels in every product: the reference's poch
+        # factor (:96) split over both factors.  Normalised three-term recurrence in 40-digit arithmetic (mpmath's legenp
+        # sums a hypergeometric series that does not converge at degree ~60, order ~40).
+        out = [zero] * P
+        if m >= P:
+            return out
+        v = one
+        for jj in range(1, m + 1):
+            v = v * mp.sqrt(mp.mpf(2 * jj - 1) / (2 * jj)) * mp.sqrt(1 - x * x)
+        out[m] = v
+        if m + 1 < P:
+            out[m + 1] = mp.sqrt(2 * m + 1) * x * v
+        for ell in range(m + 1, P - 1):
+            out[ell + 1] = ((2 * ell + 1) * x * out[ell] - mp.sqrt(mp.mpf((ell + m) * (ell - m))) * out[ell - 1]) \
+                / mp.sqrt(mp.mpf((ell + 1 - m) * (ell + 1 + m)))
+        return out
     Y = [leg(x) for x in mu]
     Y0 = leg(-mu0) if beam else None
     Gs, Ks, Bs, Zs = [], [], [], []
