@@ -3,13 +3,16 @@
 bench.py reads for roofline.traffic: HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (both counters are in
 KiB; FETCH_SIZE counts half of the bytes of coalesced streaming reads on gfx950: MI355X_MICROARCH.md, HBM section).
 
-Usage: python tools/pmc_to_json.py out.json "description" pass1.txt pass2.txt ..."""
+Usage: python tools/pmc_to_json.py out.json "description" [--columns-per-launch N] pass1.txt pass2.txt ..."""
 import ast
 import json
 import re
 import sys
 
 out, desc, files = sys.argv[1], sys.argv[2], sys.argv[3:]
+cols = None
+if files and files[0] == "--columns-per-launch":
+    cols, files = int(files[1]), files[2:]
 kern = {}
 for path in files:
     for line in open(path):
@@ -26,5 +29,5 @@ for name, k in kern.items():
 json.dump({"source": desc,
            "correction": "FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE doubled (gfx950 reports half of the bytes of "
                          "coalesced streaming reads); separate --pmc passes for FETCH_SIZE and WRITE_SIZE",
-           "kernels": kern, "total_hbm_bytes_per_step": total}, open(out, "w"), indent=1, sort_keys=True)
+           "kernels": kern, "total_hbm_bytes_per_step": total, "columns_per_launch": cols}, open(out, "w"), indent=1, sort_keys=True)
 print(out, "total GB per step: %.2f" % (total / 1e9))
