@@ -238,7 +238,7 @@ def config_leg(name, golden, maker, kwargs, columns, window, device, passes):
     fl = algorithmic_flops(nl, nq, nq, nl + 1)
     np_ = 4 if nq <= 8 else 8 if nq <= 16 else 16 if nq <= 32 else 32
     names = {"eigen": f"rtd_eigen_kernel<{np_}, 2>",
-             "bc": "rtd_bc_tile_kernel<2>" if np_ == 32 else "rtd_bc_mfma_kernel<4>" if np_ == 16 else f"rtd_iface_kernel<{np_}> + rtd_sweep_kernel<{np_}>"}
+             "bc": "rtd_bc_tile_kernel<2>" if np_ == 32 else "rtd_bc_mfma_kernel" if np_ == 16 else f"rtd_iface_kernel<{np_}> + rtd_sweep_kernel<{np_}>"}
     roof, ms = roofline_of(stage, fl, columns / nwin, names)
     roof["whole_path_tflops"] = fl["total"] * rate / 1e12
     roof["whole_path_frac"] = roof["whole_path_tflops"] / FP64_PEAK_TFLOPS
@@ -605,10 +605,10 @@ def run_rank(a, rank, world, local):
             nwin = max(1, -(-C // a.columns))
             fused_bc = stage["iface"][0] < 0.05 * stage["sweep"][0]  # NQuad = 32: one fused kernel, timed in the sweep slot
             names = {"eigen": "rtd_eigen_kernel<16, 2>",
-                     "bc": "rtd_bc_mfma_kernel<4>" if fused_bc else "rtd_iface_mfma_kernel+rtd_sweep_kernel<16>"}
+                     "bc": "rtd_bc_mfma_kernel" if fused_bc else "rtd_bc_tile_kernel<1>"}
             cols_per_launch = C / nwin  # average over the windows of a step (the last one may be short)
             roof, ms = roofline_of(stage, fl, cols_per_launch, names)
-            tkey = {"rtd_eigen_kernel<16, 2>": "rtd_eigen_kernel", "rtd_bc_mfma_kernel<4>": "rtd_bc_mfma_kernel"}.get(roof["kernel"], "rtd_sweep_kernel")
+            tkey = {"rtd_eigen_kernel<16, 2>": "rtd_eigen_kernel", "rtd_bc_mfma_kernel": "rtd_bc_mfma_kernel"}.get(roof["kernel"], "rtd_sweep_kernel")
             roof["traffic"] = measured_traffic(tkey, a.columns)
             roof["launches_per_step"] = nwin
             roof["whole_path_tflops"] = fl["total"] * value / world / 1e12

@@ -18,11 +18,13 @@
 //   banded matrix to <= 5e-13 on every golden case and on thick/thin/near-conservative stress cases
 //   (tools/proto_device_algo.py: check_structured).
 //
-// Two implementations.  16 < NQuad <= 32: rtd_bc_mfma_kernel, one wavefront per (column, mode), everything in the
-// matrix-core register layout (see its comment below).  Other stream counts (or RTD_BC_SPLIT=1): rtd_iface_kernel (all
-// (column, mode, interface) in parallel: Wp, Wq, rho through HBM) and rtd_sweep_kernel (per (column, mode): forward carry
-// recursion, bottom boundary, backward sweep); NP lanes per problem, 64/NP problems per wavefront, lane i owns row i
-// of the carry system.
+// Three implementations.  16 < NQuad <= 32: rtd_bc_mfma_kernel, one wavefront per (column, mode), everything in the
+// matrix-core register layout (see its comment below).  32 < NQuad <= 64: rtd_bc_tile_kernel<2>, the same on 2 x 2 tiles.
+// NQuad <= 16 (and the tiled kernel's last resort for a singular carry block): rtd_iface_kernel (all (column, mode,
+// interface) in parallel: Wp, Wq, rho through HBM) and rtd_sweep_kernel (per (column, mode): forward carry recursion,
+// bottom boundary, backward sweep); NP lanes per problem, 64/NP problems per wavefront, lane i owns row i of the carry
+// system.  (An MFMA form of the interface kernel at NP = 16 and a three-wavefront form of rtd_bc_mfma_kernel lost every
+// A/B of round 2 and were removed in round 3.)
 #include <cstdlib>
 #include <type_traits>
 
@@ -222,112 +224,8 @@ __global__ __launch_bounds__(64) void rtd_iface_kernel(RtdDev d, const int* only
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Interface kernel, NP = 16, on the matrix cores: one wavefront per IFACE_CHUNK consecutive interfaces of one
-// (c, m).  The two 16x16x16 FP64 products  A_l^T Y_{l+1}  and  Y_l^T A_{l+1}  are 4 + 4 v_mfma_f64_16x16x4_f64;
-// operands are loaded straight from HBM in the MFMA A/B layouts (lane: row/column lane & 15, k = lane >> 4 --
-// 128-byte coalesced segments) and layer l+1's operands are reused as layer l's for the next interface; results
-// are stored from the C/D layout (column lane & 15, rows (lane >> 4) + 4 r).  No LDS, no barriers.
-// ------------------------------------------------------------------------------------------------
 typedef double v4f64 __attribute__((ext_vector_type(4)));
-#ifndef RTD_IFACE_CHUNK
-#define RTD_IFACE_CHUNK 5
-#endif
-constexpr int IFACE_CHUNK = RTD_IFACE_CHUNK;
 
-__global__ __launch_bounds__(256) void rtd_iface_mfma_kernel(RtdDev d) {
-  constexpr int NP = 16, Q = 32;
-  const int lane = threadIdx.x & 63;
-  const int Lm1 = d.L - 1;
-  const int nchunk = (Lm1 + IFACE_CHUNK - 1) / IFACE_CHUNK;
-  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= (long)d.C * d.M * nchunk) return;  // whole wavefronts exit together
-  const long cm = wid / nchunk;
-  const int l_begin = (int)(wid % nchunk) * IFACE_CHUNK;
-  const int l_end = min(l_begin + IFACE_CHUNK, Lm1);
-  const int m = (int)(cm % d.M), c = (int)(cm / d.M);
-  const int col = lane & 15, kq = lane >> 4;
-  const double* ts0 = d.taus0 + (long)c * (d.L + 1);
-  const int mg = d.m0 + d.mstep * m;  // the Fourier mode this local index stands for (mode shards)
-  const bool iso = d.Ns > 0 && mg == 0;
-  const double mu0 = d.beam ? d.mu0[c] : 1.0;
-  // operands of layer l in the MFMA A layout (= B layout of the same matrix): element [i = 4 s + kq][col]
-  double a0[4], y0[4], a1[4], y1[4];
-  {
-    const double* A0 = d.Am + (cm * d.L + l_begin) * NP * NP;
-    const double* Y0 = d.Ym + (cm * d.L + l_begin) * NP * NP;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      a0[s] = A0[(4 * s + kq) * NP + col];
-      y0[s] = Y0[(4 * s + kq) * NP + col];
-    }
-  }
-  for (int l = l_begin; l < l_end; ++l) {
-    const long p0 = cm * d.L + l, p1 = p0 + 1;
-    const double* A1 = d.Am + p1 * NP * NP;
-    const double* Y1 = d.Ym + p1 * NP * NP;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      a1[s] = A1[(4 * s + kq) * NP + col];
-      y1[s] = Y1[(4 * s + kq) * NP + col];
-    }
-    // particular-solution jump r_l (:184-205, :242-245): (r_up +- r_dn)_i for the four i = 4 s + kq of this lane
-    const double tb = ts0[l + 1];
-    const double att = d.beam ? exp(-tb / mu0) : 0.0;
-    v4f64 vv = {0.0, 0.0, 0.0, 0.0}, uu = {0.0, 0.0, 0.0, 0.0};
-    double rt = 0.0, rb = 0.0;
-    const double kcol0 = d.kk[p0 * NP + col];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int i = 4 * s + kq;
-      vv = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], y1[s], vv, 0, 0, 0);  // (A_l^T Y')[r][c] += A_l[i][r] Y'[i][c]
-      uu = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[s], a1[s], uu, 0, 0, 0);  // (Y_l^T A')[r][c] += Y_l[i][r] A'[i][c]
-      double ru = 0.0, rd = 0.0;
-      if (d.beam) {
-        ru = (d.Bv[p1 * Q + i] - d.Bv[p0 * Q + i]) * att;
-        rd = (d.Bv[p1 * Q + NP + i] - d.Bv[p0 * Q + NP + i]) * att;
-      }
-      if (iso) {
-        const double* dq0 = d.dq + ((long)c * d.L + l) * d.Ns * Q;
-        const double* dq1 = dq0 + (long)d.Ns * Q;
-        double tp = 1.0;
-        for (int q = 0; q < d.Ns; ++q) {
-          ru += (dq1[q * Q + i] - dq0[q * Q + i]) * tp;
-          rd += (dq1[q * Q + NP + i] - dq0[q * Q + NP + i]) * tp;
-          tp *= tb;
-        }
-      }
-      // rho = G_l^-1 r:  V^-1[j][i] = T_i A[i][j],  U^-1[j][i] = -k_j T_i Y[i][j]   (j = col)
-      const double Ti = d.T[i];
-      const double pa = Ti * a0[s] * (ru + rd), pb = -kcol0 * Ti * y0[s] * (ru - rd);
-      rt += pa + pb;
-      rb += pa - pb;
-    }
-    // sum the partial rho over the four k-quarters of the wavefront (lanes col, col+16, col+32, col+48)
-    rt += __shfl_xor(rt, 16, 64);
-    rb += __shfl_xor(rb, 16, 64);
-    rt += __shfl_xor(rt, 32, 64);
-    rb += __shfl_xor(rb, 32, 64);
-    double* ws = d.Fws + (cm * Lm1 + l) * Ws<NP>::SLOT;
-    const double rk1 = 1.0 / d.kk[p1 * NP + col];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = kq + 4 * q;  // C/D layout of v_mfma_f64_16x16x4_f64
-      const double u = uu[q] * d.kk[p0 * NP + r] * rk1;  // U^-1 U' = diag(k) Y^T A' diag(1/k')
-      ws[Ws<NP>::WP + r * NP + col] = 0.5 * (vv[q] + u);
-      ws[Ws<NP>::WQ + r * NP + col] = 0.5 * (vv[q] - u);
-    }
-    if (kq == 0) {
-      ws[Ws<NP>::RT + col] = 0.25 * rt;
-      ws[Ws<NP>::RB + col] = 0.25 * rb;
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      a0[s] = a1[s];
-      y0[s] = y1[s];
-    }
-  }
-}
 
 // Gauss-Jordan with partial pivoting on [A | B | b] (NP rows, one per lane of the group): on exit the lane
 // that owned pivot column `pc` holds row pc of A^-1 B in bm[] and (A^-1 b)[pc] in bv.
@@ -796,15 +694,13 @@ struct GjFast<NB, 16> {
   static __device__ __forceinline__ void run(double (&)[4], double (&)[4], double&, int&, const int) {}
 };
 
-// WAVES = 4, the default, is the lean form: four wavefronts per SIMD need <= 128 registers and <= 10 KB of LDS each, so it
-// prefetches one layer ahead instead of two, forms the interface products one after the other (one accumulator set live),
-// takes exp(-k dtau) from memory instead of the LDS window, saves t^T once instead of four times and rotates two operand
-// sets in the backward sweep instead of three (128 VGPRs, 29 of them spilled outside the two loops; 9.8 KB).  The kernel is
-// bound by the latency of its dependent chains: LDS padding that leaves 7 / 9 / 12 wavefronts per CU gives 5.46 / 4.82 /
-// 4.33 ms for the three-wavefront form (WAVES = 3: 168 VGPRs, 12.7 KB), 16 per CU with this form 4.1 ms.
-template <int WAVES>
-__global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
-  constexpr bool LEAN = WAVES >= 4;
+// Four wavefronts per SIMD: <= 128 registers and <= 10 KB of LDS each, so the kernel prefetches one layer ahead, forms the
+// interface products one after the other (one accumulator set live), takes exp(-k dtau) from memory, saves t^T once and
+// rotates two operand sets in the backward sweep (128 VGPRs, 29 of them spilled outside the two loops; 9.8 KB).  The kernel
+// is bound by the latency of its dependent chains: a three-wavefront form (two layers of prefetch, the products side by
+// side, exp(-k dtau) in the LDS window: 168 VGPRs, 12.7 KB; removed in round 3) took 4.19-4.25 ms per 2 048 cfg4 columns
+// against this form's 4.08-4.11 ms, and padded to 7 / 9 / 12 wavefronts per CU 5.46 / 4.82 / 4.33 ms.
+__global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
   constexpr int NP = 16, Q = 32, NN = NP * NP;
   const int lane = threadIdx.x, kq = lane >> 4, col = lane & 15, rowbase = lane & 48;
   const long cm = blockIdx.x;
@@ -873,12 +769,11 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
   //      that is consumed right away (one such load makes the wave wait for everything it has in flight: the counter is
   //      in-order).
   constexpr int W = RTD_BCF_WIN;
-  constexpr int NSV = LEAN ? 8 * 64 + 16 : 9 * 64;  // the save area: rows of Ta^T, Tb^T (4 x 64 each) and t^T (lean: one copy)
+  constexpr int NSV = 8 * 64 + 16;  // the save area: rows of Ta^T, Tb^T (4 x 64 each) and one copy of t^T
   constexpr int NSTG = NSV / 64;                    // result rows it can stage in the backward sweep
   __shared__ double sSaveFlat[NSV];
   double (*const sSave)[64] = reinterpret_cast<double (*)[64]>(sSaveFlat);
   __shared__ double sPs[W][Q];  // forward: r_l; backward: p_l(tau_l)
-  __shared__ double sEk[LEAN ? 1 : W][NP];  // (lean: not used, exp(-k dtau) comes from memory)
   __shared__ double sT[2][NP];  // T and 1 / T
   __shared__ double sF[NP];
   // Diagnostic build (-DRTD_BCF_STAMPS): lane 0 of three chains records s_memtime at the phase boundaries and prints the
@@ -966,10 +861,7 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
       }
       (&sPs[0][0])[e] = v;
     }
-    if constexpr (!LEAN) {
-#pragma unroll 1
-      for (int e = lane; e < nl * NP; e += 64) (&sEk[0][0])[e] = Ek[(long)base * NP + e];
-    }
+    
     __syncthreads();
   };
   auto fill_all = [&](const int base, const bool backward) {
@@ -988,10 +880,7 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
       b0[it] = Bv[l * Q + i];
       at[it] = att[backward ? l : l + 1];
     }
-    if constexpr (!LEAN) {
-#pragma unroll
-      for (int it = 0; it < NK; ++it) ek[it] = Ek[(long)base * NP + min(lane + 64 * it, nl * NP - 1)];
-    }
+    
 #pragma unroll
     for (int it = 0; it < NE; ++it) {
       const int e = lane + 64 * it, l = base + (e >> 5), i = e & 31;
@@ -1004,11 +893,7 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
         (&sPs[0][0])[e] = v;
       }
     }
-    if constexpr (!LEAN) {
-#pragma unroll
-      for (int it = 0; it < NK; ++it)
-        if (lane + 64 * it < nl * NP) (&sEk[0][0])[lane + 64 * it] = ek[it];
-    }
+    
     __syncthreads();
   };
   // (everything the prologue needs from memory is requested here, ahead of the window's fill: one memory latency, the
@@ -1017,14 +902,10 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
   const int lsecond = min(1, Lm1);
   v4f64 a1 = a0, y1 = y0;  // (lean: layer l + 1 is requested at the top of iteration l)
   double k0c = kk[col], k1c = k0c;
-  if constexpr (!LEAN) {
-    a1 = load_d(Am + (long)lsecond * NN, kq, col);
-    y1 = load_d(Ym + (long)lsecond * NN, kq, col);
-    k1c = kk[lsecond * NP + col];
-  }
+  
   const v4f64 k_row = load_row(kk, kq);
   v4f64 e_row_g = k_row;
-  if constexpr (LEAN) e_row_g = load_row(Ek, kq);
+  e_row_g = load_row(Ek, kq);
   double tv = d.bneg[cm * NP + col];
   const double bv_top = beam ? Bv[NP + col] : 0.0, dq_top = iso ? dq[NP + col] : 0.0;
   {
@@ -1044,7 +925,7 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
     const double rT_col = sT[1][col];
     const v4f64 eye = make_eye(kq, col);
     const v4f64 yt = mm_t(y0, eye), at = mm_t(a0, eye);
-    const v4f64 e_row = LEAN ? e_row_g : load_row(&sEk[0][0], kq);
+    const v4f64 e_row = e_row_g;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const double av = at[q] * fast_rcp(k_row[q]);
@@ -1075,16 +956,12 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
     const int ln = min(l + 1, Lm1), l2 = min(l + 2, Lm1);
     v4f64 a2 = a1, y2 = y1, e1r_g = a1;
     double k2c = k1c, e0c_g = 0.0;
-    if constexpr (LEAN) {  // one layer ahead: consumed behind this iteration's elimination
+    {  // one layer ahead: consumed behind this iteration's elimination
       a1 = load_d(Am + (long)ln * NN, kq, col);
       y1 = load_d(Ym + (long)ln * NN, kq, col);
       k1c = kk[ln * NP + col];
       e0c_g = Ek[l * NP + col];
       e1r_g = load_row(Ek + ln * NP, kq);
-    } else {
-      a2 = load_d(Am + (long)l2 * NN, kq, col);
-      y2 = load_d(Ym + (long)l2 * NN, kq, col);
-      k2c = kk[l2 * NP + col];
     }
     if (ln >= wb + W) fill(l, false);
     RTD_STAMP();  // 4 l + 1: loop top (register rotation, loads issued)
@@ -1096,7 +973,7 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
         sSave[q][lane] = ta[q];
         sSave[4 + q][lane] = tb[q];
       }
-      if (!LEAN || kq == 0) sSave[8][LEAN ? col : lane] = tv;
+      if (kq == 0) sSave[8][col] = tv;
       int bad = 0;
       GjFast<4, 0>::run(ta, tb, tv, bad, col);
       bad |= (fabs(tv) + fabs(tb[0]) + fabs(tb[1]) + fabs(tb[2]) + fabs(tb[3]) < 1e300) ? 0 : 1;  // zero pivot: inf / nan
@@ -1117,7 +994,7 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) ws[Ws<NP>::S + (4 * q + kq) * NP + col] = tb[q];
     if (kq == 0) ws[Ws<NP>::SV + col] = tv;
-    if constexpr (LEAN) {
+    {
       // the same quantities with one accumulator set live at a time (Y_l is scaled in place: it is not used again)
       v4f64 a1s;
       {
@@ -1168,52 +1045,6 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
         }
       }
       tv = tnew;
-    } else {
-    // ---- interface products; the diagonal scalings are column scalings of the operands (at l = L - 1 they are not used)
-    v4f64 y0s, a1s;
-    {
-      const double rk1c = fast_rcp(k1c);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        y0s[q] = y0[q] * k0c;
-        a1s[q] = a1[q] * rk1c;
-      }
-    }
-    const v4f64 m1 = mm_t(a0, y1), m1t = mm_t(y1, a0), m2s = mm_t(y0s, a1s), m2st = mm_t(a1s, y0s);
-    __builtin_amdgcn_sched_barrier(0);  // the products' operands die here; what follows keeps ~40 registers in flight
-    // rho = G_l^-1 r_l for the particular-solution jump r_l at the interface:
-    //   rho_t/b = 1/4 [ V^-1 (r_up + r_dn) +- U^-1 (r_up - r_dn) ],  V^-1[j][i] = T_i A[i][j],  U^-1[j][i] = -k_j T_i Y[i][j]
-    double rt = 0.0, rb = 0.0;
-    {
-      const v4f64 t_row = load_row(&sT[0][0], kq);
-      const v4f64 ru = load_row(&sPs[r0][0], kq), rd = load_row(&sPs[r0][NP], kq);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const double pa = t_row[s] * a0[s] * (ru[s] + rd[s]), pb = -t_row[s] * y0s[s] * (ru[s] - rd[s]);
-        rt += pa + pb;
-        rb += pa - pb;
-      }
-      rt = 0.25 * sum_kq(rt);
-      rb = 0.25 * sum_kq(rb);
-    }
-    if (kq == 0) ws[Ws<NP>::RB + col] = rb;
-    RTD_STAMP();  // 4 l + 3: wait, stores, products, rho
-    // ---- carry of the next layer:  Ta'^T = -(Wq^T H E + Wp^T),  Tb'^T = -E' (Wp^T H E + Wq^T)  with
-    //      Wp/Wq = (M1 +- M2s)/2:  X = M1^T H E, Z = M2s^T H E
-    const double e0c = sEk[r0][col];
-    const v4f64 e1r = load_row(&sEk[r1][0], kq);
-    v4f64 he;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) he[q] = tb[q] * e0c;
-    const v4f64 xx = mm_t(m1, he), zz = mm_t(m2s, he);
-    const v4f64 hcur = {tb[0], tb[1], tb[2], tb[3]};
-    const double tnew = rt - e0c * (tv - col_dot(hcur, col_to_row(rb, rowbase, kq)));  // t' = rho_t - E (s - S rho_b)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      ta[q] = -0.5 * (xx[q] - zz[q] + m1t[q] + m2st[q]);
-      tb[q] = -0.5 * (xx[q] + zz[q] + m1t[q] - m2st[q]) * e1r[q];
-    }
-    tv = tnew;
     }
 #ifdef RTD_BCF_STAMPS
     asm volatile("" ::"v"(ta[0]), "v"(ta[3]), "v"(tb[0]), "v"(tb[3]), "v"(tv));
@@ -1222,11 +1053,7 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
     a0 = a1;
     y0 = y1;
     k0c = k1c;
-    if constexpr (!LEAN) {
-      a1 = a2;
-      y1 = y2;
-      k1c = k2c;
-    }
+    
   }
 
   // ---- bottom boundary (up-streams at tau_L) (:208-232, :248-254, :288-293):  Ba C- + Bb C+ = br,
@@ -1256,9 +1083,9 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
       }
     }
     v4f64 eLr_g = qr;
-    if constexpr (LEAN) eLr_g = load_row(Ek + l * NP, kq);
+    eLr_g = load_row(Ek + l * NP, kq);
     const double rkLc = fast_rcp(kLc);
-    const v4f64 eLr = LEAN ? eLr_g : load_row(&sEk[LEAN ? 0 : rL][0], kq);
+    const v4f64 eLr = eLr_g;
     const v4f64 rT_row = load_row(&sT[1][0], kq), eye = make_eye(kq, col);
     v4f64 p0, q0, x1 = eye, x2 = eye, rtr = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1311,7 +1138,7 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
     {
 #pragma unroll
       for (int q = 0; q < 4; ++q) sSave[q][lane] = mt[q];
-      if (!LEAN || kq == 0) sSave[8][LEAN ? col : lane] = rhs;
+      if (kq == 0) sSave[8][col] = rhs;
       int bad = 0;
       GjFast<0, 0>::run(mt, none, rhs, bad, col);
       bad |= (fabs(rhs) < 1e300) ? 0 : 1;
@@ -1419,7 +1246,7 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
     s.rb = w[Ws<NP>::RB + col];
     s.k = kk[l * NP + col];
     s.e = 0.0;
-    if constexpr (LEAN) s.e = Ek[l * NP + col];
+    s.e = Ek[l * NP + col];
     return s;
   };
   v4f64 w1, w2;
@@ -1427,7 +1254,7 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
   //  memory latency for all of it)
   const double kL = kk[Lm1 * NP + col];
   double eL_g = 0.0;
-  if constexpr (LEAN) eL_g = Ek[Lm1 * NP + col];
+  eL_g = Ek[Lm1 * NP + col];
   double attL = 0.0, buL = 0.0, bdL = 0.0;
   if (beam && um) {
     attL = d.att[(long)c * (L + 1) + L];
@@ -1438,7 +1265,7 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
   if (Lm1 > 0) s0 = load_set(Lm1 - 1);
   fill_all(max(L - W, 0), true);
   {
-    const double eL = LEAN ? eL_g : sEk[LEAN ? 0 : Lm1 - wb][col], rk = fast_rcp(kL);
+    const double eL = eL_g, rk = fast_rcp(kL);
     nstage = 1;  // slot 0 = row L: u^m at tau_L, the bottom of the last layer (e- = E_L, e+ = 1); no coefficients
     if (um) {
       const double en = eL * cminus, ep = cplus;
@@ -1481,7 +1308,7 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
     cplus = cp;
     v4f64 nw2 = {0.0, 0.0, 0.0, 0.0};
     if (l > 0 || um) {
-      const double x = cmn, y = (LEAN ? s.e : sEk[LEAN ? 0 : l - wb][col]) * cp;
+      const double x = cmn, y = s.e * cp;
       w1 = row_dot(s.y, x + y);
       w2 = row_dot(s.a, (y - x) * fast_rcp(s.k));
 #pragma unroll
@@ -1493,24 +1320,7 @@ __global__ __launch_bounds__(64, WAVES) void rtd_bc_mfma_kernel(RtdDev d) {
   __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing pending at the loop's entry (see the forward loop)
   // (issued in the order of their use: a set requested after a younger one would be waited for with a smaller count; the
   //  first set came in with the fill)
-  if constexpr (!LEAN) {
-  BwSet s1 = load_set(max(Lm1 - 2, 0));
-  __builtin_amdgcn_sched_barrier(0);
-  BwSet s2 = load_set(max(Lm1 - 3, 0));
-  __builtin_amdgcn_sched_barrier(0);
-  // (the requests are unconditional -- past the top they repeat layer 0 -- so that the number of younger loads behind each
-  //  set is the same on every path and the waits stay counted)
-  for (int l = Lm1 - 1; l >= 0; l -= 3) {
-    step(l, s0);
-    s0 = load_set(max(l - 3, 0));
-    if (l < 1) break;
-    step(l - 1, s1);
-    s1 = load_set(max(l - 4, 0));
-    if (l < 2) break;
-    step(l - 2, s2);
-    s2 = load_set(max(l - 5, 0));
-  }
-  } else {  // two sets, unrolled by two
+  {  // two sets, unrolled by two
     BwSet s1 = load_set(max(Lm1 - 2, 0));
     __builtin_amdgcn_sched_barrier(0);
     for (int l = Lm1 - 1; l >= 0; l -= 2) {
@@ -2369,8 +2179,7 @@ bool rtd_bc_fuses_eval(const RtdDev& d) {
   // the fused kernels -- rtd_bc_mfma_kernel and the tiled one at 16 or 32 streams per hemisphere -- write u^m at the
   // interfaces themselves; a window in which the tiled kernel handed a chain to the row-per-lane kernels (d.split_any)
   // is evaluated by the evaluation kernel instead (rtd_launch_eval)
-  static const bool split = getenv("RTD_BC_SPLIT") != nullptr;
-  return (d.NP == 16 || d.NP == 32) && !split;
+  return d.NP == 16 || d.NP == 32;
 }
 
 void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
@@ -2380,9 +2189,8 @@ void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
   const dim3 gi((unsigned)((nif + gpw - 1) / gpw));
   const dim3 gs((unsigned)(((long)d.C * d.M + gpw - 1) / gpw));
   const dim3 gc((unsigned)((long)d.C * d.M));
-  // RTD_BC_SPLIT=1: the two-kernel path for every stream count (A/B runs and a regression test);
   // RTD_BC_TILED=1: the tiled fused kernel also at NP = 16 (T = 1: cross-check of the 64-stream kernel's generalisation)
-  static const bool split = getenv("RTD_BC_SPLIT") != nullptr, tiled16 = getenv("RTD_BC_TILED") != nullptr;
+  static const bool tiled16 = getenv("RTD_BC_TILED") != nullptr;
   const int* none = nullptr;
 #define RTD_BC_CASE(NPV)                                                                                    \
   case NPV:                                                                                                 \
@@ -2403,36 +2211,15 @@ void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
   switch (d.NP) {
     RTD_BC_CASE(4)
     RTD_BC_CASE(8)
-    case 16: {
-      // default: the fused MFMA kernel (launched as part 1; part 0 is empty)
-      if (tiled16 && !split) {
+    case 16:
+      if (tiled16) {
         RTD_BC_TILED_CASE(16, 1)
-        break;
+      } else if (part == 1) {  // the fused MFMA kernel (part 0 is empty)
+        hipLaunchKernelGGL(rtd_bc_mfma_kernel, gc, dim3(64), 0, s, d);
       }
-      if (!split) {
-        // default: the lean form, four wavefronts per SIMD (4.08-4.11 ms per 2 048 cfg4 columns against 4.19-4.25 ms of the
-        // three-wavefront form on the same boxes); RTD_BCF_WAVES3=1: the latter (A/B runs and a regression test)
-        static const bool waves3 = getenv("RTD_BCF_WAVES3") != nullptr;
-        if (part == 1) {
-          if (waves3) hipLaunchKernelGGL(rtd_bc_mfma_kernel<3>, gc, dim3(64), 0, s, d);
-          else hipLaunchKernelGGL(rtd_bc_mfma_kernel<4>, gc, dim3(64), 0, s, d);
-        }
-        break;
-      }
-      if (part == 0 && nif > 0)
-        hipLaunchKernelGGL(rtd_iface_mfma_kernel,
-                           dim3((unsigned)(((long)d.C * d.M * ((d.L - 1 + IFACE_CHUNK - 1) / IFACE_CHUNK) + 3) / 4)),
-                           dim3(256), 0, s, d);
-      if (part == 1) hipLaunchKernelGGL(rtd_sweep_kernel<16>, gs, dim3(64), 0, s, d, none);
       break;
-    }
     case 32:
-      if (!split) {
-        RTD_BC_TILED_CASE(32, 2)
-        break;
-      }
-      if (part == 0 && nif > 0) hipLaunchKernelGGL(rtd_iface_kernel<32>, gi, dim3(64), 0, s, d, none);
-      if (part == 1) hipLaunchKernelGGL(rtd_sweep_kernel<32>, gs, dim3(64), 0, s, d, none);
+      RTD_BC_TILED_CASE(32, 2)
       break;
     default: break;
   }

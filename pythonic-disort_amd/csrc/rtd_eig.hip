@@ -5,8 +5,8 @@
 //   D+/D-, alpha, beta (:123-135), eig((alpha-beta)(alpha+beta)) (:179-183), G blocks (:186-198),
 //   beam particular solution (:143-152, :209-231), G^-1 [1/mu;-1/mu] (:203-205 + _assemble.py:124)
 //   and the isotropic-source particular solution coefficients (subroutines.py:746-862)
-//   -> rtd_eigen_kernel<NP, JV> (one fused kernel; JV = 2: Jacobi sweeps in the pair layout, JV = 1: one column per lane,
-//      kept behind RTD_EIG_V1 for A/B runs and as a regression test).
+//   -> rtd_eigen_kernel<NP, JV> (one fused kernel; JV = 2: the default; JV = 3: the same with the assembly of Pm, Qm on the
+//      matrix cores, NP = 16, behind RTD_EIG_MFMA -- the north star's wording, measured slower, kept as a tested variant).
 //
 // Algorithm (own design, not the reference's LAPACK calls): with T = diag(sqrt(mu w)) the matrices
 // -(T(alpha+beta)T^-1) = Pm and -(T(alpha-beta)T^-1) = Qm are symmetric positive definite, so with
@@ -107,48 +107,6 @@ __device__ __forceinline__ double approx_rcp(double x) {
 #ifndef RTD_JAC_TOL
 #define RTD_JAC_TOL 1e-14
 #endif
-
-// One parallel step of the one-sided (Hestenes) Jacobi iteration on the columns of W (H = W W^T at the
-// start): lane j holds column j, all pairs (j, j^T) are orthogonalised at once.  On convergence the columns
-// are k_j z_j (singular values x left singular vectors = sqrt(eigenvalues) x eigenvectors of H).
-template <int NP, int T>
-struct JacobiStep {
-  // alpha = |w|^2 of this lane's column, maintained across steps (it only steers the rotation angles, so the
-  // slow drift of the recurrence is harmless; it is recomputed from the column at every sweep start)
-  static __device__ __forceinline__ void run(double (&w)[NP], double& alpha, const int j, int& notconv) {
-    double pw[NP];
-    double gamma = 0.0;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      pw[i] = xor_lane<T>(w[i]);
-      gamma += w[i] * pw[i];
-    }
-    const double beta = xor_lane<T>(alpha);
-    const bool lo = (j & high_bit(T)) == 0;  // j < j^T
-    // tan(2 theta) = 2 gamma / (a_hi - a_lo);  t = tan(theta) without cancellation.  Branch-free: the tiny term keeps
-    // gamma = 0 (decoupled or already orthogonal columns, also with equal norms) at t = 0, c = 1 without a 0/0.
-    const double delta = lo ? (beta - alpha) : (alpha - beta);
-    const double g2 = 2.0 * gamma;
-    const double r2 = delta * delta + (g2 * g2 + 1e-280);
-    const double rho = r2 * approx_rsqrt(r2);
-    const double den = delta + copysign(rho, delta);
-    const double tt = g2 * approx_rcp(den);
-    // c from ONE Newton step (4e-15): the error scales BOTH columns of the pair by the same 1 + eps, so orthogonality and
-    // the directions z are untouched; only the norms k drift, by ~50 rotations x 4e-15 (parity unchanged)
-    const double c = approx_rsqrt(1.0 + tt * tt);
-    const double tsg = lo ? -tt : tt;
-    const double sg = tsg * c;
-    notconv |= (gamma * gamma > RTD_JAC_TOL * alpha * beta) ? 1 : 0;
-    alpha = fma(tsg, gamma, alpha);  // |c w + sg pw|^2 = alpha -+ t gamma for the rotation that annihilates gamma
-#pragma unroll
-    for (int i = 0; i < NP; ++i) w[i] = c * w[i] + sg * pw[i];
-    JacobiStep<NP, T + 1>::run(w, alpha, j, notconv);
-  }
-};
-template <int NP>
-struct JacobiStep<NP, NP> {
-  static __device__ __forceinline__ void run(double (&)[NP], double&, const int, int&) {}
-};
 
 // Transposed reduction: every lane enters with NP terms v[0..NP) (term i belongs to row i) and leaves with the sum of
 // row `j` over the NP lanes of its group -- NP-1 swizzle-adds in registers, no LDS memory.
@@ -395,7 +353,7 @@ __device__ __forceinline__ ProbId locate(const RtdDev& d, const int tx = threadI
 // ------------------------------------------------------------------------------------------------
 // Jacobi sweeps in the "pair" layout (the default): the NP lanes of a problem are NP/2 pair slots x 2 halves; lane
 // (p, u) holds the elements [u NP/2, (u + 1) NP/2) of BOTH columns of the pair in slot p.  Against the column-per-lane
-// form (JacobiStep): the dot product of a pair is NP/2 FMAs and one cross-lane add (not NP FMAs after NP column moves),
+// form of round 1 (one column per lane, removed in round 3): the dot product of a pair is NP/2 FMAs and one cross-lane add (not NP FMAs after NP column moves),
 // and after the rotation only ONE of the two columns moves on, as a half column: NP/2 doubles per lane (not NP) to
 // lane ^ mask with mask in {1, 2, 3, 7, 8, 15} -- a single DPP move per dword.  Per step a wavefront issues
 // ~NP/2 + 25 + 2 NP FP64 instructions and NP + 6 moves instead of NP + 34 + 2 NP and 2 NP + 2.
@@ -538,8 +496,7 @@ __host__ __device__ constexpr int tri(int r, int c) { return r * (r + 1) / 2 + c
 #define RTD_ESTAMP(k)
 #endif
 
-template <int NP, int JV>  // JV: 2 = Jacobi sweeps in the pair layout (default), 1 = one column per lane (RTD_EIG_V1),
-//                             3 = 2 with the assembly of Pm, Qm on the matrix cores (RTD_EIG_MFMA, NP = 16)
+template <int NP, int JV>  // JV: 2 = default; 3 = the assembly of Pm, Qm on the matrix cores (RTD_EIG_MFMA, NP = 16)
 __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES)) void rtd_eigen_kernel(RtdDev d) {
   constexpr int GPW = 64 / NP;
   // Cholesky factor L of Pm in LDS: a padded square at NP <= 16; at NP = 32 the packed lower triangle (element (r, c), r >= c,
@@ -823,20 +780,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES
   // one-sided Jacobi on the columns of F
   int nsweep = 0;
   bool converged = false;
-  if constexpr (JV == 1) {
-    for (int sweep = 0; sweep < 40; ++sweep) {
-      int notconv = 0;
-      double alpha = 0.0;
-#pragma unroll
-      for (int i = 0; i < NP; ++i) alpha += w[i] * w[i];
-      JacobiStep<NP, 1>::run(w, alpha, j, notconv);
-      ++nsweep;
-      if (!__any(notconv)) {
-        converged = true;
-        break;
-      }
-    }
-  } else {
+  {
     constexpr int H = NP / 2;
     const int u = j / H, p = j % H;  // lane (p, u): half u of the two columns of pair slot p
     double xh[H], yh[H];
@@ -1135,20 +1079,17 @@ void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part) {
   if (part != 1) return;
   const int gpw = 64 / d.NP;
   const dim3 grid((unsigned)((long)d.C * d.M * ((d.ln + gpw - 1) / gpw)));
-  // RTD_EIG_V1=1: the one-column-per-lane form of the sweeps (A/B runs and a regression test)
   // RTD_EIG_MFMA=1: the assembly of Pm, Qm on the matrix cores (NP = 16; A/B runs and a regression test)
-  static const bool v1 = getenv("RTD_EIG_V1") != nullptr, mfma = getenv("RTD_EIG_MFMA") != nullptr;
+  static const bool mfma = getenv("RTD_EIG_MFMA") != nullptr;
 #define RTD_EIG_CASE(NPV)                                                                        \
   case NPV:                                                                                      \
-    if (v1) hipLaunchKernelGGL((rtd_eigen_kernel<NPV, 1>), grid, dim3(64), 0, s, d);             \
-    else hipLaunchKernelGGL((rtd_eigen_kernel<NPV, 2>), grid, dim3(64), 0, s, d);                \
+    hipLaunchKernelGGL((rtd_eigen_kernel<NPV, 2>), grid, dim3(64), 0, s, d);                     \
     break;
   switch (d.NP) {
     RTD_EIG_CASE(4)
     RTD_EIG_CASE(8)
     case 16:
-      if (v1) hipLaunchKernelGGL((rtd_eigen_kernel<16, 1>), grid, dim3(64), 0, s, d);
-      else if (mfma) hipLaunchKernelGGL((rtd_eigen_kernel<16, 3>), grid, dim3(64), 0, s, d);
+      if (mfma) hipLaunchKernelGGL((rtd_eigen_kernel<16, 3>), grid, dim3(64), 0, s, d);
       else hipLaunchKernelGGL((rtd_eigen_kernel<16, 2>), grid, dim3(64), 0, s, d);
       break;
     RTD_EIG_CASE(32)

@@ -579,25 +579,23 @@ def test_fused_bc_kernel_pivoted_path_on_goldens():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["RTD_BC_SPLIT", "RTD_EIG_V1", "RTD_EIG_MFMA", "RTD_BC_TILED", "RTD_BC_FORCE_HANDOVER",
-                                    "RTD_BCF_WAVES3"])
+@pytest.mark.parametrize("switch", ["RTD_EIG_MFMA", "RTD_BC_TILED", "RTD_BC_FORCE_HANDOVER", "RTD_NO_PIPELINE"])
 def test_alternative_kernel_paths_stay_correct(switch):
-    """The runtime switches that select an alternative kernel path -- RTD_BC_SPLIT=1: interface operators through HBM +
-    row-per-lane sweep kernel instead of the fused MFMA-layout kernels; RTD_EIG_V1=1: Jacobi sweeps with one column per lane
-    instead of the pair layout; RTD_EIG_MFMA=1: the assembly of Pm, Qm as rank-4 MFMA updates (32 streams); RTD_BC_TILED=1: the tiled fused kernel (the 64-stream kernel) with one tile, in place of the
-    32-stream kernel it generalises; RTD_BCF_WAVES3=1: the three-wavefronts-per-SIMD form of the 32-stream fused kernel (two layers of prefetch, the
-    interface products side by side, three operand sets in the backward sweep) in place of the lean four-wavefront form;
-    RTD_BC_FORCE_HANDOVER=1: the tiled kernel hands every third chain to the pivoted
+    """The runtime switches that select an alternative path -- RTD_EIG_MFMA=1: the assembly of Pm, Qm as rank-4 MFMA updates
+    (32 streams); RTD_BC_TILED=1: the tiled fused kernel (the 64-stream kernel) with one tile, in place of the 32-stream
+    kernel it generalises; RTD_BC_FORCE_HANDOVER=1: the tiled kernel hands every third Fourier mode's chain to the pivoted
     row-per-lane kernels (its last resort for singular carry blocks; the window's fused interface evaluation is then
-    replaced by the evaluation kernel) -- pass the golden replay (it has 40-, 48- and 64-stream cases), the synthetic configs
-    incl. cfg5, the random cases and the fused-evaluation comparison."""
+    replaced by the evaluation kernel); RTD_NO_PIPELINE=1: the windows of a plan one after the other on one stream instead
+    of the two-stream pipeline -- pass the golden replay (it has 40-, 48- and 64-stream cases), the synthetic configs incl.
+    cfg5, the random cases, the windowed plans and the fused-evaluation comparison.  (Round 3 removed the switches whose
+    paths had lost every A/B: RTD_BC_SPLIT at 32 streams, RTD_EIG_V1, RTD_BCF_WAVES3.)"""
     import subprocess
     import sys
     env = dict(os.environ, **{switch: "1"})
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"),
                         os.path.join(os.path.dirname(__file__), "test_gpu_random_parity.py"),
-                        "-k", "reference_golden or synthetic_config or random_many or edge_cases or fused_interface"],
+                        "-k", "reference_golden or synthetic_config or random_many or edge_cases or fused_interface or windowed"],
                        env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 

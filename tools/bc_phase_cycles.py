@@ -29,10 +29,8 @@ plan.run(); plan.synchronize()
 
 if __name__ == "__main__":
     C = sys.argv[1] if len(sys.argv) > 1 else "2048"
-    # (the phase stamps sit in the three-wavefront instance of the kernel: the lean default forms its products in one block
-    #  with the carry and has no boundary between them)
-    out = subprocess.run([sys.executable, "-c", CHILD, C], capture_output=True, text=True,
-                         env=dict(os.environ, RTD_BCF_WAVES3="1")).stdout
+    # (three stamps per forward iteration: the kernel forms its products in one block with the carry, no boundary between them)
+    out = subprocess.run([sys.executable, "-c", CHILD, C], capture_output=True, text=True).stdout
     d = collections.defaultdict(dict)
     for ln in out.splitlines():
         if ln.startswith("ST "):
@@ -41,10 +39,10 @@ if __name__ == "__main__":
     L = 20
     for cm, v in sorted(d.items()):
         seq = [v[i] for i in range(1, max(v) + 1)]
-        fw = np.array(seq[1:1 + 4 * (L - 1)]).reshape(L - 1, 4)
-        rest = seq[1 + 4 * (L - 1):]
+        fw = np.array(seq[1:1 + 3 * (L - 1)]).reshape(L - 1, 3)
+        rest = seq[1 + 3 * (L - 1):]
         bw = np.array(rest[3:3 + 2 * (L - 1)]).reshape(L - 1, 2)
         print(f"chain {cm}: total {sum(seq)} cycles; prologue {seq[0]}")
-        print("  forward, mean per layer [top+loads, elimination, wait+stores+products+rho, carry]:", fw.mean(0).round(0))
+        print("  forward, mean per layer [top+loads, elimination, wait+stores+products+rho+carry]:", fw.mean(0).round(0))
         print("  last elimination, bottom boundary, first backward part:", rest[:3])
         print("  backward, mean per layer [operands+C+, rest]:", bw.mean(0).round(0), " tail:", rest[3 + 2 * (L - 1):])
