@@ -595,7 +595,7 @@ def test_alternative_kernel_paths_stay_correct(switch):
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"),
                         os.path.join(os.path.dirname(__file__), "test_gpu_random_parity.py"),
-                        "-k", "reference_golden or synthetic_config or random_many or edge_cases or fused_interface or windowed"],
+                        "-k", "reference_golden or synthetic_config or random_many or edge_cases or fused_interface or windowed or layer_shards"],
                        env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
@@ -836,7 +836,42 @@ def test_numerical_failure_is_reported_not_returned(amd):
         plan.evaluate(np.tile([0.0, 1.0], (C, 1)), np.array([0.0]))
     with pytest.raises(np.linalg.LinAlgError):   # the reference's exception type is a base class of ours
         plan.evaluate(np.tile([0.0, 1.0], (C, 1)), np.array([0.0]))
+    # A failed solve whose results are never fetched must not haunt the next batch on the same plan (round-2 advisor
+    # finding: the device status word used to be cleared only after a fetch): solve the bad batch again, do NOT fetch,
+    # upload a good batch, run + fetch -> clean.
+    plan.solve()
+    good = prepare_columns(np.tile([0.5, 1.0, 2.0], (C, 1)), np.full((C, Lr), 0.9), NQ, np.tile(0.7 ** np.arange(NQ + 1), (C, Lr, 1)),
+                           np.full(C, 0.6), np.full(C, np.pi), np.zeros(C), NQ, NQ, np.zeros((C, N, NQ)), np.zeros((C, N, NQ)),
+                           np.zeros((C, Lr)), np.zeros((C, Lr, 0)), np.zeros((C, 0, N, N)), np.zeros((C, 0, N)))
+    plan.set_columns(good)
+    plan.set_eval_points(np.tile([0.0, 1.0], (C, 1)), np.array([0.0]))
+    out = plan.run_fetch()
+    assert np.all(np.isfinite(out["u"])) and np.all(out["flux_up"] > 0)
     plan.close()
+
+
+@pytest.mark.gpu
+def test_raw_upload_checks_every_shape(amd):
+    """rtd_plan_set_columns_raw takes bare pointers whose extents the plan implies: the Python layer refuses any array whose
+    shape does not match (round-2 advisor finding: only two of them used to be checked), and the plan's view of the batch
+    (tau range of the closures) follows a raw upload."""
+    from pydisort_amd import synthetic
+    cfg = synthetic.cfg4_columns(5, L=4, NQuad=8)
+    _, sol = amd.pydisort_batch(device_prepare=True, **cfg)
+    plan, raw = sol.plan, dict(sol.prep["raw"])
+    for key, bad in (("omega_arr", np.zeros((5, 3))), ("f_arr", np.zeros((4, 4))), ("mu0", np.zeros(6)), ("I0", np.zeros((5, 1))),
+                     ("b_pos", np.zeros((5, 8, 3))), ("leg", np.zeros((5, 4, 3))), ("tau_arr", np.ones((5, 5)))):
+        with pytest.raises(ValueError):
+            plan.set_columns_raw(dict(raw, **{key: bad}))
+    other = synthetic.cfg4_columns(5, L=4, NQuad=8, seed=11)
+    raw2 = dict(raw, tau_arr=other["tau_arr"], omega_arr=other["omega_arr"])
+    plan.set_columns_raw(raw2)
+    assert np.array_equal(plan.prep["tau"], other["tau_arr"])
+    plan.solve()
+    tau = np.concatenate((np.zeros((5, 1)), other["tau_arr"]), axis=1)
+    _, want = amd.pydisort_batch(**dict(cfg, tau_arr=other["tau_arr"], omega_arr=other["omega_arr"]))
+    got = plan.evaluate(tau, np.array([0.0, 1.0]))
+    assert np.max(np.abs(got["u"] - want.u(tau, np.array([0.0, 1.0])))) <= 1e-12 * np.max(np.abs(got["u"]))
 
 
 @pytest.mark.gpu
