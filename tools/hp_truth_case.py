@@ -27,6 +27,7 @@ Usage (build container; minutes per case on 6 processes):
     python3 tools/hp_truth_case.py random32 9 25          # family, seeds ...
     python3 tools/hp_truth_case.py random64 11
     python3 tools/hp_truth_case.py golden 8ARTS_A
+    python3 tools/hp_truth_case.py synth cfg4_9 cfg5_0     # a column of a synthetic BASELINE config (cfg5: ~1.5 h)
     python3 tools/hp_truth_case.py --near-conservative    # every random32 / random64 seed with an omega > 1 - 1e-5 layer
 """
 import multiprocessing
@@ -39,7 +40,7 @@ import numpy as np
 import mpmath as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "pythonic-disort_amd")]
 from oracle import disort_oracle as O  # noqa: E402  (host-side preparation only: delta-M scaling, quadrature, tables)
 
 mp.mp.dps = 40
@@ -296,6 +297,22 @@ def case_of(family, key):
     return kw, tau, phi
 
 
+def case_synth(key):
+    """A column of a synthetic BASELINE config, "cfg4_<i>" or "cfg5_<i>", at the points of its reference-computed golden
+    (tests/golden/synth/<cfg>.npz); the tabulated BDRF modes of cfg5 become callables on the quadrature grid."""
+    from pydisort_amd import synthetic
+    name, col = key.rsplit("_", 1)
+    col = int(col)
+    cfg = {"cfg4": synthetic.cfg4_columns, "cfg5": synthetic.cfg5_columns}[name](col + 1)
+    kw = synthetic.column_kwargs(cfg, col)
+    if "bdrf_q" in cfg:
+        q, q0 = cfg["bdrf_q"][col], cfg["bdrf_q0"][col]
+        kw["BDRF_Fourier_modes"] = [(lambda mu, nmup, m=m: q0[m][:, None] if len(np.atleast_1d(nmup)) == 1 else q[m])
+                                    for m in range(q.shape[0])]
+    z = np.load(os.path.join(ROOT, "tests", "golden", "synth", name + ".npz"))
+    return kw, z[f"c{col}.tau_pts"], z["phi"]
+
+
 def _golden_call(job):
     kw, tau, phi = job
     return truth(kw, tau, phi, parallel=False)[0]
@@ -331,7 +348,7 @@ def run_golden(test_id):
 
 
 def run(family, key):
-    kw, tau, phi = case_of(family, key)
+    kw, tau, phi = case_synth(key) if family == "synth" else case_of(family, key)
     t0 = time.time()
     u, u0, fup = truth(kw, tau, phi)
     kwo = dict(kw)
