@@ -53,7 +53,11 @@ int rtd_device_count(int32_t* count);
  * ~8 MB per 20-layer 32-stream column) are held for one *window* of columns at a time and the kernels run window after
  * window on the plan's stream, so ncols is bounded by the inputs and results only (10^5 columns of BASELINE.json's
  * configs[3] need 2.3 GB).  rtd_plan_create sizes the window itself (environment RTD_WORK_BYTES, default 24 GiB of
- * intermediates); rtd_plan_create_windowed takes it from the caller (work_columns <= 0: automatic). */
+ * intermediates); rtd_plan_create_windowed takes it from the caller (work_columns <= 0: automatic).
+ * A plan of more than one window pipelines them: it keeps the eigen stage's hand-off buffers twice and runs the eigen
+ * stage of window w + 1 on a second HIP stream beside the boundary-condition and evaluation stage of window w (events
+ * order the two; RTD_NO_PIPELINE=1 in the environment runs the windows one after the other).  Nothing of this is visible
+ * at the ABI: every call below is ordered on the plan's stream as before, rtd_plan_synchronize covers both. */
 int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** plan);
 int rtd_plan_create_windowed(const rtd_dims* dims, int32_t device, int32_t work_columns, rtd_plan** plan);
 /* columns per window and number of windows of a plan */

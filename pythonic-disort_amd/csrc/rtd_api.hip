@@ -589,6 +589,7 @@ int rtd_plan_destroy(rtd_plan* p) {
 int rtd_plan_synchronize(rtd_plan* p) {
   if (!p) return fail(RTD_ERR_ARG, "null plan");
   HIP_TRY(hipStreamSynchronize(p->stream));
+  if (p->eig_stream) HIP_TRY(hipStreamSynchronize(p->eig_stream));  // (every eigen stage is consumed on `stream`: a formality)
   if (p->comm_stream) HIP_TRY(hipStreamSynchronize(p->comm_stream));
   return 0;
 }
