@@ -767,6 +767,41 @@ def test_windowed_plan_equals_single_window(amd):
 
 
 @pytest.mark.gpu
+def test_window_pipeline_equals_serial_windows(amd):
+    """The two-stream window pipeline (eigen stage of window w + 1 beside the boundary-condition stage of window w, two sets
+    of hand-off buffers, events per slot) against the same plan with its windows one after the other (RTD_NO_PIPELINE=1):
+    3 000 cfg4 columns in 12 windows of 256 (the last one short), three runs queued back to back without a host
+    synchronisation in between (the pipeline stays full across runs), then run_fetch -- bit for bit."""
+    from pydisort_amd import synthetic
+    C = 3000
+    cfg = synthetic.cfg4_columns_block(C, first=123)
+    tau = np.concatenate((np.zeros((C, 1)), cfg["tau_arr"]), axis=1)
+    phi = np.array([0.0, np.pi / 2, np.pi])
+    results = {}
+    for mode in ("pipelined", "serial"):
+        if mode == "serial":
+            os.environ["RTD_NO_PIPELINE"] = "1"
+        try:
+            _, sol = amd.pydisort_batch(work_columns=256, _defer_solve=True, **cfg)
+        finally:
+            os.environ.pop("RTD_NO_PIPELINE", None)
+        plan = sol.plan
+        assert plan.windows() == (256, 12)
+        plan.set_eval_points(tau, phi)
+        for _ in range(3):
+            plan.run()
+        a = plan.fetch()
+        b = plan.run_fetch()
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (mode, k)
+        results[mode] = a
+        plan.close()
+    for k in results["serial"]:
+        assert np.array_equal(results["pipelined"][k], results["serial"][k]), k
+    assert np.all(np.isfinite(results["pipelined"]["u"])) and np.all(results["pipelined"]["flux_up"][:, 0] > 0)  # (black surface: 0 at the bottom)
+
+
+@pytest.mark.gpu
 def test_cfg5_windowed_plan_equals_single_window(amd):
     """The 64-stream path (eigen kernel at NP = 32, tiled fused boundary-condition kernel, 2-mode BDRF, thermal source) through
     a plan of several windows, the last one short: 22 cfg5 columns in windows of 8 -- interface points (the fused evaluation
