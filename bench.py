@@ -70,6 +70,31 @@ def measured_traffic(kernel, columns_per_launch):
         return None
 
 
+def north_star_evidence(columns_per_launch, seconds_per_window):
+    """The north star asks for "rocprof HBM GB/s and MFMA utilisation against peak": MEASURED traffic (not algorithmic: the
+    path is compute-bound) of all kernels of a window from the committed PMC passes over this run's time per
+    window, and the matrix-pipe / vector-issue busy fractions of the two main kernels from the same passes."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+            rec = json.load(f)
+        if int(rec.get("columns_per_launch", 0)) != int(columns_per_launch):
+            return None
+        total = float(rec["total_hbm_bytes_per_step"])
+        out = {"hbm_bytes_per_window": total, "hbm_GB_per_s": total / seconds_per_window / 1e9,
+               "frac_of_8_TB_per_s": total / seconds_per_window / 8e12,
+               "what": "measured traffic (FETCH_SIZE x 2 + WRITE_SIZE of every kernel of a window, profiles/r03_pmc_traffic.json) / "
+                       "this run's time per window; NOT algorithmic bytes (22.5 KB per column: 0.003 % of 8 TB/s)"}
+        for k, name in (("rtd_eigen_kernel", "eigen"), ("rtd_bc_mfma_kernel", "bc")):
+            v = rec["kernels"][k]
+            simd_cycles = v["SQ_BUSY_CYCLES"] / 32.0 * 1024.0
+            out[name + "_kernel"] = {"mfma_busy_frac": v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / simd_cycles,
+                                     "valu_issue_frac": 4.0 * v["SQ_INSTS_VALU"] / simd_cycles,
+                                     "hbm_bytes_per_launch": v["hbm_bytes_per_launch"]}
+        return out
+    except Exception:
+        return None
+
+
 # ---------------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (NumPy/SciPy restatement of the reference, same LAPACK calls) on the host cores
 # ---------------------------------------------------------------------------------------------------------
@@ -621,6 +646,9 @@ def run_rank(a, rank, world, local):
                             "traffic = HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes at this "
                             "window size (profiles/r03_pmc_traffic.json), not measured in this run")
             out["roofline"] = roof
+            ev = north_star_evidence(a.columns, elapsed / a.steps / max(nwin, 1))
+            if ev:
+                out["measured_hbm_and_mfma"] = ev
         out["cpu_baseline"] = cpu
         out.update(extras)
         sys.stdout.flush()
