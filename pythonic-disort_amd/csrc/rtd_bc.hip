@@ -1025,18 +1025,37 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
       for (int q = 0; q < 4; ++q) he[q] = tb[q] * e0c;
       const v4f64 hcur = {tb[0], tb[1], tb[2], tb[3]};
       const double tnew = rt - e0c * (tv - col_dot(hcur, col_to_row(rb, rowbase, kq)));  // t' = rho_t - E (s - S rho_b)
+      // The transposes M1^T = Y'^T A_l and M2s^T come through LDS (the save area is free once the elimination is over), not
+      // from a second MFMA chain: FP64 MFMAs and FP64 vector instructions share the DP ALUs on gfx950
+      // (tools/hiptests/dp_coissue.hip), so the 8 MFMAs were 512 cycles of the very resource the kernel is short of.
+#ifndef RTD_BC_LDS_TRANSPOSE
+#define RTD_BC_LDS_TRANSPOSE 1
+#endif
+      auto transposed = [&](const v4f64& mm, const v4f64& x, const v4f64& y) -> v4f64 {  // mm = x^T y  ->  y^T x
+        if constexpr (!RTD_BC_LDS_TRANSPOSE) return mm_t(y, x);
+        double* const sT17 = &sSaveFlat[0];  // 16 rows of 17 doubles
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sT17[(4 * q + kq) * 17 + col] = mm[q];
+        __syncthreads();
+        v4f64 t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = sT17[col * 17 + 4 * q + kq];
+        __syncthreads();
+        return t;
+      };
       v4f64 s1;  // X + M1^T
       {
         const v4f64 m1 = mm_t(a0, y1);
         const v4f64 xx = mm_t(m1, he);
-        const v4f64 m1t = mm_t(y1, a0);
+        const v4f64 m1t = transposed(m1, a0, y1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) s1[q] = xx[q] + m1t[q];
       }
       {
         const v4f64 m2s = mm_t(y0, a1s);
         const v4f64 zz = mm_t(m2s, he);
-        const v4f64 m2st = mm_t(a1s, y0);
+        const v4f64 m2st = transposed(m2s, y0, a1s);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const double dd = zz[q] - m2st[q];
@@ -1834,11 +1853,32 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
       for (int J = 0; J < T; ++J)
 #pragma unroll
         for (int q = 0; q < 4; ++q) he.t[I][J][q] = tb.t[I][J][q] * e0c.c[J];
+    // the transposes M1^T, M2s^T through the (now free) save area instead of a second MFMA chain each: FP64 MFMAs occupy the
+    // DP ALUs the vector instructions need (tools/hiptests/dp_coissue.hip); at T = 2 they were 64 of the 192 MFMAs of a layer
+    auto transposedT = [&](const MatT<T>& mm) {
+      MatT<T> t;
+      __syncthreads();
+#pragma unroll
+      for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int J = 0; J < T; ++J)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sM[(16 * I + 4 * q + kq) * LDM + 16 * J + col] = mm.t[I][J][q];
+      __syncthreads();
+#pragma unroll
+      for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int J = 0; J < T; ++J)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t.t[I][J][q] = sM[(16 * J + col) * LDM + 16 * I + 4 * q + kq];
+      __syncthreads();
+      return t;
+    };
     MatT<T> s1;  // X + M1^T
     {
       const MatT<T> m1 = mmT<T>(a0, y1);
       const MatT<T> xx = mmT<T>(m1, he);
-      const MatT<T> m1t = mmT<T>(y1, a0);
+      const MatT<T> m1t = transposedT(m1);
 #pragma unroll
       for (int I = 0; I < T; ++I)
 #pragma unroll
@@ -1849,7 +1889,7 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
     {
       const MatT<T> m2s = mmT<T>(y0s, a1s);
       const MatT<T> zz = mmT<T>(m2s, he);
-      const MatT<T> m2st = mmT<T>(a1s, y0s);
+      const MatT<T> m2st = transposedT(m2s);
 #pragma unroll
       for (int I = 0; I < T; ++I)
 #pragma unroll
