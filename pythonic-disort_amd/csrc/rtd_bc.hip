@@ -709,7 +709,7 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
   // Timing experiment (RTD_BC_ALIAS=1 | 2 | 3, results are garbage): the chains read the eigen stage's hand-off of only 32
   // chains (bit 0: 2.6 MB, served by the L2s) or of 2 048 chains (bit 1: 168 MB, served by the Infinity Cache); with both
   // bits the factors H, s, rho_b of the forward sweep are aliased to 32 chains as well.  What the kernel takes then is
-  // the floor that any scheme for cutting its HBM traffic can approach (profiles/r03_bc_traffic_floor.json).
+  // the floor that any scheme for cutting its HBM traffic can approach (profiles/r03_experiments.json: bc_traffic_floor).
   const long cmr = (d.flags & 4) ? cm % 32 : (d.flags & 8) ? cm % 2048 : cm;
   const long cmw = ((d.flags & 12) == 12) ? cm % 32 : cm;
   const double* Ym = d.Ym + cmr * L * NN;
