@@ -220,9 +220,10 @@ int rtd_comm_unique_id(char id[128]);
 int rtd_comm_init(rtd_plan* plan, const char id[128], int32_t rank, int32_t nranks);
 int rtd_comm_allgather_fluxes(rtd_plan* plan);               /* asynchronous on the plan's stream */
 int rtd_comm_fetch_gathered(rtd_plan* plan, double* out);    /* host [nranks][3][C][ntau] */
-/* u AND fluxes of the last rtd_plan_run: two ncclAllGather on the plan's communication stream, ordered after the run by
- * an event, so that the next rtd_plan_run overlaps them (its evaluation kernel, which overwrites the results, waits for
- * the gather).  rtd_plan_synchronize waits for both streams. */
+/* u AND fluxes of the last rtd_plan_run: the rank's results are snapshot into its own slot of the gathered arrays (device
+ * copy on the plan's stream), then two IN-PLACE ncclAllGather run from there on the plan's communication stream, ordered
+ * after the copy by an event: the next rtd_plan_run overlaps them completely (nothing of it waits for the collective; the
+ * next gather's snapshot does, a whole step later).  rtd_plan_synchronize waits for both streams. */
 int rtd_comm_allgather_results(rtd_plan* plan);
 /* The same results gathered on ONE rank only ("if only rank 0 needs results"): the other ranks
  * ncclSend their u and fluxes, `root` ncclRecv's them into the layout of rtd_comm_allgather_results (one group call on

@@ -333,10 +333,7 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
     }
     mark(6);
     if (ev) {
-      if (w == 0 && p->gather_inflight) {  // the previous run's results are still being gathered from these buffers
-        (void)hipStreamWaitEvent(s, p->ev_gathered, 0);
-        p->gather_inflight = false;
-      }
+      // (a gather of the previous run's results may still be in flight: it reads its own snapshot, not these buffers)
       RtdEval e = window_eval(p, *ev, c0);
       e.um_in = fused ? p->um_buf : nullptr;
       rtd_launch_eval(d, e, s);
@@ -1248,13 +1245,22 @@ int rtd_comm_allgather_results(rtd_plan* p) {
   if (!p->comm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking));
   if (!p->ev_results) HIP_TRY(hipEventCreateWithFlags(&p->ev_results, hipEventDisableTiming));
   if (!p->ev_gathered) HIP_TRY(hipEventCreateWithFlags(&p->ev_gathered, hipEventDisableTiming));
-  // the gather starts when the run that produced the results is done, and runs beside the next run's kernels
+  // The rank's own results are first copied (device to device, on the plan's stream, behind the run that produced them) into
+  // this rank's slot of the gathered arrays, and the all-gather runs IN PLACE from there on the communication stream: the
+  // result buffers are free at once, so the next run's evaluation kernels never wait for the collective (with windows of
+  // 256 columns only ~1 ms of the next run precedes its first evaluation kernel: waiting there would expose most of the
+  // gather).  The copy of the NEXT gather waits for this gather (one whole step later).
+  if (p->gather_inflight) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_gathered, 0));
+  double* const my_u = p->gathered_u + (int64_t)p->comm_rank * nu;
+  double* const my_fl = p->gathered_fl + (int64_t)p->comm_rank * nfl;
+  if (nu > 0) HIP_TRY(hipMemcpyAsync(my_u, p->ev_u, (size_t)nu * 8, hipMemcpyDeviceToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(my_fl, p->ev_fl, (size_t)nfl * 8, hipMemcpyDeviceToDevice, p->stream));
   HIP_TRY(hipEventRecord(p->ev_results, p->stream));
   HIP_TRY(hipStreamWaitEvent(p->comm_stream, p->ev_results, 0));
   RcclApi* r = rccl();
   ncclResult_t nr = ncclSuccess;
-  if (nu > 0) nr = r->AllGather(p->ev_u, p->gathered_u, (size_t)nu, ncclDouble, p->comm, p->comm_stream);
-  if (nr == ncclSuccess) nr = r->AllGather(p->ev_fl, p->gathered_fl, (size_t)nfl, ncclDouble, p->comm, p->comm_stream);
+  if (nu > 0) nr = r->AllGather(my_u, p->gathered_u, (size_t)nu, ncclDouble, p->comm, p->comm_stream);
+  if (nr == ncclSuccess) nr = r->AllGather(my_fl, p->gathered_fl, (size_t)nfl, ncclDouble, p->comm, p->comm_stream);
   if (nr != ncclSuccess) return fail(RTD_ERR_HIP, std::string("ncclAllGather: ") + r->GetErrorString(nr));
   HIP_TRY(hipEventRecord(p->ev_gathered, p->comm_stream));
   p->gather_inflight = true;
@@ -1272,13 +1278,20 @@ int rtd_comm_gather_results(rtd_plan* p, int32_t root) {
   const int64_t nu = np > 0 ? C * Qr * nt * np : 0, nfl = 3 * C * nt;
   const bool is_root = p->comm_rank == root;
   int rc;
-  if (is_root) {  // only the root holds the gathered arrays
-    if ((rc = grow(p, &p->gathered_u, &p->cap_gathered_u, std::max<int64_t>(nu, 1) * p->comm_size))) return rc;
-    if ((rc = grow(p, &p->gathered_fl, &p->cap_gathered_fl, nfl * p->comm_size))) return rc;
-  }
+  // the root holds the gathered arrays; the other ranks one shard of each, as the send buffer (a snapshot of their results)
+  const int64_t slots = is_root ? p->comm_size : 1;
+  if ((rc = grow(p, &p->gathered_u, &p->cap_gathered_u, std::max<int64_t>(nu, 1) * slots))) return rc;
+  if ((rc = grow(p, &p->gathered_fl, &p->cap_gathered_fl, nfl * slots))) return rc;
   if (!p->comm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking));
   if (!p->ev_results) HIP_TRY(hipEventCreateWithFlags(&p->ev_results, hipEventDisableTiming));
   if (!p->ev_gathered) HIP_TRY(hipEventCreateWithFlags(&p->ev_gathered, hipEventDisableTiming));
+  // as rtd_comm_allgather_results: the rank's results are snapshot on the plan's stream (the root: into its own slot), the
+  // transfers read the snapshot, the next run's evaluation kernels do not wait for them
+  if (p->gather_inflight) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_gathered, 0));
+  double* const my_u = p->gathered_u + (is_root ? (int64_t)root * nu : 0);
+  double* const my_fl = p->gathered_fl + (is_root ? (int64_t)root * nfl : 0);
+  if (nu > 0) HIP_TRY(hipMemcpyAsync(my_u, p->ev_u, (size_t)nu * 8, hipMemcpyDeviceToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(my_fl, p->ev_fl, (size_t)nfl * 8, hipMemcpyDeviceToDevice, p->stream));
   HIP_TRY(hipEventRecord(p->ev_results, p->stream));
   HIP_TRY(hipStreamWaitEvent(p->comm_stream, p->ev_results, 0));
   hipStream_t cs = p->comm_stream;
@@ -1290,18 +1303,14 @@ int rtd_comm_gather_results(rtd_plan* p, int32_t root) {
       if (nr == ncclSuccess) nr = r->Recv(p->gathered_fl + q * nfl, (size_t)nfl, ncclDouble, q, p->comm, cs);
     }
   } else {
-    if (nu > 0) nr = r->Send(p->ev_u, (size_t)nu, ncclDouble, root, p->comm, cs);
-    if (nr == ncclSuccess) nr = r->Send(p->ev_fl, (size_t)nfl, ncclDouble, root, p->comm, cs);
+    if (nu > 0) nr = r->Send(my_u, (size_t)nu, ncclDouble, root, p->comm, cs);
+    if (nr == ncclSuccess) nr = r->Send(my_fl, (size_t)nfl, ncclDouble, root, p->comm, cs);
   }
   ncclResult_t ne = r->GroupEnd();
   if (nr == ncclSuccess) nr = ne;
   if (nr != ncclSuccess) return fail(RTD_ERR_HIP, std::string("ncclSend / ncclRecv: ") + r->GetErrorString(nr));
-  if (is_root) {  // the root's own shard: a device copy on the same stream
-    if (nu > 0) HIP_TRY(hipMemcpyAsync(p->gathered_u + root * nu, p->ev_u, (size_t)nu * 8, hipMemcpyDeviceToDevice, cs));
-    HIP_TRY(hipMemcpyAsync(p->gathered_fl + root * nfl, p->ev_fl, (size_t)nfl * 8, hipMemcpyDeviceToDevice, cs));
-  }
   HIP_TRY(hipEventRecord(p->ev_gathered, cs));
-  p->gather_inflight = true;  // the next run's evaluation kernel, which overwrites the results, waits for this
+  p->gather_inflight = true;
   return 0;
 }
 
@@ -1310,6 +1319,8 @@ int rtd_comm_fetch_gathered_results(rtd_plan* p, double* u, double* fluxes) {
   HIP_TRY(hipSetDevice(p->device));
   const int64_t C = p->d.C, Qr = 2 * p->d.N, nt = p->ev_ntau, np = p->ev_nphi;
   const int64_t nu = np > 0 ? C * Qr * nt * np : 0, nfl = 3 * C * nt;
+  if (p->cap_gathered_fl < nfl * p->comm_size || (u && nu > 0 && p->cap_gathered_u < nu * p->comm_size))
+    return fail(RTD_ERR_STATE, "this rank holds no gathered arrays (rtd_comm_gather_results: only the root does)");
   hipStream_t s = p->comm_stream;
   if (u && nu > 0) HIP_TRY(hipMemcpyAsync(u, p->gathered_u, (size_t)(nu * p->comm_size) * 8, hipMemcpyDeviceToHost, s));
   if (fluxes) HIP_TRY(hipMemcpyAsync(fluxes, p->gathered_fl, (size_t)(nfl * p->comm_size) * 8, hipMemcpyDeviceToHost, s));
