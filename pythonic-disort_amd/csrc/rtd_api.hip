@@ -505,14 +505,8 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   if (p->pipelined) {
     HIP_TRY(hipMemsetAsync(h1.Bv, 0, (size_t)(Cw * M * L * Q2) * 8, p->stream));
     if (Ns > 0) HIP_TRY(hipMemsetAsync(h1.dq, 0, (size_t)(Cw * L * Ns * Q2) * 8, p->stream));
-    {  // RTD_PIPE_PRIO=eig | bc: give that stage's stream the higher dispatch priority (experiments; default: equal)
-      const char* pr = getenv("RTD_PIPE_PRIO");
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent (numerically largest), hi = most urgent
-      if (pr && pr[0] == 'e') HIP_TRY(hipStreamCreateWithPriority(&p->eig_stream, hipStreamNonBlocking, hi));
-      else if (pr && pr[0] == 'b') HIP_TRY(hipStreamCreateWithPriority(&p->eig_stream, hipStreamNonBlocking, lo));
-      else HIP_TRY(hipStreamCreateWithFlags(&p->eig_stream, hipStreamNonBlocking));
-    }
+    // (stream priorities either way changed nothing: profiles/r03_experiments.json)
+    HIP_TRY(hipStreamCreateWithFlags(&p->eig_stream, hipStreamNonBlocking));
     for (hipEvent_t* e : {&p->ev_eig[0], &p->ev_eig[1], &p->ev_bc[0], &p->ev_bc[1], &p->ev_fork})
       HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
