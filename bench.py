@@ -70,7 +70,7 @@ def measured_traffic(kernel, columns_per_launch):
         return None
 
 
-def north_star_evidence(columns_per_launch, seconds_per_window):
+def north_star_evidence(columns_per_launch, seconds_per_window, live=None):
     """The north star asks for "rocprof HBM GB/s and MFMA utilisation against peak": MEASURED traffic (not algorithmic: the
     path is compute-bound) of all kernels of a window from the committed PMC passes over this run's time per
     window, and the matrix-pipe / vector-issue busy fractions of the two main kernels from the same passes."""
@@ -79,8 +79,8 @@ def north_star_evidence(columns_per_launch, seconds_per_window):
             rec = json.load(f)
         if int(rec.get("columns_per_launch", 0)) != int(columns_per_launch):
             return None
-        total = float(rec["total_hbm_bytes_per_step"])
-        out = {"hbm_bytes_per_window": total, "hbm_GB_per_s": total / seconds_per_window / 1e9,
+        total = float(sum(live.values())) if live else float(rec["total_hbm_bytes_per_step"])
+        out = {"hbm_bytes_per_window": total, "traffic_measured_in_this_run": bool(live), "hbm_GB_per_s": total / seconds_per_window / 1e9,
                "frac_of_8_TB_per_s": total / seconds_per_window / 8e12,
                "what": "measured traffic (FETCH_SIZE x 2 + WRITE_SIZE of every kernel of a window, profiles/r03_pmc_traffic.json) / "
                        "this run's time per window; NOT algorithmic bytes (22.5 KB per column: 0.003 % of 8 TB/s)"}
@@ -187,6 +187,68 @@ def cpu_baseline_subprocess():
     global _ORACLE_SAMPLES
     _ORACLE_SAMPLES = [(int(f), np.array(u)) for f, u in res.pop("_samples")]
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------
+# live HBM traffic: rocprofv3 --pmc passes over a short child run of the same workload (before this process touches a GPU)
+# ---------------------------------------------------------------------------------------------------------
+def pmc_child(columns):
+    """The workload of the traffic passes: one warm-up and one measured step of 32 windows, windows one after the other
+    (a kernel's counters are its own).  No output."""
+    from pydisort_amd import synthetic
+    from pydisort_amd._engine import Plan
+    from pydisort_amd._prepare import prepare_columns
+    C, N = 32 * columns, NQUAD // 2
+    cfg = synthetic.cfg4_columns_block(C, first=0)
+    prep = prepare_columns(cfg["tau_arr"], cfg["omega_arr"], NQUAD, cfg["Leg_coeffs_all"], cfg["mu0"], cfg["I0"], cfg["phi0"], NQUAD,
+                           NQUAD, None, None, cfg["f_arr"], np.zeros((C, L, 0)), np.zeros((C, 0, N, N)), np.zeros((C, 0, N)))
+    plan = Plan(prep, device=0, work_columns=columns)
+    plan.set_eval_points(np.concatenate((np.zeros((C, 1)), cfg["tau_arr"]), axis=1), np.array([0.0, np.pi / 2, np.pi]))
+    for _ in range(2):
+        plan.run()
+    plan.synchronize()
+    plan.close()
+
+
+def live_traffic(columns, timeout=150):
+    """HBM bytes per launch of the two main kernels, measured NOW: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE cannot
+    share one) of `bench.py --pmc-child`, corrected as MI355X_MICROARCH.md prescribes (KiB units; FETCH_SIZE doubled on
+    gfx950).  Returns {kernel: bytes per launch} or None when rocprofv3 is not usable here."""
+    import csv
+    import re
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    env = dict(os.environ, RTD_NO_PIPELINE="1", TMPDIR="/tmp")
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = tempfile.mkdtemp(prefix="rtd_pmc_", dir="/tmp")
+            try:
+                r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--columns", str(columns)],
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+                files = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
+                if r.returncode != 0 or not files:
+                    print(f"[bench] live traffic pass {counter} failed (rc {r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
+                    return None
+                acc = {}
+                with open(files[0]) as f:
+                    for row in csv.DictReader(f):
+                        m = re.search(r"rtd_\w+", row["Kernel_Name"])
+                        if m and row["Counter_Name"] == counter:
+                            acc.setdefault(m.group(0), []).append(float(row["Counter_Value"]))
+                for k, v in acc.items():
+                    v = v[len(v) // 2:]  # the second (measured) step
+                    got.setdefault(k, {})[counter] = sum(v) / len(v)
+            finally:
+                shutil.rmtree(out, ignore_errors=True)
+    except Exception as e:  # profiler missing, timeout, unreadable output: the committed passes are used instead
+        print(f"[bench] live traffic unavailable: {e!r}", file=sys.stderr)
+        return None
+    return {k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in got.items() if len(v) == 2} or None
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -469,6 +531,9 @@ def run_rank(a, rank, world, local):
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not stub:
         cpu = cpu_baseline_subprocess()
+    live = None
+    if rank == 0 and world == 1 and not a.no_extras and not a.no_live_traffic and not stub:
+        live = live_traffic(a.columns)  # before this process touches the GPU (the profiler runs a child of its own)
 
     first, C = shard_columns(rank, world, a.columns, a.total_columns)
     strong = a.total_columns > 0
@@ -634,7 +699,12 @@ def run_rank(a, rank, world, local):
             cols_per_launch = C / nwin  # average over the windows of a step (the last one may be short)
             roof, ms = roofline_of(stage, fl, cols_per_launch, names)
             tkey = {"rtd_eigen_kernel<16, 2>": "rtd_eigen_kernel", "rtd_bc_mfma_kernel": "rtd_bc_mfma_kernel"}.get(roof["kernel"], "rtd_sweep_kernel")
-            roof["traffic"] = measured_traffic(tkey, a.columns)
+            roof["traffic"] = live.get(tkey) if live and tkey in live else measured_traffic(tkey, a.columns)
+            roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation (child process, "
+                                      "32 windows, windows one after the other)" if live and tkey in live else
+                                      "profiles/r03_pmc_traffic.json (committed passes)")
+            if live:
+                roof["traffic_all_kernels_per_window"] = float(sum(live.values()))
             roof["launches_per_step"] = nwin
             roof["whole_path_tflops"] = fl["total"] * value / world / 1e12
             roof["whole_path_frac"] = fl["total"] * value / world / 1e12 / FP64_PEAK_TFLOPS
@@ -646,7 +716,7 @@ def run_rank(a, rank, world, local):
                             "traffic = HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes at this "
                             "window size (profiles/r03_pmc_traffic.json), not measured in this run")
             out["roofline"] = roof
-            ev = north_star_evidence(a.columns, elapsed / a.steps / max(nwin, 1))
+            ev = north_star_evidence(a.columns, elapsed / a.steps / max(nwin, 1), live)
             if ev:
                 out["measured_hbm_and_mfma"] = ev
         out["cpu_baseline"] = cpu
@@ -676,8 +746,14 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the parity, only_flux and end-to-end legs (profiling runs: every kernel launch is then the workload)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the multi-rank code path even with one rank")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="take roofline.traffic from the committed PMC passes instead of two rocprofv3 passes of a child run (~20 s)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.pmc_child:  # child of live_traffic(), under rocprofv3: the workload only
+        pmc_child(a.columns)
+        return
     if a.cpu_baseline_only:  # child of cpu_baseline_subprocess(): no GPU, one JSON line
         res = cpu_baseline()
         res["_samples"] = [(int(f), u.tolist()) for f, u in _ORACLE_SAMPLES]
