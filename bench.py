@@ -221,6 +221,8 @@ def live_traffic(columns, timeout=150):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None  # this process is being profiled itself: no profiler inside a profiler
     env = dict(os.environ, RTD_NO_PIPELINE="1", TMPDIR="/tmp")
     got = {}
     try:
