@@ -154,8 +154,8 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
 
 def solve_columns_streamed(cfg, tau, phi, chunk_columns=0, device=0, only_flux=False, out=None):
     """Throughput form for large column counts: ONE plan holds the inputs and the results of all columns, the
-    intermediates of the solve (~8 MB per cfg4 column) live for `chunk_columns` columns at a time (0: sized by the
-    library) and the device-to-host copies of a window overlap the kernels of the next (``Plan.run_fetch``).
+    intermediates of the solve (~8 MB per cfg4 column) live for `chunk_columns` columns at a time (0: ~8 192 (column,
+    mode) chains per window) and the device-to-host copies of a window overlap the kernels of the next (``Plan.run_fetch``).
     Source terms are taken from the whole batch (a beam or a thermal source in any column switches it on for all).
 
     cfg : dict of ``pydisort_batch`` keyword arguments with a leading column axis (tau_arr, omega_arr, Leg_coeffs_all,
@@ -165,6 +165,12 @@ def solve_columns_streamed(cfg, tau, phi, chunk_columns=0, device=0, only_flux=F
     Returns dict(u [C, NQuad, ntau, nphi] (absent when only_flux), u0, flux_up, flux_down_diffuse, flux_down_direct)."""
     tau = np.ascontiguousarray(np.asarray(tau, float))
     C, ntau = tau.shape
+    if chunk_columns <= 0:
+        # windows of ~8 192 (column, mode) chains: the two-stream window pipeline of the library does best there (256 cfg4
+        # columns: +4 % over windows of 2 048, DESIGN.md section 7b); the library caps it by its memory budget
+        nq = int(cfg["NQuad"])
+        modes = 1 if only_flux else int(cfg.get("NFourier") or cfg.get("NLeg") or nq)
+        chunk_columns = max(64, 8192 // max(modes, 1))
     _, sol = pydisort_batch(only_flux=only_flux, device=device, work_columns=chunk_columns, device_prepare=True,
                             _defer_solve=True, **cfg)
     plan = sol.plan
