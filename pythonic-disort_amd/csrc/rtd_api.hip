@@ -121,6 +121,11 @@ struct rtd_plan {
   // `stream`.  The eigen kernel is bound by vector-instruction issue, the boundary-condition kernel by the latency of its
   // dependent chains: wavefronts of both kinds resident on a SIMD fill each other's bubbles (profiles/r03_window_pipeline.json).
   struct HandOff { double *Y0, *att, *Ym, *Am, *kk, *Bv, *dq, *zneg, *Ek; } slot1{};
+  // Legendre tables at -mu0 and beam attenuations of ALL columns, kept from run to run (they depend on the inputs and the
+  // mode shard only): one launch after the inputs change instead of one per window and run (19 us of 1.17 ms per 256-column
+  // cfg4 window).  Plans of one window keep them in d.Y0 / d.att; larger plans in these arrays when C M P doubles fit 2 GiB.
+  double *Y0_all = nullptr, *att_all = nullptr;
+  bool tables_cached = false, tables_valid = false;
   bool pipelined = false;
   bool fork_needed = true;               // inputs were (re)uploaded on `stream` since the last solve: the eigen stream must wait for them
   bool bc_recorded[2] = {false, false};  // ev_bc[slot] has been recorded by some earlier window (possibly of an earlier run)
@@ -231,6 +236,10 @@ RtdDev window_dev(const rtd_plan* p, int64_t c0, int cnt, int slot = 0) {
     const rtd_plan::HandOff& h = p->slot1;
     w.Y0 = h.Y0; w.att = h.att; w.Ym = h.Ym; w.Am = h.Am; w.kk = h.kk; w.Bv = h.Bv; w.dq = h.dq; w.zneg = h.zneg; w.Ek = h.Ek;
   }
+  if (p->tables_cached) {  // the window's part of the all-columns tables
+    w.Y0 = p->Y0_all + c0 * (int64_t)p->d.M * p->d.P;
+    w.att = p->att_all + c0 * ((int64_t)p->d.L + 1);
+  }
   const int64_t L = w.L, M = w.M, P = w.P, NP = w.NP, Ns = w.Ns, NB = w.NBDRF;
   w.C = cnt;
   w.omega += c0 * L; w.tau += c0 * L; w.taus0 += c0 * (L + 1); w.scale += c0 * L; w.wleg += c0 * L * P;
@@ -288,13 +297,21 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
     if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
     p->numeric_status = 0;  // a new solve starts clean
   }
+  if (with_solve && p->tables_cached && !p->tables_valid) {  // the tables of all columns, once per change of the inputs
+    RtdDev all = p->d;
+    all.Y0 = p->Y0_all;
+    all.att = p->att_all;
+    rtd_launch_tables(all, se, true);
+    p->tables_valid = true;
+  }
+  const bool per_window_tables = !p->tables_cached;
   auto eigen_stage = [&](int w) {  // tables + eigen kernel of window w into hand-off slot w & 1, on the eigen stream
     const int64_t c0 = (int64_t)w * p->Cw;
     const int cnt = (int)std::min<int64_t>(p->Cw, p->d.C - c0);
     const int slot = w & 1;
     RtdDev d = window_dev(p, c0, cnt, slot);
     if (p->bc_recorded[slot]) (void)hipStreamWaitEvent(se, p->ev_bc[slot], 0);  // the slot's previous tenant has been consumed
-    rtd_launch_tables(d, se, w == 0);
+    if (per_window_tables) rtd_launch_tables(d, se, w == 0);
     rtd_launch_eig(d, se, 1);
     (void)hipEventRecord(p->ev_eig[slot], se);
   };
@@ -319,7 +336,7 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
       rtd_launch_bc(d, s, 1);
     } else if (with_solve) {
       mark(0);
-      rtd_launch_tables(d, s, w == 0);
+      if (per_window_tables) rtd_launch_tables(d, s, w == 0);
       mark(1);
       rtd_launch_eig(d, s, 0);
       mark(2);
@@ -497,6 +514,16 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   d.omega = omega; d.tau = tau; d.taus0 = taus0; d.scale = scale; d.wleg = wleg;
   d.mu0 = mu0; d.I0 = I0; d.phi0 = phi0; d.rescale = rescale; d.bpos = bpos; d.bneg = bneg;
   d.spoly = spoly; d.bdrfq = bq; d.bdrfq0 = bq0; d.lperm = lperm;
+  if (p->nwin == 1) {
+    p->Y0_all = d.Y0;
+    p->att_all = d.att;
+    p->tables_cached = true;
+  } else if ((double)C * (double)(M * P + L + 1) * 8.0 <= 2.0 * (double)(1ull << 30)) {
+    int rc;
+    if ((rc = p->alloc(&p->Y0_all, C * M * P))) return rc;
+    if ((rc = p->alloc(&p->att_all, C * (L + 1)))) return rc;
+    p->tables_cached = true;
+  }
   HIP_TRY(hipMemsetAsync(d.status, 0, sizeof(int), p->stream));
   HIP_TRY(hipMemsetAsync(d.sweeps, 0, sizeof(int), p->stream));
   HIP_TRY(hipMemsetAsync(d.split_any, 0, sizeof(int), p->stream));
@@ -615,6 +642,7 @@ int rtd_plan_set_quadrature(rtd_plan* p, const double* mu_pos, const double* wei
   HIP_TRY(hipStreamSynchronize(p->stream));
   p->have_quad = true;
   p->fork_needed = true;
+  p->tables_valid = false;
   p->solved = false;
   return 0;
 }
@@ -700,6 +728,7 @@ int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* 
   p->ev_iface = false;  // stored evaluation points, if any, are no longer known to be this batch's interfaces
   p->have_cols = true;
   p->fork_needed = true;
+  p->tables_valid = false;
   p->solved = false;
   return 0;
 }
@@ -765,6 +794,7 @@ int rtd_plan_set_columns_raw(rtd_plan* p, const double* tau_arr, const double* o
   p->ev_iface = false;
   p->have_cols = true;
   p->fork_needed = true;
+  p->tables_valid = false;
   p->solved = false;
   return 0;
 }
@@ -807,6 +837,7 @@ int rtd_plan_set_mode_shard(rtd_plan* p, int32_t first, int32_t stride, int32_t 
   d.mstep = stride;
   d.mtot = total;
   p->solved = false;
+  p->tables_valid = false;
   return 0;
 }
 
@@ -1025,7 +1056,7 @@ int rtd_plan_get_tensors(rtd_plan* p, int32_t column, double* GC, double* K, dou
   if (p->nwin > 1) {  // the column is solved again on its own (its window's intermediates may have been overwritten)
     d = window_dev(p, column, 1);
     local = 0;
-    rtd_launch_tables(d, s, false);
+    if (!p->tables_cached || !p->tables_valid) rtd_launch_tables(d, s, false);
     for (int part = 0; part < 3; ++part) rtd_launch_eig(d, s, part);
     for (int part = 0; part < 2; ++part) rtd_launch_bc(d, s, part);
   }
@@ -1369,6 +1400,7 @@ int rtd_plan_solve_layers(rtd_plan* p, int32_t first, int32_t count) {
   HIP_TRY(hipMemsetAsync(d.status, 0, sizeof(int), p->stream));  // as launch_windows: a new solve starts clean
   p->numeric_status = 0;
   rtd_launch_tables(d, p->stream, true);
+  p->tables_valid = true;  // (one-window plan: d.Y0 / d.att are the all-columns tables)
   rtd_launch_eig(d, p->stream, 1);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
