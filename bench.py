@@ -250,7 +250,9 @@ def live_traffic(columns, timeout=150):
     except Exception as e:  # profiler missing, timeout, unreadable output: the committed passes are used instead
         print(f"[bench] live traffic unavailable: {e!r}", file=sys.stderr)
         return None
-    return {k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in got.items() if len(v) == 2} or None
+    # (the table kernels run once per change of the inputs, not per window: they are not part of a window's traffic)
+    return {k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in got.items()
+            if len(v) == 2 and not k.startswith("rtd_tables")} or None
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -25,7 +25,8 @@ total = 0.0
 for name, k in kern.items():
     if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
         k["hbm_bytes_per_launch"] = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
-        total += k["hbm_bytes_per_launch"]
+        if not name.startswith("rtd_tables"):  # the table kernels run once per change of the inputs, not per window
+            total += k["hbm_bytes_per_launch"]
 json.dump({"source": desc,
            "correction": "FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE doubled (gfx950 reports half of the bytes of "
                          "coalesced streaming reads); separate --pmc passes for FETCH_SIZE and WRITE_SIZE",
