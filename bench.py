@@ -340,6 +340,38 @@ def config_leg(name, golden, maker, kwargs, columns, window, device, passes):
             "parity": golden_parity(golden, maker, kwargs, device)}
 
 
+def single_column_leg(device, calls=30):
+    """BASELINE configs[1] as worded: Test Problem 5 (Cloud C.1, 300 moments, one layer of optical depth 64, beam source) at
+    32 streams with delta-M and the Nakajima-Tanaka corrections, ONE column per call: latency of a whole `pydisort()` call
+    with the intensity evaluated at the golden points (host to host: checks, plan, upload, kernels, D2H), and parity against
+    the reference's output at that stream count (tests/golden/synth/cfg2_q32_cloud_b.npz)."""
+    import warnings
+    import pydisort_amd
+    z = np.load(os.path.join(ROOT, "tests", "golden", "synth", "cfg2_q32_cloud_b.npz"))
+    leg = z["Leg_coeffs_all"]
+    kw = dict(tau_arr=np.array([64.0]), omega_arr=z["omega"], NQuad=32, Leg_coeffs_all=leg, mu0=1.0, I0=np.pi, phi0=np.pi,
+              f_arr=np.array([leg[0, 32]]), NT_cor=True, device=device)
+    times = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(calls + 3):
+            t0 = time.perf_counter()
+            res = pydisort_amd.pydisort(**kw)
+            u = res[4](z["tau_pts"], z["phi"])
+            times.append(time.perf_counter() - t0)
+            res[1].__self__.plan.close()
+    times = sorted(times[3:])
+    want = z["u"]
+    diff = np.abs(u - want)
+    sig = np.abs(want) > 1e-8 * np.max(np.abs(want))
+    return {"value": 1.0 / times[len(times) // 2], "unit": "column-solves/sec", "latency_ms_median": 1e3 * times[len(times) // 2],
+            "latency_ms_min": 1e3 * times[0], "calls": calls,
+            "workload": "cfg2: Test Problem 5 (Cloud C.1, 300 moments, tau = 64, omega = 0.9, beam) at 32 streams, delta-M + "
+                        "Nakajima-Tanaka corrections, one column per pydisort() call, u at 7 depths x 3 azimuths, host to host",
+            "parity": {"max_scale_rel": float(diff.max() / np.max(np.abs(want))), "max_rel_dI": float((diff[sig] / np.abs(want[sig])).max()),
+                       "columns_checked": 1, "against": "reference-computed golden tests/golden/synth/cfg2_q32_cloud_b.npz"}}
+
+
 def extra_measurements(device, main_cfg=None, window=2048):
     """max |dI| of the HIP path against the oracle on the sample columns of the cpu_baseline leg, the only_flux
     throughput, the host-to-host rate of the main batch, and BASELINE's other configs."""
@@ -379,6 +411,7 @@ def extra_measurements(device, main_cfg=None, window=2048):
     plan.close()
     out["e2e"] = end_to_end(device, main_cfg, window)
     out["other_configs"] = {
+        "cfg2_cloudC1_Q32_single_column": single_column_leg(device),
         "cfg3_L6_Q8_x1024": config_leg("cfg3: Test Problem 9c (6 layers, 8 streams, thermal + beam + Lambertian surface) x 1024 perturbed columns",
                                        "cfg3_small", "cfg3_columns", {"big": False}, 1024, 0, device, 50),
         "cfg3_L8_Q16_x1024": config_leg("cfg3 at BASELINE's size (8 layers, 16 streams) x 1024 perturbed columns",

@@ -318,6 +318,40 @@ def test_full_size_properties(amd):
     assert np.all(np.diff(net, axis=1) < 1e-9)
 
 
+def test_baseline_batch_of_100000_columns_properties(amd):
+    """BASELINE.json configs[3] at its literal size (10^5 cfg4 columns, NumPy in -> NumPy out through the windowed,
+    pipelined path): everything finite, Beer's law for the direct beam, the net flux never grows with depth (omega < 1, no
+    thermal source), and the 64 golden columns -- spliced into the batch 1 500 columns apart, so that they fall into
+    different windows -- equal the reference's outputs and, bit for bit, what a 64-column call returns for them."""
+    from pydisort_amd import synthetic
+    C = 100_000
+    cfg = synthetic.cfg4_columns_block(C, first=0)
+    z = np.load(f"{goldens.HERE}/golden/synth/cfg4.npz")
+    ncol = int(z["ncol"])
+    gold = synthetic.cfg4_columns(ncol)
+    at = 7 + 1500 * np.arange(ncol)
+    for k, v in gold.items():
+        if isinstance(v, np.ndarray):
+            cfg[k][at] = v
+    tau = np.concatenate((np.zeros((C, 1)), cfg["tau_arr"]), axis=1)
+    phi = z["phi"][:3]
+    res = amd.solve_columns_streamed(cfg, tau, phi, chunk_columns=2048)
+    for k in ("u", "u0", "flux_up", "flux_down_diffuse", "flux_down_direct"):
+        assert np.all(np.isfinite(res[k])), k
+    assert np.allclose(res["flux_down_direct"], (cfg["I0"] * cfg["mu0"])[:, None] * np.exp(-tau / cfg["mu0"][:, None]), rtol=1e-13)
+    net = res["flux_down_diffuse"] + res["flux_down_direct"] - res["flux_up"]
+    assert np.all(np.diff(net, axis=1) < 1e-9)
+    assert np.all(res["flux_up"][:, 0] > 0)  # (u itself may dip below zero: delta-M without the NT corrections)
+    worst = 0.0
+    for i in range(ncol):  # the golden points are the interfaces and the mid-layer points: compare at the interfaces
+        pts = np.searchsorted(z[f"c{i}.tau_pts"], tau[at[i]])
+        assert np.array_equal(z[f"c{i}.tau_pts"][pts], tau[at[i]])
+        worst = max(worst, goldens.max_rel_err(res["u"][at[i]], z[f"c{i}.u"][:, pts, :3])[0])
+    assert worst < TOL, worst
+    small = amd.solve_columns_streamed(gold, tau[at], phi, chunk_columns=2048)
+    assert np.array_equal(small["u"], res["u"][at]) and np.array_equal(small["flux_up"], res["flux_up"][at])
+
+
 def test_tensors_match_oracle_invariants(amd):
     """The exported reference-layout tensors: K sorted, B, and the gauge-invariant product GC exp(K dtau)."""
     from oracle import disort_oracle as O
