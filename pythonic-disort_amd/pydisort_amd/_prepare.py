@@ -5,15 +5,25 @@ quadrature (:304-306), delta-M scaling (:316-338), source rescaling (:351-372) -
 leading column axis C.  Everything after this (eigen stage, boundary-condition solve, evaluation)
 runs on the GPU.
 """
+from functools import lru_cache
 from math import comb
 
 import numpy as np
 
 
+@lru_cache(maxsize=64)
+def _double_gauss_cached(N):
+    x, w = np.polynomial.legendre.leggauss(N)
+    mu, W = 0.5 * (x + 1.0), 0.5 * w
+    mu.setflags(write=False)
+    W.setflags(write=False)
+    return mu, W
+
+
 def double_gauss(N):
-    """Gauss-Legendre nodes and weights on [0, 1] (pydisort.py:304; subroutines.py:116-138)."""
-    x, w = np.polynomial.legendre.leggauss(int(N))
-    return 0.5 * (x + 1.0), 0.5 * w
+    """Gauss-Legendre nodes and weights on [0, 1] (pydisort.py:304; subroutines.py:116-138).  Cached per N (the eigenvalue
+    problem behind `leggauss` was 40 % of a one-column call's latency); the cached arrays are read-only."""
+    return _double_gauss_cached(int(N))
 
 
 def _recentre_poly(coef, a, b):
