@@ -352,6 +352,49 @@ def test_baseline_batch_of_100000_columns_properties(amd):
     assert np.array_equal(small["u"], res["u"][at]) and np.array_equal(small["flux_up"], res["flux_up"][at])
 
 
+def test_plans_on_concurrent_host_threads(amd):
+    """one host thread per plan, plans independent.  Eight threads create, solve, evaluate and
+    close their own one-column plans at the same time (ctypes releases the GIL during the calls): every result is
+    bit-identical to the single-threaded one, and an error raised in one thread (tau out of range) carries its own text."""
+    import threading
+    from pydisort_amd import synthetic
+    cases = [synthetic.column_kwargs(synthetic.cfg4_columns(1, first=i), 0) for i in range(3)]
+    cases += [goldens.load(n)[0]["kwargs"] for n in ("9c", "5a", "6d")]
+
+    def run(kw):
+        res = amd.pydisort(**kw)
+        tau = np.concatenate(([0.0], np.atleast_1d(kw["tau_arr"])))
+        out = res[4](tau, np.array([0.0, 1.0])) if len(res) > 4 else res[3](tau)  # (only_flux cases return no u)
+        res[1].__self__.plan.close()
+        return out
+
+    bad, errors = [], []
+
+    def worker(tid):
+        try:
+            for it in range(40):
+                i = (it * 5 + tid) % len(cases)
+                if not np.array_equal(run(cases[i]), want[i]):
+                    bad.append((tid, it, i))
+                if it % 10 == 0 and tid % 2 == 0:
+                    res = amd.pydisort(**cases[3])
+                    with pytest.raises(ValueError, match="tau"):
+                        res[1](np.array([99.0]))
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+
+    with warnings.catch_warnings():  # (the filter list is process-wide: set once, around all threads)
+        warnings.simplefilter("ignore")
+        want = [run(kw) for kw in cases]
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    assert not errors, errors
+    assert not bad, bad
+
+
 def test_tensors_match_oracle_invariants(amd):
     """The exported reference-layout tensors: K sorted, B, and the gauge-invariant product GC exp(K dtau)."""
     from oracle import disort_oracle as O
