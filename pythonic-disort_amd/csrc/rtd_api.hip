@@ -548,14 +548,9 @@ int rtd_plan_create_windowed(const rtd_dims* dims, int32_t device, int32_t work_
   if (dims->ncols < 1 || dims->nlayers < 1 || dims->nquad < 2 || (dims->nquad & 1) || dims->nleg < 1 ||
       dims->nfourier < 1 || dims->nfourier > dims->nleg || dims->nscoeffs < 0 || dims->nbdrf < 0)
     return fail(RTD_ERR_ARG, "invalid dimensions");
-  if (N > 32) return fail(RTD_ERR_ARG, "NQuad > 64 is not supported by this build (N = NQuad/2 <= 32)");
+  // 2 ... 64 streams: the tuned kernels; 66 ... 128 streams: the generic instances (one problem / one chain per wavefront)
+  if (N > 64) return fail(RTD_ERR_ARG, "NQuad > 128 is not supported by this build (N = NQuad/2 <= 64)");
   HIP_TRY(hipSetDevice(device));
-  {  // the evaluation kernel keeps 2 M 2 NP doubles of a point in LDS: refuse sizes a gfx950 workgroup cannot hold
-    constexpr size_t kLdsPerWorkgroup = 160u << 10;  // gfx950: a workgroup may use the CU's whole 160 KiB
-    const size_t need = (size_t)2 * dims->nfourier * 2 * pad_pow2(N) * sizeof(double) + 64;
-    if (need > kLdsPerWorkgroup)
-      return fail(RTD_ERR_ARG, "nfourier x nquad needs " + std::to_string(need) + " bytes of LDS per workgroup (limit 163840)");
-  }
   rtd_plan* p = new rtd_plan();
   const int rc = plan_build(p, dims, device, work_columns);
   if (rc) {

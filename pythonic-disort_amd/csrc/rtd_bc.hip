@@ -42,6 +42,7 @@ namespace {
 
 template <int MASK>
 __device__ __forceinline__ double xor_lane(double v) {
+  if constexpr (MASK >= 32) return __shfl_xor(v, MASK, 64);  // across the halves of the wavefront: ds_bpermute (128 streams only)
   constexpr int pat = (MASK << 10) | 0x1F;
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_ds_swizzle(lo, pat);
@@ -56,6 +57,7 @@ __device__ __forceinline__ double group_max(double v) {
   if (NP > 4) v = fmax(v, xor_lane<4>(v));
   if (NP > 8) v = fmax(v, xor_lane<8>(v));
   if (NP > 16) v = fmax(v, xor_lane<16>(v));
+  if (NP > 32) v = fmax(v, xor_lane<32>(v));
   return v;
 }
 
@@ -77,6 +79,7 @@ __device__ __forceinline__ float group_max_key(float v) {
     const int o = __builtin_amdgcn_ds_swizzle(__float_as_int(v), (16 << 10) | 0x1F);
     v = fmaxf(v, __int_as_float(o));
   }
+  if (NP > 32) v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
 
@@ -264,8 +267,8 @@ struct GjStep {
       bv -= f * bcast16<K>(bv);
     } else {
       const unsigned long long bal = __ballot(key == kmax);
-      const unsigned int bits = (unsigned int)((bal >> (grp * NP)) & ((NP == 32) ? 0xffffffffull : ((1ull << NP) - 1)));
-      const int src = __ffs((int)bits) - 1;  // pivot lane of this group
+      const unsigned long long bits = NP == 64 ? bal : (bal >> (grp * NP)) & ((1ull << (NP & 63)) - 1);
+      const int src = __ffsll((long long)bits) - 1;  // pivot lane of this group
       isp = (j == src);
       const int addr = (grp * NP + src) << 2;
       const double piv = bperm(addr, am[K]);
@@ -2251,6 +2254,7 @@ void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
   switch (d.NP) {
     RTD_BC_CASE(4)
     RTD_BC_CASE(8)
+    RTD_BC_CASE(64)  // 66 ... 128 streams: the row-per-lane kernels, one chain per wavefront
     case 16:
       if (tiled16) {
         RTD_BC_TILED_CASE(16, 1)

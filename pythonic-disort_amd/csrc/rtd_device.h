@@ -68,6 +68,7 @@ struct RtdEval {
   double *u, *u0, *fup, *fdn, *fdir, *ulast;  // device outputs (may be null)
   const double* um_in;  // [C][M][ntau][Q2] Fourier modes already formed by the boundary-condition kernel (else null)
   const int* run_if_set;  // not null: the evaluation kernel leaves at once unless this flag is set (see rtd_launch_eval)
+  int mchunk;  // Fourier modes per pass of the evaluation kernel (set by rtd_launch_eval; 0: all)
 };
 
 // Nakajima-Tanaka corrections (rtd_nt.hip)

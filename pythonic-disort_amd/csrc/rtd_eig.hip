@@ -37,7 +37,8 @@ constexpr __host__ __device__ int dpp_xor_ctrl(int mask) {
 
 template <int MASK>
 __device__ __forceinline__ double xor_lane(double v) {
-  // value of lane (lane ^ MASK); MASK < 32
+  // value of lane (lane ^ MASK)
+  if constexpr (MASK >= 32) return __shfl_xor(v, MASK, 64);  // across the halves of the wavefront: ds_bpermute (NP = 64 only)
   int lo = __double2loint(v), hi = __double2hiint(v);
   constexpr int ctrl = dpp_xor_ctrl(MASK);
   if constexpr (ctrl >= 0 && ((RTD_XOR_DPP >> MASK) & 1)) {  // one VALU move per dword, no LDS crossbar (RTD_XOR_DPP = bit set of masks)
@@ -141,6 +142,7 @@ __device__ __forceinline__ double group_sum(double v) {
   if (NP > 4) v += xor_lane<4>(v);
   if (NP > 8) v += xor_lane<8>(v);
   if (NP > 16) v += xor_lane<16>(v);
+  if (NP > 32) v += xor_lane<32>(v);
   return v;
 }
 
@@ -497,7 +499,7 @@ __host__ __device__ constexpr int tri(int r, int c) { return r * (r + 1) / 2 + c
 #endif
 
 template <int NP, int JV>  // JV: 2 = default; 3 = the assembly of Pm, Qm on the matrix cores (RTD_EIG_MFMA, NP = 16)
-__global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : RTD_EIGEN32_WAVES)) void rtd_eigen_kernel(RtdDev d) {
+__global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EIGEN32_WAVES : 1)) void rtd_eigen_kernel(RtdDev d) {
   constexpr int GPW = 64 / NP;
   // Cholesky factor L of Pm in LDS: a padded square at NP <= 16; at NP = 32 the packed lower triangle (element (r, c), r >= c,
   // at r (r + 1) / 2 + c): half the LDS, which is what lets two wavefronts per SIMD fit there (A/B: 12.4 -> 11.6 ms per 128
@@ -1093,6 +1095,7 @@ void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part) {
       else hipLaunchKernelGGL((rtd_eigen_kernel<16, 2>), grid, dim3(64), 0, s, d);
       break;
     RTD_EIG_CASE(32)
+    RTD_EIG_CASE(64)  // 66 ... 128 streams: the generic column-per-lane form, one problem per wavefront (correct, not tuned)
     default: break;
   }
 #undef RTD_EIG_CASE

@@ -6,6 +6,8 @@
 // GC exp(K dtau) + B exp(-tau*/mu0) + v(tau*) (:221-254), Fourier sum (:256-260), fluxes (:519, :601),
 // rescale (:262), and their is_antiderivative_wrt_tau variants.  One workgroup per (column, tau point);
 // the M x Q x Q temporary of the reference is never formed: G rows are streamed once per point.
+#include <algorithm>
+
 #include "rtd_device.h"
 
 namespace {
@@ -42,8 +44,11 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
   constexpr int Q = 2 * NP;
   extern __shared__ double smem[];
   const int M = d.M, L = d.L, N = d.N;
-  double* e_s = smem;           // [M][Q] scaled exponentials times BC coefficients
-  double* um = smem + M * Q;    // [M][Q] Fourier modes of the intensity at this point
+  // The Fourier modes are taken MC at a time (MC = M unless 2 M Q doubles exceed 64 KiB of LDS: more than 32 modes at 128
+  // streams), the sums over m accumulated from chunk to chunk.
+  const int MC = ev.mchunk > 0 && ev.mchunk < M ? ev.mchunk : M;
+  double* e_s = smem;           // [MC][Q] scaled exponentials times BC coefficients
+  double* um = smem + MC * Q;   // [MC][Q] Fourier modes of the intensity at this point
   __shared__ int s_l;
   __shared__ double s_ts;
   if (ev.run_if_set != nullptr && *ev.run_if_set == 0) return;  // (the Fourier-sum kernel has done this window)
@@ -70,17 +75,20 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
   const double dtop = ts - ts0[l], dbot = ts0[l + 1] - ts;
   const bool beam = d.beam != 0;
   const double mu0 = beam ? d.mu0[c] : 1.0;
+  for (int mb = 0; mb < M; mb += MC) {  // (one pass unless the modes do not fit the LDS)
+  const int mc = min(MC, M - mb);
+  if (mb > 0) __syncthreads();  // the previous chunk's modes have been summed
   if (ev.um_in != nullptr) {
     // the boundary-condition kernel has formed u^m at this point (a layer interface) already: only the sums are left
-    for (int idx = tid; idx < M * Q; idx += EVAL_THREADS) {
+    for (int idx = tid; idx < mc * Q; idx += EVAL_THREADS) {
       const int m = idx / Q, i = idx % Q;
-      um[idx] = ev.um_in[(((long)c * M + m) * ev.ntau + t) * Q + i];
+      um[idx] = ev.um_in[(((long)c * M + mb + m) * ev.ntau + t) * Q + i];
     }
   } else {
   // exponent * coefficient, both halves non-positive exponents (:197-203)
-  for (int idx = tid; idx < M * NP; idx += EVAL_THREADS) {
+  for (int idx = tid; idx < mc * NP; idx += EVAL_THREADS) {
     const int m = idx / NP, jj = idx % NP;
-    const long ml = ((long)c * M + m) * L + l;
+    const long ml = ((long)c * M + mb + m) * L + l;
     const double k = d.kk[ml * NP + jj];
     double en = exp(-k * dtop) * d.coef[ml * Q + jj];
     double ep = exp(-k * dbot) * d.coef[ml * Q + NP + jj];
@@ -99,8 +107,8 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
   // down-stream of a quadrature node share the two row sums  P = Y_i . (en+ep),  Qs = A_i . (en-ep)/k
   const int grp = tid / NP, jj = tid % NP;
   constexpr int NGRP = EVAL_THREADS / NP;
-  for (int m = grp; m < M; m += NGRP) {  // one NP-lane group per Fourier mode; lane jj ends up owning node i = jj
-    const long ml = ((long)c * M + m) * L + l;
+  for (int m = grp; m < mc; m += NGRP) {  // one NP-lane group per Fourier mode; lane jj ends up owning node i = jj
+    const long ml = ((long)c * M + mb + m) * L + l;
     const double* Yl = d.Ym + ml * NP * NP + jj;
     const double* Al = d.Am + ml * NP * NP + jj;
     const double e1 = e_s[m * Q + jj], e2 = e_s[m * Q + NP + jj];
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
       vu += d.Bv[ml * Q + jj] * bfac;
       vd += d.Bv[ml * Q + NP + jj] * bfac;
     }
-    if (d.m0 + d.mstep * m == 0 && d.Ns > 0) {  // isotropic-source particular solution (subroutines.py:786-862)
+    if (d.m0 + d.mstep * (mb + m) == 0 && d.Ns > 0) {  // isotropic-source particular solution (subroutines.py:786-862)
       const double* dq = d.dq + ((long)c * L + l) * d.Ns * Q;
       double tp = antider ? ts : 1.0;
       for (int q = 0; q < d.Ns; ++q) {
@@ -143,26 +151,29 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
       const double dl = phi0 - ev.phi[p];
       // sum_k um[k] cos((m0 + k mstep) dl): Chebyshev recurrence in steps of mstep (m0 = 0, mstep = 1 without mode shards)
       const double cs = cos(d.mstep * dl);
-      double ckm1 = cos((d.m0 - d.mstep) * dl), ck = cos(d.m0 * dl);
+      const int mf = d.m0 + d.mstep * mb;  // the chunk's first mode
+      double ckm1 = cos((mf - d.mstep) * dl), ck = cos(mf * dl);
       double acc = 0.0;
-      for (int m = 0; m < M; ++m) {
+      for (int m = 0; m < mc; ++m) {
         acc += um[m * Q + i2] * ck;
         const double cn = 2.0 * cs * ck - ckm1;
         ckm1 = ck;
         ck = cn;
       }
-      ev.u[(((long)c * Qr + ir) * ev.ntau + t) * ev.nphi + p] = rescale * acc;
+      double* out = ev.u + (((long)c * Qr + ir) * ev.ntau + t) * ev.nphi + p;  // (the same thread owns it in every chunk)
+      *out = mb == 0 ? rescale * acc : *out + rescale * acc;
     }
   }
   if (tid < Qr) {
     const int i2 = tid < N ? tid : NP + (tid - N);
     // with mode shards the zeroth / last mode belongs to one shard only; the others contribute zeros to the sum
     const bool own0 = d.m0 == 0, ownlast = d.m0 + d.mstep * (M - 1) == d.mtot - 1;
-    if (ev.u0 != nullptr) ev.u0[((long)c * Qr + tid) * ev.ntau + t] = own0 ? rescale * um[i2] : 0.0;
-    if (ev.ulast != nullptr) ev.ulast[((long)c * Qr + tid) * ev.ntau + t] = ownlast ? rescale * um[(M - 1) * Q + i2] : 0.0;
+    if (ev.u0 != nullptr && mb == 0) ev.u0[((long)c * Qr + tid) * ev.ntau + t] = own0 ? rescale * um[i2] : 0.0;
+    if (ev.ulast != nullptr && mb + mc == M)
+      ev.ulast[((long)c * Qr + tid) * ev.ntau + t] = ownlast ? rescale * um[(mc - 1) * Q + i2] : 0.0;
   }
   // fluxes from the zeroth mode (:519, :568-601)
-  if (tid == 0 && (ev.fup != nullptr || ev.fdn != nullptr || ev.fdir != nullptr)) {
+  if (mb == 0 && tid == 0 && (ev.fup != nullptr || ev.fdn != nullptr || ev.fdir != nullptr)) {
     double fu = 0.0, fd = 0.0;
     for (int i = 0; i < N; ++i) {
       const double mw = d.mu[i] * d.w[i];
@@ -185,6 +196,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
     if (ev.fdn != nullptr) ev.fdn[o] = own * rescale * (2.0 * M_PI * fd + direct_s - direct);
     if (ev.fdir != nullptr) ev.fdir[o] = own * rescale * direct;
   }
+  }  // chunks of modes
 }
 
 // The throughput path: the boundary-condition kernel has left u^m at the points already (the layer interfaces [0, tau_arr],
@@ -323,12 +335,16 @@ void rtd_launch_eval(const RtdDev& d, const RtdEval& e, hipStream_t s) {
     return;
   }
   const dim3 grid((unsigned)((long)e.ntau * d.C));  // 1-D: no 65535 limit on the column count
-  const size_t shm = (size_t)2 * d.M * 2 * d.NP * sizeof(double);
+  // modes per pass of the evaluation kernel: all of them unless 2 M 2 NP doubles exceed 64 KiB of LDS
+  RtdEval e2 = e;
+  e2.mchunk = std::min<int>(d.M, (64 << 10) / (int)(2 * 2 * d.NP * sizeof(double)));
+  const size_t shm = (size_t)2 * e2.mchunk * 2 * d.NP * sizeof(double);
   switch (d.NP) {
-    case 4: hipLaunchKernelGGL(rtd_eval_kernel<4>, grid, dim3(EVAL_THREADS), shm, s, d, e); break;
-    case 8: hipLaunchKernelGGL(rtd_eval_kernel<8>, grid, dim3(EVAL_THREADS), shm, s, d, e); break;
-    case 16: hipLaunchKernelGGL(rtd_eval_kernel<16>, grid, dim3(EVAL_THREADS), shm, s, d, e); break;
-    case 32: hipLaunchKernelGGL(rtd_eval_kernel<32>, grid, dim3(EVAL_THREADS), shm, s, d, e); break;
+    case 4: hipLaunchKernelGGL(rtd_eval_kernel<4>, grid, dim3(EVAL_THREADS), shm, s, d, e2); break;
+    case 8: hipLaunchKernelGGL(rtd_eval_kernel<8>, grid, dim3(EVAL_THREADS), shm, s, d, e2); break;
+    case 16: hipLaunchKernelGGL(rtd_eval_kernel<16>, grid, dim3(EVAL_THREADS), shm, s, d, e2); break;
+    case 32: hipLaunchKernelGGL(rtd_eval_kernel<32>, grid, dim3(EVAL_THREADS), shm, s, d, e2); break;
+    case 64: hipLaunchKernelGGL(rtd_eval_kernel<64>, grid, dim3(EVAL_THREADS), shm, s, d, e2); break;
     default: break;
   }
 }

@@ -61,8 +61,8 @@ def _assemble_intensity_and_fluxes(
     if autograd_compatible:
         raise NotImplementedError("autograd_compatible=True is outside the scope of the HIP path.")
     N, NQuad, NLeg, NFourier, NLayers, NBDRF = int(N), int(NQuad), int(NLeg), int(NFourier), int(NLayers), int(NBDRF)
-    if NQuad != 2 * N or NQuad > 64:
-        raise ValueError("Need NQuad = 2 N <= 64.")
+    if NQuad != 2 * N or NQuad > 128:
+        raise ValueError("Need NQuad = 2 N <= 128.")
     mu = np.asarray(mu_arr_pos, float).reshape(N)
     tau_arr = np.asarray(tau_arr, float).reshape(NLayers)
     beam = bool(there_is_beam_source)

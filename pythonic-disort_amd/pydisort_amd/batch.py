@@ -70,8 +70,8 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
     N = NQuad // 2
     NLeg = NQuad if NLeg is None else NLeg
     NFourier = 1 if only_flux else (NQuad if NFourier is None else NFourier)
-    if NQuad % 2 or NQuad < 2 or NQuad > 64:
-        raise ValueError("NQuad must be even and between 2 and 64.")
+    if NQuad % 2 or NQuad < 2 or NQuad > 128:
+        raise ValueError("NQuad must be even and between 2 and 128.")
     if not (0 < NFourier <= NLeg <= NQuad and NLeg <= Leg.shape[2]):
         raise ValueError("Need 0 < NFourier <= NLeg <= NQuad and NLeg <= number of Legendre coefficients provided.")
     if not (np.all(tau_arr > 0) and np.all(np.diff(tau_arr, axis=1) > 0)):

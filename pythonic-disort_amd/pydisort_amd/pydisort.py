@@ -148,8 +148,8 @@ def pydisort(
         raise ValueError("The fractional scattering must be between 0 and 1.")
     if not use_banded_solver_NLayers >= 3:
         raise ValueError("The minimum threshold `use_banded_solver_NLayers` is 3, else the matrix will not be banded.")
-    if NQuad > 64:
-        raise ValueError("This build supports at most 64 streams (NQuad <= 64).")
+    if NQuad > 128:  # (66 ... 128 streams run on generic, untuned kernel instances)
+        raise ValueError("This build supports at most 128 streams (NQuad <= 128).")
 
     mu_pos, W = double_gauss(N)
     mu_arr = np.concatenate([mu_pos, -mu_pos])

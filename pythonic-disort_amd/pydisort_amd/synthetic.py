@@ -109,3 +109,26 @@ def literal_cases():
                           f_arr=0.85**32, NT_cor=True), np.array([0.0, 3.2, 32.0, 64.0])),
     }
     return cases
+
+
+def many_stream_cases():
+    """More than 64 streams (the reference has no cap on NQuad; its associated-Legendre tables overflow when l + m passes
+    ~170, so NFourier stays where the reference itself is finite):
+    q72  : 72 streams, 4 layers, all 72 modes, delta-M, beam + Dirichlet bottom;
+    q96  : 96 streams, 3 layers, 40 modes, thermal source + Lambertian surface + beam;
+    q128 : 128 streams, 2 layers, 64 modes, strongly forward-peaked Henyey-Greenstein (g = 0.9), delta-M."""
+    def hg(g, n, L):
+        return np.tile(g ** np.arange(n), (L, 1))
+    cases = {
+        "q72": (dict(tau_arr=np.array([0.3, 1.1, 2.0, 5.0]), omega_arr=np.array([0.95, 0.6, 0.99, 0.8]), NQuad=72,
+                     Leg_coeffs_all=hg(0.8, 77, 4), mu0=0.55, I0=np.pi, phi0=0.4, f_arr=np.full(4, 0.8**72), b_pos=0.2),
+                np.array([0.0, 0.15, 0.3, 1.1, 1.5, 2.0, 4.0, 5.0])),
+        "q96": (dict(tau_arr=np.array([0.5, 2.0, 3.0]), omega_arr=np.array([0.7, 0.9, 0.5]), NQuad=96,
+                     Leg_coeffs_all=hg(0.7, 100, 3), mu0=0.8, I0=2.0, phi0=1.0, NFourier=40,
+                     s_poly_coeffs=np.array([[0.3, 0.05], [0.4, 0.0], [0.2, 0.1]]), BDRF_Fourier_modes=[0.25], b_neg=0.05),
+                np.array([0.0, 0.25, 0.5, 1.0, 2.0, 2.5, 3.0])),
+        "q128": (dict(tau_arr=np.array([1.0, 4.0]), omega_arr=np.array([0.98, 0.85]), NQuad=128,
+                      Leg_coeffs_all=hg(0.9, 140, 2), mu0=0.35, I0=np.pi, phi0=0.0, NFourier=64, f_arr=np.full(2, 0.9**128)),
+                 np.array([0.0, 0.5, 1.0, 2.5, 4.0])),
+    }
+    return cases

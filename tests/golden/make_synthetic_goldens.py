@@ -102,7 +102,13 @@ if __name__ == "__main__":
     if "--cfg5-only" in sys.argv:  # after a change of synthetic.cfg5_columns
         run("cfg5", synthetic.cfg5_columns(8), 8)
         sys.exit(0)
+    if "--many-streams-only" in sys.argv:  # 72 / 96 / 128 streams (round 3: the 64-stream cap went)
+        for name, (kw, tau_pts) in synthetic.many_stream_cases().items():
+            run_single(name, kw, tau_pts)
+        sys.exit(0)
     for name, (kw, tau_pts) in synthetic.literal_cases().items():
+        run_single(name, kw, tau_pts)
+    for name, (kw, tau_pts) in synthetic.many_stream_cases().items():
         run_single(name, kw, tau_pts)
     for name, (kw, tau_pts) in cloud_c1_cases().items():
         run_cloud(name, kw, tau_pts)

@@ -489,6 +489,74 @@ def test_baseline_literal_configs(amd, name):
     assert np.allclose(fd[1], z["flux_down_direct"], rtol=1e-12, atol=1e-300)
 
 
+@pytest.mark.parametrize("name", ["q72", "q96", "q128"])
+def test_beyond_64_streams_vs_reference(amd, name):
+    """72 / 96 / 128 streams -- the reference has no cap on NQuad (pydisort.py:258-264); these sizes run on the generic
+    kernel instances (one eigenproblem / one boundary-condition chain per wavefront) -- against the reference's own outputs
+    (tests/golden/synth/q*.npz, make_synthetic_goldens.py).  Tolerances: the north star's 1e-6 pointwise; 1e-7 of the field
+    scale (the reference's float64 algorithm and its restatement in oracle/ differ by 3e-10 from each other here)."""
+    from conftest import record_parity
+    from pydisort_amd import synthetic
+    kw, tau_pts = synthetic.many_stream_cases()[name]
+    z = np.load(f"{goldens.HERE}/golden/synth/{name}.npz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mu_arr, Fp, Fm, u0, u = amd.pydisort(**kw)
+    a, b = goldens.max_rel_err(u(tau_pts, z["phi"]), z["u"])
+    record_parity("synthetic/" + name, a, b, 1e-7, PW_TOL, against="reference")
+    assert a < 1e-7 and b < PW_TOL
+    scale = np.max(np.abs(z["u"]))
+    assert np.max(np.abs(u0(tau_pts) - z["u0"])) / scale < 1e-7
+    assert np.allclose(Fp(tau_pts), z["flux_up"], rtol=1e-8, atol=1e-10 * scale)
+    fd = Fm(tau_pts)
+    assert np.allclose(fd[0], z["flux_down_diffuse"], rtol=1e-8, atol=1e-10 * scale)
+    assert np.allclose(fd[1], z["flux_down_direct"], rtol=1e-12, atol=1e-300)
+    assert Fp.__self__.plan.max_sweeps() <= 14
+
+
+def test_beyond_64_streams_feature_paths(amd):
+    """The other entry points at more than 64 streams: Nakajima-Tanaka corrections, antiderivatives and the Fourier-error
+    output at 80 streams against the oracle; a batch of 96-stream columns against per-column calls (bit-identical), as a
+    three-window plan (bit-identical) and through the raw-input streamed path; callable BDRF modes at 72 streams."""
+    from oracle import disort_oracle as O
+    from pydisort_amd import synthetic
+    phi = np.array([0.0, 1.0, 3.0])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kw = dict(tau_arr=np.array([1.0, 3.0]), omega_arr=np.array([0.9, 0.8]), NQuad=80, Leg_coeffs_all=np.tile(0.85 ** np.arange(200), (2, 1)),
+                  mu0=0.5, I0=pi, phi0=0.0, f_arr=np.full(2, 0.85**80), NT_cor=True, NFourier=6)
+        got, ref = amd.pydisort(**kw), O.pydisort(**kw)
+        tau = np.array([0.0, 0.4, 1.0, 2.0, 3.0])
+        scale = np.max(np.abs(ref[4](tau, phi)))
+        assert np.max(np.abs(got[4](tau, phi) - ref[4](tau, phi))) / scale < 1e-8
+        assert np.max(np.abs(got[4](tau, phi, True) - ref[4](tau, phi, True))) / scale < 1e-8
+        assert np.max(np.abs(got[4](tau, phi, False, True)[1] - ref[4](tau, phi, False, True)[1])) < 1e-6
+        assert np.max(np.abs(got[3](tau, True) - ref[3](tau, True))) / scale < 1e-8
+        assert np.max(np.abs(got[1](tau, True) - ref[1](tau, True))) / scale < 1e-8
+        C = 5
+        cfg = synthetic.cfg4_columns(C, L=3, NQuad=96)
+        cfg["NFourier"] = 4
+        _, sol = amd.pydisort_batch(**cfg)
+        taub = np.concatenate((np.zeros((C, 1)), cfg["tau_arr"]), axis=1)
+        ub = sol.u(taub, phi)
+        for i in range(C):
+            kwi = synthetic.column_kwargs(cfg, i)
+            kwi["NFourier"] = 4
+            assert np.array_equal(amd.pydisort(**kwi)[4](taub[i], phi), ub[i])
+        ro = O.pydisort(**dict(synthetic.column_kwargs(cfg, 0), NFourier=4))
+        assert np.max(np.abs(ro[4](taub[0], phi) - ub[0])) / np.max(np.abs(ub[0])) < 1e-8
+        _, sol3 = amd.pydisort_batch(work_columns=2, **cfg)
+        assert sol3.plan.windows()[1] == 3 and np.array_equal(sol3.u(taub, phi), ub)
+        res = amd.solve_columns_streamed(cfg, taub, phi, chunk_columns=4)
+        assert np.max(np.abs(res["u"] - ub)) / np.max(np.abs(ub)) < 1e-12
+        kw = dict(tau_arr=np.array([0.5]), omega_arr=np.array([0.8]), NQuad=72, Leg_coeffs_all=np.array([0.7 ** np.arange(73)]), mu0=0.6,
+                  I0=1.0, phi0=0.0, NFourier=3,
+                  BDRF_Fourier_modes=[lambda mu, nmup: 0.2 + 0.1 * np.outer(mu, nmup), lambda mu, nmup: 0.05 * np.outer(mu, nmup), 0.01])
+        got, ref = amd.pydisort(**kw), O.pydisort(**kw)
+        tau = np.array([0.0, 0.25, 0.5])
+        assert np.max(np.abs(got[4](tau, phi) - ref[4](tau, phi))) / np.max(np.abs(ref[4](tau, phi))) < 1e-8
+
+
 EDGE_CASES = {
     # two streams (N = 1, padded to 4 lanes), single layer
     "two_streams": dict(tau_arr=0.7, omega_arr=0.6, NQuad=2, Leg_coeffs_all=np.array([1.0, 0.3, 0.1]), mu0=0.4, I0=2.0, phi0=1.0),

@@ -15,7 +15,7 @@ HP_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hp"
 # Seeds whose random input the oracle refuses (raises) or solves to a non-finite / wildly ill-conditioned field: none at
 # present.  A seed listed here is skipped by name; any OTHER seed that the oracle cannot solve fails the test -- coverage
 # cannot shrink silently.
-ORACLE_REJECTS = {"random": set(), "random32": set(), "random64": set()}
+ORACLE_REJECTS = {"random": set(), "random32": set(), "random64": set(), "random128": set()}
 
 
 def eval_points(family, seed, kw):
@@ -23,9 +23,9 @@ def eval_points(family, seed, kw):
     fixtures at the same points)."""
     tau_arr = np.atleast_1d(kw["tau_arr"])
     rng = np.random.default_rng(seed)
-    extra = 3 if family == "random64" else 5
+    extra = 3 if family in ("random64", "random128") else 5
     tau = np.sort(np.concatenate(([0.0, tau_arr[-1]], tau_arr[:-1], rng.uniform(0, tau_arr[-1], extra))))
-    phi = np.array([0.0, 0.7, 3.0]) if family == "random64" else np.array([0.0, 0.7, 3.0, 5.5])
+    phi = np.array([0.0, 0.7, 3.0]) if family in ("random64", "random128") else np.array([0.0, 0.7, 3.0, 5.5])
     return tau, phi
 
 
@@ -244,3 +244,56 @@ def test_random_64_stream_case_matches_oracle(seed):
         a, b = goldens.max_rel_err(gotu, want)
         record_parity("random64/%d" % seed, a, b, 2e-9, 1e-6)
         assert np.allclose(got[1](tau), ref[1](tau), rtol=2e-8, atol=2e-9 * scale)
+
+
+def make_case_128_streams(seed):
+    """Cases beyond 64 streams (66 <= NQuad <= 128, N = 33..64 padded to 64 lanes: the generic kernel instances, one
+    eigenproblem / one chain per wavefront): 1-4 layers, omega <= 0.995 (no near-conservative layer: a 40-digit arbitration
+    at these sizes takes hours), delta-M, beam / thermal / surface / Dirichlet sources mixed, few Fourier modes for most
+    seeds and up to 40 for some (the reference's Legendre tables overflow beyond l + m ~ 170)."""
+    rng = np.random.default_rng([2029, seed])
+    NQuad = int(rng.choice([66, 70, 80, 96, 100, 112, 128]))
+    N = NQuad // 2
+    L = int(rng.integers(1, 5))
+    g = rng.uniform(0.3, 0.9, L)
+    nall = NQuad + int(rng.integers(1, 6))
+    kw = dict(tau_arr=np.cumsum(rng.choice([0.01, 0.3, 1.0, 6.0], L) * rng.uniform(0.5, 1.5, L)),
+              omega_arr=rng.uniform(0.05, 0.995, L), NQuad=NQuad, Leg_coeffs_all=g[:, None] ** np.arange(nall)[None, :],
+              mu0=float(rng.uniform(0.1, 1.0)), I0=float(rng.uniform(0.5, 4.0)), phi0=float(rng.uniform(0, 2 * np.pi)),
+              NFourier=int(rng.choice([1, 2, 3, 5, 8, 40])))
+    if rng.random() < 0.7:
+        kw["f_arr"] = g**NQuad
+    if rng.random() < 0.4:
+        kw["s_poly_coeffs"] = rng.uniform(0.0, 1.0, (L, int(rng.integers(1, 4))))
+    if rng.random() < 0.5:
+        kw["BDRF_Fourier_modes"] = [float(rng.uniform(0.05, 0.6))]
+    if rng.random() < 0.4:
+        kw["b_pos"] = rng.uniform(0, 1, N) if rng.random() < 0.5 else float(rng.uniform(0, 1))
+    if rng.random() < 0.4:
+        kw["b_neg"] = float(rng.uniform(0, 1))
+    if rng.random() < 0.2:
+        kw["I0"], kw["mu0"] = 0.0, 0.0
+        if "s_poly_coeffs" not in kw and "b_neg" not in kw:
+            kw["b_neg"] = 0.5
+    return kw
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_128_stream_case_matches_oracle(seed):
+    """Beyond 64 streams: scale tolerance 1e-7 (the oracle and the reference themselves differ by ~3e-10 at these sizes,
+    tests/test_oracle_vs_reference_goldens.py), the north star's 1e-6 pointwise."""
+    import pydisort_amd
+    from conftest import record_parity
+    import goldens
+    kw = make_case_128_streams(seed)
+    tau, phi = eval_points("random128", seed, kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = oracle_solution("random128", seed, kw, tau)
+        got = pydisort_amd.pydisort(**kw)
+    want, gotu = ref[4](tau, phi), got[4](tau, phi)
+    scale = max(float(np.max(np.abs(want))), 1e-300)
+    a, b = goldens.max_rel_err(gotu, want)
+    record_parity("random128/%d" % seed, a, b, 1e-7, 1e-6)
+    assert np.allclose(got[1](tau), ref[1](tau), rtol=1e-7, atol=1e-8 * scale)
+    assert np.allclose(got[2](tau)[0], ref[2](tau)[0], rtol=1e-7, atol=1e-8 * scale)

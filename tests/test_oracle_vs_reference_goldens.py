@@ -51,6 +51,24 @@ def test_oracle_on_baseline_literal_configs(name):
     assert np.allclose(Fp(tau_pts), z["flux_up"], rtol=1e-10, atol=1e-13 * scale)
 
 
+@pytest.mark.parametrize("name", ["q72", "q96", "q128"])
+def test_oracle_beyond_64_streams(name):
+    """72 / 96 / 128 streams (pydisort_amd.synthetic.many_stream_cases) against the reference run here.  The two float64
+    implementations of the same algorithm agree to ~3e-10 of the field scale at these sizes (eigenvector conditioning),
+    hence 1e-8."""
+    import os
+    from pydisort_amd import synthetic
+    kw, tau_pts = synthetic.many_stream_cases()[name]
+    z = np.load(os.path.join(goldens.HERE, "golden", "synth", name + ".npz"))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mu_arr, Fp, Fm, u0, u = O.pydisort(**kw)
+    scale = np.max(np.abs(z["u"]))
+    assert np.max(np.abs(u(tau_pts, z["phi"]) - z["u"])) / scale < 1e-8
+    assert np.allclose(Fp(tau_pts), z["flux_up"], rtol=1e-9, atol=1e-11 * scale)
+
+
 def test_oracle_against_high_precision_truth():
     """How far the reference's algorithm in float64 (this oracle) is from a 40-digit solution (tools/hp_truth_m0.py):
     rounding level on a benign atmosphere, ~6e-9 when omega = 1 - 1e-6 layers are present.  GPU parity tests against
