@@ -34,7 +34,7 @@ typedef struct rtd_plan rtd_plan; /* opaque */
 typedef struct {
   int32_t ncols;    /* C : independent atmospheric columns                                  */
   int32_t nlayers;  /* NLayers                                                              */
-  int32_t nquad;    /* NQuad (streams, even; N = NQuad/2 per hemisphere)                    */
+  int32_t nquad;    /* NQuad (streams, even, 2 ... 128; N = NQuad/2 per hemisphere)         */
   int32_t nleg;     /* NLeg  (phase-function moments used, <= NQuad)                        */
   int32_t nfourier; /* NFourier (1 when only fluxes are wanted)                             */
   int32_t nscoeffs; /* Nscoeffs: polynomial order+1 of the isotropic source (0 = none)      */

@@ -590,7 +590,7 @@ EDGE_CASES = {
                       phi0=0.0, f_arr=np.array([0.85, 0.5, 0.2, 0.7]) ** 30,
                       BDRF_Fourier_modes=[lambda mu, nmup: 0.3 * (1 + 0.4 * np.outer(mu, nmup)),
                                           lambda mu, nmup: 0.1 * np.outer(np.sqrt(1 - mu**2), np.sqrt(1 - np.asarray(nmup) ** 2))]),
-    # 64 streams (the largest accepted size): fused eigen kernel at 32 lanes per problem, row-per-lane BC kernels
+    # 64 streams (the largest size of the tuned kernels): fused eigen kernel at 32 lanes per problem, row-per-lane BC kernels
     "max_streams_64": dict(tau_arr=np.array([0.5, 2.5, 3.0]), omega_arr=np.array([0.9, 0.6, 0.95]), NQuad=64,
                            Leg_coeffs_all=np.array([0.9, 0.4, 0.8])[:, None] ** np.arange(66)[None, :], mu0=0.45, I0=1.0,
                            phi0=1.0, f_arr=np.array([0.9, 0.4, 0.8]) ** 64, NFourier=5, b_pos=0.3,
