@@ -161,33 +161,69 @@ __global__ __launch_bounds__(64) void rtd_iface_kernel(RtdDev d, const int* only
       Y0[i * LD + j] = Ym[i * NP + j];
     }
   }
-  // column j of Y' and A' of layer l+1
-  double ycol[NP], acol[NP];
-  {
-    const double* Ym = d.Ym + p1 * NP * NP;
-    const double* Am = d.Am + p1 * NP * NP;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      ycol[i] = Ym[i * NP + j];
-      acol[i] = Am[i * NP + j];
-    }
-  }
-  __syncthreads();
   // V^-1 V' = A^T Y'   and   U^-1 U' = diag(k) Y^T A' diag(1/k')   (T cancels)
   const double rk1 = 1.0 / d.kk[p1 * NP + j];
   double* ws = d.Fws + (cm * Lm1 + l) * Ws<NP>::SLOT;
-#pragma unroll 4
-  for (int r = 0; r < NP; ++r) {
-    double vv = 0.0, uu = 0.0;
+  if constexpr (NP <= 32) {
+    // column j of Y' and A' of layer l+1
+    double ycol[NP], acol[NP];
+    {
+      const double* Ym = d.Ym + p1 * NP * NP;
+      const double* Am = d.Am + p1 * NP * NP;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      vv += A0[i * LD + r] * ycol[i];
-      uu += Y0[i * LD + r] * acol[i];
+      for (int i = 0; i < NP; ++i) {
+        ycol[i] = Ym[i * NP + j];
+        acol[i] = Am[i * NP + j];
+      }
     }
-    uu *= d.kk[p0 * NP + r] * rk1;
-    if (valid) {
-      ws[Ws<NP>::WP + r * NP + j] = 0.5 * (vv + uu);
-      ws[Ws<NP>::WQ + r * NP + j] = 0.5 * (vv - uu);
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < NP; ++r) {
+      double vv = 0.0, uu = 0.0;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        vv += A0[i * LD + r] * ycol[i];
+        uu += Y0[i * LD + r] * acol[i];
+      }
+      uu *= d.kk[p0 * NP + r] * rk1;
+      if (valid) {
+        ws[Ws<NP>::WP + r * NP + j] = 0.5 * (vv + uu);
+        ws[Ws<NP>::WQ + r * NP + j] = 0.5 * (vv - uu);
+      }
+    }
+  } else {
+    // 128 streams: one product at a time (a column of 64 doubles each: both at once do not fit the register file); the
+    // first product waits in the Wp slot
+    __syncthreads();
+    double col[NP];
+    {
+      const double* Ym = d.Ym + p1 * NP * NP;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) col[i] = Ym[i * NP + j];
+    }
+#pragma unroll 2
+    for (int r = 0; r < NP; ++r) {
+      double vv = 0.0;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) vv += A0[i * LD + r] * col[i];
+      if (valid) ws[Ws<NP>::WP + r * NP + j] = vv;
+    }
+    {
+      const double* Am = d.Am + p1 * NP * NP;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) col[i] = Am[i * NP + j];
+    }
+#pragma unroll 2
+    for (int r = 0; r < NP; ++r) {
+      double uu = 0.0;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) uu += Y0[i * LD + r] * col[i];
+      uu *= d.kk[p0 * NP + r] * rk1;
+      if (valid) {
+        const double vv = ws[Ws<NP>::WP + r * NP + j];  // (this lane's own store)
+        ws[Ws<NP>::WP + r * NP + j] = 0.5 * (vv + uu);
+        ws[Ws<NP>::WQ + r * NP + j] = 0.5 * (vv - uu);
+      }
     }
   }
   // particular-solution jump r_l at the interface (:184-205, :242-245) and rho = G_l^-1 r_l:
