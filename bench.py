@@ -372,6 +372,42 @@ def single_column_leg(device, calls=30):
                        "columns_checked": 1, "against": "reference-computed golden tests/golden/synth/cfg2_q32_cloud_b.npz"}}
 
 
+def many_stream_leg(device, columns=32):
+    """The other reading of BASELINE configs[4]: 128 streams, 50 layers, Fourier modes capped at 64
+    -- beyond that the reference's own Legendre tables overflow -- on the generic (untuned) kernel instances; parity against
+    the reference's output for the 128-stream golden case (tests/golden/synth/q128.npz)."""
+    import warnings
+    import pydisort_amd
+    from pydisort_amd import synthetic
+    cfg = synthetic.cfg4_columns(columns, L=50, NQuad=128, g_hi=0.9)
+    cfg["NFourier"] = 64
+    _, sol = pydisort_amd.pydisort_batch(device=device, _defer_solve=True, **cfg)
+    plan = sol.plan
+    tau = np.concatenate((np.zeros((columns, 1)), cfg["tau_arr"]), axis=1)
+    plan.set_eval_points(tau, np.array([0.0, np.pi / 2, np.pi]))
+    plan.run()
+    plan.synchronize()
+    t0 = time.perf_counter()
+    plan.run()
+    plan.synchronize()
+    rate = columns / (time.perf_counter() - t0)
+    cw, nwin = plan.windows()
+    plan.close()
+    kw, tau_pts = synthetic.many_stream_cases()["q128"]
+    z = np.load(os.path.join(ROOT, "tests", "golden", "synth", "q128.npz"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = pydisort_amd.pydisort(device=device, **kw)
+    u, want = res[4](tau_pts, z["phi"]), z["u"]
+    res[1].__self__.plan.close()
+    diff = np.abs(u - want)
+    sig = np.abs(want) > 1e-8 * np.max(np.abs(want))
+    return {"value": rate, "unit": "column-solves/sec", "columns": columns, "columns_per_window": cw, "windows": nwin,
+            "workload": "128 streams, 50 layers, 64 Fourier modes (Henyey-Greenstein, g up to 0.9, delta-M): generic kernel instances, not tuned",
+            "parity": {"max_scale_rel": float(diff.max() / np.max(np.abs(want))), "max_rel_dI": float((diff[sig] / np.abs(want[sig])).max()),
+                       "columns_checked": 1, "against": "reference-computed golden tests/golden/synth/q128.npz (128 streams, 2 layers, 64 modes)"}}
+
+
 def extra_measurements(device, main_cfg=None, window=2048):
     """max |dI| of the HIP path against the oracle on the sample columns of the cpu_baseline leg, the only_flux
     throughput, the host-to-host rate of the main batch, and BASELINE's other configs."""
@@ -418,6 +454,7 @@ def extra_measurements(device, main_cfg=None, window=2048):
                                         "cfg3_big", "cfg3_columns", {"big": True}, 1024, 0, device, 50),
         "cfg5_L50_Q64_x1024": config_leg("cfg5: 50 layers, 64 streams, 64 Fourier modes, 2-mode BDRF surface, thermal source; 1024 columns in windows",
                                          "cfg5", "cfg5_columns", {}, 1024, 128, device, 2),
+        "cfg5alt_L50_Q128_M64_x32": many_stream_leg(device),
     }
     return out
 
