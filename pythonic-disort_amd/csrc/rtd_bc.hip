@@ -339,6 +339,47 @@ struct GjStep<NP, NB, NP> {
   static __device__ __forceinline__ void run(double (&)[NP], double (&)[NB], double&, int&, const int) {}
 };
 
+// 128 streams (NP = 64, one chain per wavefront): the rows [Ta | Tb | t] live in LDS, not in registers (64 fully unrolled
+// pivot steps over 129 registers per lane spilled 267 registers and 256 KB of code per elimination), and the elimination is a
+// rolled loop: step K reads the pivot row as LDS broadcasts and updates the own row in place; the pivot row is scaled by the
+// same FMA (f = 1 - 1/pivot on the pivot lane).  Columns (K, NP) and [x0, x1) of the rows are updated.
+template <bool IN_LDS, typename A>
+__device__ __forceinline__ decltype(auto) pick_row(A& regs, double* lds) {
+  if constexpr (IN_LDS) return lds;
+  else return (regs);
+}
+__device__ __forceinline__ void gj_rows_in_lds(double* R, const int ldr, const int j, const int x0, const int x1, int& pc) {
+  constexpr int NP = 64;
+  double* row = R + j * ldr;
+  for (int K = 0; K < NP; ++K) {
+    const float key = (pc < 0) ? fabsf((float)row[K]) : -1.0f;
+    const float kmax = group_max_key<NP>(key);
+    const unsigned long long bal = __ballot(key == kmax);
+    const int src = __ffsll((long long)bal) - 1;  // pivot lane (wave-uniform)
+    const bool isp = j == src;
+    const double* prow = R + src * ldr;
+    const double rp = fast_rcp(prow[K]);
+    const double f = isp ? 1.0 - rp : row[K] * rp;
+    if (isp) pc = K;
+    // eight columns at a time, every load of a batch issued before its first store: the rows may alias each other for the
+    // compiler, element by element every update waited for two LDS round trips (columns below K + 1 that a batch touches are
+    // dead: nothing reads them again)
+    auto batch = [&](const int c0) {
+      double pv[8], rv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pv[e] = prow[c0 + e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rv[e] = row[c0 + e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) row[c0 + e] = fma(-f, pv[e], rv[e]);
+    };
+    for (int c0 = (K + 1) & ~7; c0 < NP; c0 += 8) batch(c0);
+    int c = x0;
+    for (; c + 8 <= x1; c += 8) batch(c);
+    for (; c < x1; ++c) row[c] -= f * prow[c];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Sweep kernel: per (c, m): forward carry recursion over the layers, bottom BC, backward sweep.
 // ------------------------------------------------------------------------------------------------
@@ -348,6 +389,9 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
   __shared__ double sA[GPW][NP * LD];  // Wq (forward) / S (bottom)
   __shared__ double sB[GPW][NP * LD];  // Wp
   __shared__ double sV[GPW][4][NP];
+  constexpr bool ROWS_IN_LDS = NP == 64;  // (see gj_rows_in_lds)
+  constexpr int LDR = 2 * NP + 3;         // [Ta | Tb | t | bottom right-hand side], odd
+  __shared__ double sR[ROWS_IN_LDS ? NP * LDR : 1];
   const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
   const long nprob = (long)d.C * d.M;
   long cm = (long)blockIdx.x * GPW + grp;
@@ -395,7 +439,9 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
   };
 
   // carry rows, one per lane: Ta C- + Tb C+ = t.  Top boundary (down-streams at tau = 0) (:161-179, :284-285)
-  double ta[NP], tb[NP], tt;
+  double ta_regs[ROWS_IN_LDS ? 1 : NP], tb_regs[ROWS_IN_LDS ? 1 : NP], tt;
+  auto&& ta = pick_row<ROWS_IN_LDS>(ta_regs, sR + j * LDR);
+  auto&& tb = pick_row<ROWS_IN_LDS>(tb_regs, sR + j * LDR + NP);
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     const double yv = Ym[j * NP + k], av = Am[j * NP + k] / kk[k];
@@ -409,7 +455,13 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
   int pc = -1;
   for (int l = 0; l < L; ++l) {
     pc = -1;
-    GjStep<NP, NP, 0>::run(ta, tb, tt, pc, grp);  // lane now holds row pc of S = Ta^-1 Tb and s[pc]
+    if constexpr (ROWS_IN_LDS) {
+      sR[j * LDR + 2 * NP] = tt;
+      gj_rows_in_lds(sR, LDR, j, NP, 2 * NP + 1, pc);
+      tt = sR[j * LDR + 2 * NP];
+    } else {
+      GjStep<NP, NP, 0>::run(ta, tb, tt, pc, grp);  // lane now holds row pc of S = Ta^-1 Tb and s[pc]
+    }
     if (l == Lm1) break;
     double* ws = wsb + (long)l * Ws<NP>::SLOT;
     __syncthreads();
@@ -433,6 +485,27 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
 #pragma unroll
     for (int k = 0; k < NP; ++k) srb += tb[k] * v0[k];  // (S rho_b)[pc]
     const double tnew = ws[Ws<NP>::RT + pc] - Er * (tt - srb);
+    if constexpr (ROWS_IN_LDS) {
+      // the S row into registers once (the rows in LDS may alias each other for the compiler), eight columns at a time
+      double srow[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) srow[k] = tb[k];
+      for (int c0 = 0; c0 < NP; c0 += 8) {
+        double swq[8] = {}, swp[8] = {};
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            swq[e] += srow[k] * A_[k * LD + c0 + e];
+            swp[e] += srow[k] * B_[k * LD + c0 + e];
+          }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          ta[c0 + e] = -(Er * swq[e] + B_[pc * LD + c0 + e]);
+          tb[c0 + e] = -(Er * swp[e] + A_[pc * LD + c0 + e]) * v1[c0 + e];  // (srow keeps the inputs)
+        }
+      }
+    } else {
     double nbuf[NP];
 #pragma unroll
     for (int cc = 0; cc < NP; ++cc) {
@@ -448,6 +521,7 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) tb[k] = nbuf[k];
+    }
     tt = tnew;
   }
 
@@ -520,7 +594,15 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
 #pragma unroll
     for (int k = 0; k < NP; ++k) bvec -= ba[k] * v0[k];
     int pc2 = -1;
-    GjStep<NP, 1, 0>::run(am, dummy, bvec, pc2, grp);  // lane holds C+[pc2]
+    if constexpr (ROWS_IN_LDS) {  // (the Ta part of the rows is free; the S rows stay where they are)
+#pragma unroll
+      for (int k = 0; k < NP; ++k) ta[k] = am[k];
+      sR[j * LDR + 2 * NP + 1] = bvec;
+      gj_rows_in_lds(sR, LDR, j, 2 * NP + 1, 2 * NP + 2, pc2);
+      bvec = sR[j * LDR + 2 * NP + 1];
+    } else {
+      GjStep<NP, 1, 0>::run(am, dummy, bvec, pc2, grp);  // lane holds C+[pc2]
+    }
     v1[pc2] = bvec;
     __syncthreads();
     double cmin = tt;  // C-[pc] = s[pc] - S[pc][:] C+
