@@ -386,10 +386,11 @@ __device__ __forceinline__ void gj_rows_in_lds(double* R, const int ldr, const i
 template <int NP>
 __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1))) void rtd_sweep_kernel(RtdDev d, const int* only) {
   constexpr int GPW = 64 / NP, LD = NP + 1, Q = 2 * NP;
-  __shared__ double sA[GPW][NP * LD];  // Wq (forward) / S (bottom)
-  __shared__ double sB[GPW][NP * LD];  // Wp
+  constexpr bool ROWS_IN_LDS = NP == 64;  // (see gj_rows_in_lds; the whole wavefront is one chain there: Wq, Wp are wave-uniform
+                                          //  and come as scalar loads, not through LDS: two workgroups fit a CU)
+  __shared__ double sA[GPW][ROWS_IN_LDS ? 1 : NP * LD];  // Wq (forward) / S (bottom)
+  __shared__ double sB[GPW][ROWS_IN_LDS ? 1 : NP * LD];  // Wp
   __shared__ double sV[GPW][4][NP];
-  constexpr bool ROWS_IN_LDS = NP == 64;  // (see gj_rows_in_lds)
   constexpr int LDR = 2 * NP + 3;         // [Ta | Tb | t | bottom right-hand side], odd
   __shared__ double sR[ROWS_IN_LDS ? NP * LDR : 1];
   const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
@@ -466,10 +467,12 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
     double* ws = wsb + (long)l * Ws<NP>::SLOT;
     __syncthreads();
     {  // stage Wq, Wp of this interface in LDS (coalesced rows); store S row and s for the backward sweep
+      if constexpr (!ROWS_IN_LDS) {
 #pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        A_[i * LD + j] = ws[Ws<NP>::WQ + i * NP + j];
-        B_[i * LD + j] = ws[Ws<NP>::WP + i * NP + j];
+        for (int i = 0; i < NP; ++i) {
+          A_[i * LD + j] = ws[Ws<NP>::WQ + i * NP + j];
+          B_[i * LD + j] = ws[Ws<NP>::WP + i * NP + j];
+        }
       }
       v0[j] = ws[Ws<NP>::RB + j];
       v1[j] = Ek[(l + 1) * NP + j];
@@ -496,13 +499,13 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
         for (int k = 0; k < NP; ++k)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            swq[e] += srow[k] * A_[k * LD + c0 + e];
-            swp[e] += srow[k] * B_[k * LD + c0 + e];
+            swq[e] += srow[k] * ws[Ws<NP>::WQ + k * NP + c0 + e];  // wave-uniform addresses: scalar loads
+            swp[e] += srow[k] * ws[Ws<NP>::WP + k * NP + c0 + e];
           }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          ta[c0 + e] = -(Er * swq[e] + B_[pc * LD + c0 + e]);
-          tb[c0 + e] = -(Er * swp[e] + A_[pc * LD + c0 + e]) * v1[c0 + e];  // (srow keeps the inputs)
+          ta[c0 + e] = -(Er * swq[e] + ws[Ws<NP>::WP + pc * NP + c0 + e]);
+          tb[c0 + e] = -(Er * swp[e] + ws[Ws<NP>::WQ + pc * NP + c0 + e]) * v1[c0 + e];  // (srow keeps the inputs)
         }
       }
     } else {
@@ -529,7 +532,10 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
   //      with C- = s - S C+  ->  (Bb - Ba S) C+ = br - Ba s.
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < NP; ++k) A_[pc * LD + k] = tb[k];  // S at its true row index
+  for (int k = 0; k < NP; ++k)
+    if constexpr (!ROWS_IN_LDS) A_[pc * LD + k] = tb[k];  // S at its true row index
+  int* lane_of_row = reinterpret_cast<int*>(v3);  // rows in LDS: row r of S is the Tb part of lane lane_of_row[r]
+  if constexpr (ROWS_IN_LDS) lane_of_row[pc] = j;
   v0[pc] = tt;                                            // s
   __syncthreads();
   {
@@ -586,7 +592,10 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
     for (int cc = 0; cc < NP; ++cc) {
       double a = bb[cc];
 #pragma unroll
-      for (int k = 0; k < NP; ++k) a -= ba[k] * A_[k * LD + cc];
+      for (int k = 0; k < NP; ++k) {
+        if constexpr (ROWS_IN_LDS) a -= ba[k] * sR[lane_of_row[k] * LDR + NP + cc];
+        else a -= ba[k] * A_[k * LD + cc];
+      }
       am[cc] = a;
       RTD_FENCE();
     }
