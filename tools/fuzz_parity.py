@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Wide random sweep on the GPU box: the HIP path against the oracle on seeds beyond the fixed ranges of
+tests/test_gpu_random_parity.py (660 cases, 14 s).  A near-conservative case (omega > 1 - 1e-5) further than 1e-6 from the oracle
+is to be arbitrated by its 40-digit solution (tools/hp_truth_case.py <family> <seed>) and pinned in EXTRA_ARBITRATED there.
+Usage: python tools/fuzz_parity.py"""
+import os, sys, time, warnings
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "pythonic-disort_amd")]
+import pydisort_amd
+from oracle import disort_oracle as O
+import test_gpu_random_parity as T
+warnings.simplefilter("ignore")
+fams = [("random", T.make_case, range(100, 500)), ("random32", T.make_case_many_streams, range(100, 260)),
+        ("random64", T.make_case_64_streams, range(100, 160)), ("random128", T.make_case_128_streams, range(100, 140))]
+worst = {}
+t00 = time.time()
+for fam, mk, seeds in fams:
+    nbad = 0
+    w = 0.0
+    for seed in seeds:
+        kw = mk(seed)
+        tau, phi = T.eval_points(fam, seed, kw)
+        try:
+            ref = O.pydisort(**kw)
+            r0 = ref[3](tau)
+            ok = np.all(np.isfinite(r0))
+        except Exception as e:
+            ok = False
+        if not ok:
+            print(fam, seed, "oracle cannot solve", flush=True)
+            continue
+        try:
+            got = pydisort_amd.pydisort(**kw)
+            g0 = got[3](tau)
+            scale = max(float(np.max(np.abs(r0))), 1e-300)
+            err = float(np.max(np.abs(g0 - r0)) / scale)
+            fe = float(np.max(np.abs(got[1](tau) - ref[1](tau))) / max(scale, 1e-300))
+            if len(got) > 4:
+                wu = ref[4](tau, phi)
+                su = max(float(np.max(np.abs(wu))), scale)
+                err = max(err, float(np.max(np.abs(got[4](tau, phi) - wu)) / su))
+            got[1].__self__.plan.close()
+        except Exception as e:
+            print(fam, seed, "HIP EXCEPTION", repr(e)[:200], flush=True)
+            nbad += 1
+            continue
+        nc = bool(np.any(np.asarray(kw["omega_arr"]) > 1 - 1e-5))
+        tol = 1e-5 if nc else (1e-7 if fam == "random128" else 1e-8)
+        w = max(w, err if not nc else 0.0)
+        if not (err < tol and fe < 10 * tol):
+            nbad += 1
+            print(fam, seed, "MISMATCH err %.2e flux %.2e near-conservative %s NQuad %d L %d" % (err, fe, nc, kw["NQuad"], len(np.atleast_1d(kw["tau_arr"]))), flush=True)
+    print(fam, "seeds", seeds.start, seeds.stop, "bad", nbad, "worst well-conditioned err %.2e" % w, "elapsed %.0f s" % (time.time() - t00), flush=True)
