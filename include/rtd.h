@@ -66,6 +66,13 @@ int rtd_plan_destroy(rtd_plan* plan);
 int rtd_plan_synchronize(rtd_plan* plan);
 /* bytes of device memory held by the plan */
 int rtd_plan_device_bytes(rtd_plan* plan, int64_t* bytes);
+/* Which columns of the batch failed numerically in the last solve: status[ncols], 0 = fine.  Bits 1..4 of the low byte:
+ * 2 eigen-iteration not converged, 4 non-positive Cholesky pivot / non-finite eigenvalue, 8 singular boundary-condition
+ * system, 16 non-finite beam particular solution -- raised by Fourier mode 0; the same bits shifted left by 8: raised by
+ * a mode m > 0 (the fluxes and u0 of such a column are still valid: they come from mode 0; the reference returns NaN
+ * intensities and valid fluxes there, _solve_for_gen_and_part_sols.py:186).  A column's failure does not touch the other
+ * columns' results; rtd_plan_fetch / _evaluate report RTD_ERR_NUMERIC when any column they return has failed. */
+int rtd_plan_get_column_status(rtd_plan* plan, int32_t* status);
 
 /* --- inputs (host -> device) -------------------------------------------------------------- */
 /* Quadrature of one hemisphere: mu_arr_pos[N], W[N]  (pydisort.py:304-306). */

@@ -246,6 +246,7 @@ RtdDev window_dev(const rtd_plan* p, int64_t c0, int cnt, int slot = 0) {
   w.mu0 += c0; w.I0 += c0; w.phi0 += c0; w.rescale += c0;
   w.bpos += c0 * M * NP; w.bneg += c0 * M * NP; w.spoly += c0 * L * Ns;
   w.bdrfq += c0 * NB * NP * NP; w.bdrfq0 += c0 * NB * NP; w.lperm += c0 * L;
+  w.col_status += c0;
   return w;
 }
 RtdEval window_eval(const rtd_plan* p, const RtdEval& e, int64_t c0) {
@@ -294,6 +295,7 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
     // the device status word too: bits raised by an earlier solve whose results were never fetched must not be
     // reported against this one (this solve's own evaluation, queued behind the memset, raises the tau bit again)
     if (e == hipSuccess) e = hipMemsetAsync(p->d.status, 0, sizeof(int), se);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d.col_status, 0, sizeof(int) * (size_t)p->d.C, se);
     if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
     p->numeric_status = 0;  // a new solve starts clean
   }
@@ -387,8 +389,10 @@ int launch_solve(rtd_plan* p, bool with_eval, const RtdEval* ev, bool with_nt = 
   return launch_windows(p, true, with_eval ? ev : nullptr, with_nt, [](int, int64_t, int) { return 0; });
 }
 
-// read and clear the device status word after the stream has drained; maps it to an error code
-int check_status(rtd_plan* p) {
+// read and clear the device status word after the stream has drained; maps it to an error code.  all_modes = false: the
+// caller's outputs come from Fourier mode 0 alone (fluxes, u0): a failure confined to the modes m > 0 is not theirs -- the
+// reference returns them unharmed then (and NaN for u; here u reports the failure).
+int check_status(rtd_plan* p, const bool all_modes = true) {
   int st = 0;
   HIP_TRY(hipMemcpyAsync(&st, p->d.status, sizeof(int), hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
@@ -398,13 +402,28 @@ int check_status(rtd_plan* p) {
   }
   p->numeric_status |= st & ~RTD_ST_TAU;  // a failed solve stays failed for every later evaluation of it
   if (st & RTD_ST_TAU) return fail(RTD_ERR_TAU_RANGE, "tau input outside the tau range specified for the atmosphere");
-  st = p->numeric_status;
+  const int low = p->numeric_status & 0xFF, high = (p->numeric_status >> RTD_ST_HIGH_MODE_SHIFT) & 0xFF;
+  st = low | (all_modes ? high : 0);
   if (st == 0) return 0;
   std::string what;
   if (st & RTD_ST_CHOL) what += " non-positive Cholesky pivot or non-finite eigenvalue (phase function not positive definite?);";
   if (st & RTD_ST_JACOBI) what += " Jacobi eigen-iteration did not converge;";
   if (st & RTD_ST_BEAM) what += " non-finite beam particular solution (1/mu0 coincides with an eigenvalue?);";
   if (st & RTD_ST_BC) what += " singular boundary-condition system (non-finite coefficients);";
+  if (low == 0) what += " in Fourier modes m > 0 only: the fluxes and u0 of this solve are valid";
+  {  // which columns (rtd_plan_get_column_status has the bits of every column)
+    std::vector<int> cs((size_t)p->d.C);
+    if (hipMemcpy(cs.data(), p->d.col_status, cs.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
+      int64_t n = 0;
+      std::string first;
+      for (size_t c = 0; c < cs.size(); ++c)
+        if (cs[c] & (all_modes ? 0xFFFF : 0xFF)) {
+          if (n < 8) first += (n ? ", " : "") + std::to_string(c);
+          ++n;
+        }
+      if (n > 0) what += "; " + std::to_string(n) + " of " + std::to_string(cs.size()) + " columns (" + first + (n > 8 ? ", ..." : "") + ")";
+    }
+  }
   return fail(RTD_ERR_NUMERIC, "numerical failure on the device:" + what);
 }
 
@@ -485,7 +504,7 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
     A(d.Y, M * P * NP)
     // inputs: all C columns
     A(lperm, C * L) A(omega, C * L) A(tau, C * L) A(taus0, C * (L + 1)) A(scale, C * L) A(wleg, C * L * P)
-    A(mu0, C) A(I0, C) A(phi0, C) A(rescale, C)
+    A(mu0, C) A(I0, C) A(phi0, C) A(rescale, C) A(d.col_status, C)
     A(bpos, C * M * NP) A(bneg, C * M * NP) A(spoly, C * L * Ns) A(bq, C * NB * NP * NP) A(bq0, C * NB * NP)
     // intermediates: one window of Cw columns
     A(d.Y0, Cw * M * P) A(d.att, Cw * (L + 1))
@@ -525,6 +544,7 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
     p->tables_cached = true;
   }
   HIP_TRY(hipMemsetAsync(d.status, 0, sizeof(int), p->stream));
+  HIP_TRY(hipMemsetAsync(d.col_status, 0, sizeof(int) * (size_t)C, p->stream));
   HIP_TRY(hipMemsetAsync(d.sweeps, 0, sizeof(int), p->stream));
   HIP_TRY(hipMemsetAsync(d.split_any, 0, sizeof(int), p->stream));
   HIP_TRY(hipMemsetAsync(d.Bv, 0, (size_t)(Cw * M * L * Q2) * 8, p->stream));
@@ -604,6 +624,15 @@ int rtd_plan_synchronize(rtd_plan* p) {
   HIP_TRY(hipStreamSynchronize(p->stream));
   if (p->eig_stream) HIP_TRY(hipStreamSynchronize(p->eig_stream));  // (every eigen stage is consumed on `stream`: a formality)
   if (p->comm_stream) HIP_TRY(hipStreamSynchronize(p->comm_stream));
+  return 0;
+}
+
+int rtd_plan_get_column_status(rtd_plan* p, int32_t* status) {
+  if (!p || !status) return fail(RTD_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  if (p->eig_stream) HIP_TRY(hipStreamSynchronize(p->eig_stream));
+  HIP_TRY(hipMemcpy(status, p->d.col_status, sizeof(int32_t) * (size_t)p->d.C, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -908,7 +937,7 @@ int rtd_plan_fetch(rtd_plan* p, double* u, double* u0, double* flux_up, double* 
   if (flux_up) HIP_TRY(hipMemcpyAsync(flux_up, p->ev_fl, (size_t)(C * nt) * 8, hipMemcpyDeviceToHost, s));
   if (fdn) HIP_TRY(hipMemcpyAsync(fdn, p->ev_fl + C * nt, (size_t)(C * nt) * 8, hipMemcpyDeviceToHost, s));
   if (fdir) HIP_TRY(hipMemcpyAsync(fdir, p->ev_fl + 2 * C * nt, (size_t)(C * nt) * 8, hipMemcpyDeviceToHost, s));
-  return check_status(p);
+  return check_status(p, u != nullptr);  // (u0 and the fluxes come from Fourier mode 0 alone)
 }
 
 // solve + evaluate + copy out, window by window: the device-to-host copy of window w (copy stream, pinned staging)
@@ -968,7 +997,7 @@ int rtd_plan_run_fetch(rtd_plan* p, double* u, double* u0, double* flux_up, doub
   if (rc) return rc;
   for (int w = std::max(0, p->nwin - 2); w < p->nwin; ++w)
     if ((rc = drain(w))) return rc;
-  return check_status(p);
+  return check_status(p, u != nullptr);
 }
 
 int rtd_plan_result_dev_ptrs(rtd_plan* p, void** u_dev, int64_t* u_bytes, void** flux_dev, int64_t* flux_bytes) {
@@ -1393,6 +1422,7 @@ int rtd_plan_solve_layers(rtd_plan* p, int32_t first, int32_t count) {
   d.um = nullptr;
   HIP_TRY(hipMemsetAsync(d.sweeps, 0, sizeof(int), p->stream));
   HIP_TRY(hipMemsetAsync(d.status, 0, sizeof(int), p->stream));  // as launch_windows: a new solve starts clean
+  HIP_TRY(hipMemsetAsync(d.col_status, 0, sizeof(int) * (size_t)d.C, p->stream));
   p->numeric_status = 0;
   rtd_launch_tables(d, p->stream, true);
   p->tables_valid = true;  // (one-window plan: d.Y0 / d.att are the all-columns tables)

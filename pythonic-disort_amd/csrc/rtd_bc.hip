@@ -355,8 +355,9 @@ __device__ __forceinline__ void gj_rows_in_lds(double* R, const int ldr, const i
     const float key = (pc < 0) ? fabsf((float)row[K]) : -1.0f;
     const float kmax = group_max_key<NP>(key);
     const unsigned long long bal = __ballot(key == kmax);
-    const int src = __ffsll((long long)bal) - 1;  // pivot lane (wave-uniform)
-    const bool isp = j == src;
+    const int found = __ffsll((long long)bal) - 1;  // pivot lane (wave-uniform); -1: a chain that has gone NaN
+    const bool isp = j == found;
+    const int src = found < 0 ? 0 : found;
     const double* prow = R + src * ldr;
     const double rp = fast_rcp(prow[K]);
     const double f = isp ? 1.0 - rp : row[K] * rp;
@@ -463,6 +464,10 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
     } else {
       GjStep<NP, NP, 0>::run(ta, tb, tt, pc, grp);  // lane now holds row pc of S = Ta^-1 Tb and s[pc]
     }
+    // a chain that has gone NaN (failed eigen stage of its mode) finds no pivots: its lanes keep their own row index, so
+    // that what they write below stays inside their group's LDS and workspace (the other chains of the wavefront are
+    // other modes and other columns); the NaN coefficients raise RTD_ST_BC for this chain's mode at the end
+    if (pc < 0) pc = j;
     if (l == Lm1) break;
     double* ws = wsb + (long)l * Ws<NP>::SLOT;
     __syncthreads();
@@ -612,6 +617,7 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
     } else {
       GjStep<NP, 1, 0>::run(am, dummy, bvec, pc2, grp);  // lane holds C+[pc2]
     }
+    if (pc2 < 0) pc2 = j;  // (NaN chain, as above)
     v1[pc2] = bvec;
     __syncthreads();
     double cmin = tt;  // C-[pc] = s[pc] - S[pc][:] C+
@@ -623,7 +629,7 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
       coef[(long)l * Q + j] = v2[j];
       coef[(long)l * Q + NP + j] = v1[j];
       // singular system (the reference's solve_banded / solve raises LinAlgError, :326-333, :383)
-      if (!(fabs(v2[j]) + fabs(v1[j]) < 1e300)) atomicOr(d.status, RTD_ST_BC);
+      if (!(fabs(v2[j]) + fabs(v1[j]) < 1e300)) rtd_raise(d, RTD_ST_BC, mg, c);
     }
   }
   // ---- backward sweep: C+_l = Wq C-' + Wp E' C+' + rho_b ;  C-_l = s - S C+_l
@@ -1442,7 +1448,7 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
   }
   if (Lm1 == 0) {  // single layer: no interface, no workspace
     flush();
-    if (!(fabs(cminus) + fabs(cplus) < 1e300)) atomicOr(d.status, RTD_ST_BC);
+    if (!(fabs(cminus) + fabs(cplus) < 1e300)) rtd_raise(d, RTD_ST_BC, mg, c);
     return;
   }
   auto step = [&](const int l, const BwSet& s) {
@@ -1486,7 +1492,7 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
   if (lane == 0 && (cm == 1000 || cm == 30000 || cm == 60000 || (d.C <= 64 && (cm == 100 || cm == 300))))
     for (int i = 1; i < min(nstamp, 512); ++i) printf("ST %d %d %lld\n", (int)cm, i, sStamp[i] - sStamp[i - 1]);
 #endif
-  if (!(fabs(cminus) + fabs(cplus) < 1e300)) atomicOr(d.status, RTD_ST_BC);
+  if (!(fabs(cminus) + fabs(cplus) < 1e300)) rtd_raise(d, RTD_ST_BC, mg, c);
 }
 
 
@@ -2340,7 +2346,7 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
   double chk = 0.0;
 #pragma unroll
   for (int J = 0; J < T; ++J) chk += fabs(cminus.c[J]) + fabs(cplus.c[J]);
-  if (!(chk < 1e300)) atomicOr(d.status, RTD_ST_BC);
+  if (!(chk < 1e300)) rtd_raise(d, RTD_ST_BC, mg, c);
 }
 
 }  // namespace

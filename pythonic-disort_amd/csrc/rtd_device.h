@@ -50,6 +50,7 @@ struct RtdDev {
   int* split_any;     // [1]     set when any chain of the window was handed over (then the fused evaluation is incomplete)
   int* sweeps;        // [1] max Jacobi sweeps (diagnostic)
   int* status;        // [1] device-side status flags (RTD_ST_*)
+  int* col_status;    // [C] the numerical bits of `status` per column (which columns of a batch failed)
 };
 
 // device-side status bits (rtd_api.hip maps bit 0 to RTD_ERR_TAU_RANGE, the others to RTD_ERR_NUMERIC)
@@ -58,8 +59,18 @@ enum : int {
   RTD_ST_JACOBI = 2,  // the Jacobi iteration of some eigenproblem hit its sweep limit
   RTD_ST_CHOL = 4,    // non-positive pivot in a Cholesky factorisation / non-finite eigenvalue
   RTD_ST_BC = 8,      // non-finite boundary-condition coefficients (singular system)
-  RTD_ST_BEAM = 16    // non-finite beam particular solution (1/mu0 on an eigenvalue)
+  RTD_ST_BEAM = 16,   // non-finite beam particular solution (1/mu0 on an eigenvalue)
+  // The numerical bits are raised in the low byte by Fourier mode 0 and in the next byte by the modes m > 0: the fluxes
+  // and u0 come from mode 0 alone, and the reference returns them unharmed when only a higher mode fails (its u is NaN then).
+  RTD_ST_HIGH_MODE_SHIFT = 8
 };
+#ifdef __HIPCC__
+__device__ __forceinline__ void rtd_raise(const RtdDev& d, const int bit, const int mode, const int column) {
+  const int b = mode == 0 ? bit : bit << RTD_ST_HIGH_MODE_SHIFT;
+  atomicOr(d.status, b);
+  atomicOr(d.col_status + column, b);
+}
+#endif
 
 struct RtdEval {
   int ntau, nphi, antider;

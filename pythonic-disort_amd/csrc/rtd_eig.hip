@@ -831,7 +831,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
   est_sweeps = nsweep;
 #endif
   if (threadIdx.x == 0 && nsweep > *(volatile int*)d.sweeps) atomicMax(d.sweeps, nsweep);
-  if (!converged && threadIdx.x == 0) atomicOr(d.status, RTD_ST_JACOBI);  // NaN input (failed Cholesky) also ends here
+  if (!converged && threadIdx.x == 0) rtd_raise(d, RTD_ST_JACOBI, id.mg, id.c);  // NaN input (failed Cholesky) also ends here
   }
   // ---- stage 2: eigenvector blocks and particular solutions.  The lane's identifiers are rebuilt from an opaque copy
   //      of the lane index, so that none of them is kept (and spilled) across the Jacobi loop.
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
   const double rk0 = fast_rsqrt(k2), kj = k2 * rk0;
   // a non-positive Cholesky pivot (phase function not positive definite after delta-M scaling) or an overflow shows up
   // as a non-finite or non-positive eigenvalue: the reference's eig / sqrt would return NaN here (:186)
-  if (valid && !(k2 > 0.0 && k2 < 1e300)) atomicOr(d.status, RTD_ST_CHOL);
+  if (valid && !(k2 > 0.0 && k2 < 1e300)) rtd_raise(d, RTD_ST_CHOL, id.mg, id.c);
   double zc[NP];
   {
 #pragma unroll
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
       d.Bv[base * 2 * NP + j] = 0.5 * (s_j + d_j);
       d.Bv[base * 2 * NP + NP + j] = 0.5 * (s_j - d_j);
       // 1/mu0 on an eigenvalue: the reference's solve (:226-231) meets a singular matrix
-      if (!(fabs(s_j) + fabs(d_j) < 1e300)) atomicOr(d.status, RTD_ST_BEAM);
+      if (!(fabs(s_j) + fabs(d_j) < 1e300)) rtd_raise(d, RTD_ST_BEAM, id.mg, id.c);
     }
   }
   __syncthreads();

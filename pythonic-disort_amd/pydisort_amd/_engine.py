@@ -157,12 +157,12 @@ class Plan:
         u0 = np.empty((self.C, self.Q, ntau)) if "u0" in want else None
         ul = np.empty((self.C, self.Q, ntau)) if "ulast" in want else None
         fl = [np.empty((self.C, ntau)) for _ in range(3)] if "flux" in want else [None] * 3
-        _lib.check(self._lib.rtd_plan_evaluate(self._h, ntau, _lib.dptr(tau), nphi, _lib.dptr(phi),
-                                               int(bool(antiderivative)) | (2 if skip_nt else 0), _lib.dptr(u),
-                                               _lib.dptr(u0),
-                                               _lib.dptr(fl[0]), _lib.dptr(fl[1]), _lib.dptr(fl[2]),
-                                               _lib.dptr(ul)))
         out.update(u=u, u0=u0, ulast=ul, flux_up=fl[0], flux_down_diffuse=fl[1], flux_down_direct=fl[2])
+        self._checked(self._lib.rtd_plan_evaluate(self._h, ntau, _lib.dptr(tau), nphi, _lib.dptr(phi),
+                                                  int(bool(antiderivative)) | (2 if skip_nt else 0), _lib.dptr(u),
+                                                  _lib.dptr(u0),
+                                                  _lib.dptr(fl[0]), _lib.dptr(fl[1]), _lib.dptr(fl[2]),
+                                                  _lib.dptr(ul)), out)
         return out
 
     # ---- throughput form (results stay in HBM until fetch) ----
@@ -193,7 +193,7 @@ class Plan:
                        flux_up=np.empty((self.C, ntau)), flux_down_diffuse=np.empty((self.C, ntau)),
                        flux_down_direct=np.empty((self.C, ntau)))
         keys = ("u", "u0", "flux_up", "flux_down_diffuse", "flux_down_direct")
-        _lib.check(self._lib.rtd_plan_run_fetch(self._h, *[_lib.dptr(out.get(k)) for k in keys]))
+        self._checked(self._lib.rtd_plan_run_fetch(self._h, *[_lib.dptr(out.get(k)) for k in keys]), out)
         self.solved = True
         return out
 
@@ -202,8 +202,9 @@ class Plan:
         u = np.empty((self.C, self.Q, ntau, nphi))
         u0 = np.empty((self.C, self.Q, ntau))
         fl = [np.empty((self.C, ntau)) for _ in range(3)]
-        _lib.check(self._lib.rtd_plan_fetch(self._h, _lib.dptr(u), _lib.dptr(u0), *[_lib.dptr(a) for a in fl]))
-        return dict(u=u, u0=u0, flux_up=fl[0], flux_down_diffuse=fl[1], flux_down_direct=fl[2])
+        out = dict(u=u, u0=u0, flux_up=fl[0], flux_down_diffuse=fl[1], flux_down_direct=fl[2])
+        self._checked(self._lib.rtd_plan_fetch(self._h, _lib.dptr(u), _lib.dptr(u0), *[_lib.dptr(a) for a in fl]), out)
+        return out
 
     def result_dev_ptrs(self):
         up, fp = C.c_void_p(), C.c_void_p()
@@ -290,6 +291,29 @@ class Plan:
         n = C.c_int32()
         _lib.check(self._lib.rtd_plan_pivoted_chains(self._h, C.byref(n)))
         return n.value
+
+    # ---- a failed column in a batch: raise (default) or mark ----
+    numeric_errors = "raise"  # or "nan": fill the failed columns of the returned arrays with NaN instead of raising
+
+    def _checked(self, rc, arrays):
+        """Maps the status of a call that returns results.  numeric_errors == "nan": a numerical failure (rc 5) is not raised;
+        the columns it belongs to are NaN in `arrays` (u: any failed mode; u0 and fluxes: a failed mode 0 -- the others
+        keep their values: they come from mode 0 alone), every other column keeps its result."""
+        if rc == _lib.RTD_ERR_NUMERIC and self.numeric_errors == "nan":
+            st = self.column_status()
+            for k, a in arrays.items():
+                if a is not None:
+                    a[(st & (0xFFFF if k in ("u", "ulast") else 0xFF)) != 0] = np.nan
+            return
+        _lib.check(rc)
+
+    def column_status(self):
+        """int32 [C]: 0 for a column that solved cleanly, else the numerical-failure bits of include/rtd.h
+        (rtd_plan_get_column_status): low byte raised by Fourier mode 0, next byte by modes m > 0 (fluxes and u0 of such a
+        column are still valid).  After a NumericalError from a batch this tells which columns to drop."""
+        out = np.zeros(self.C, dtype=np.int32)
+        _lib.check(self._lib.rtd_plan_get_column_status(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
 
     def max_sweeps(self):
         s = C.c_int32()

@@ -43,7 +43,7 @@ class BatchSolution:
 def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLeg=None, NFourier=None,
                    b_pos=0, b_neg=0, only_flux=False, f_arr=0, NT_cor=False, bdrf_q=None, bdrf_q0=None,
                    s_poly_coeffs=None, device=0, bdrf_samples=None, NBDRF=None, mode_shard=None, work_columns=0,
-                   device_prepare=False, _defer_solve=False):
+                   device_prepare=False, numeric_errors="raise", _defer_solve=False):
     """Like ``pydisort`` with a leading column axis on every atmospheric input:
     tau_arr, omega_arr, f_arr [C, L]; Leg_coeffs_all [C, L, NLeg_all]; mu0, I0, phi0 [C];
     b_pos / b_neg: scalar, [C], [C, N] or [C, N, NFourier]; s_poly_coeffs [C, L, Ns];
@@ -58,6 +58,9 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
     result (u0, fluxes and NT corrections come from shard 0 only; ``Plan.allreduce_results`` sums across RCCL ranks).
     device_prepare=True: the delta-M scaling and the source rescaling of pydisort.py:316-372 run on the device from the raw
     inputs (``rtd_plan_set_columns_raw``) instead of in NumPy -- for throughput batches; not with NT_cor or mode_shard.
+    numeric_errors: "raise" (a column whose solve fails numerically -- e.g. a phase function whose truncation is not
+    positive -- raises NumericalError from the evaluators; ``sol.plan.column_status()`` tells which) or "nan" (the failed
+    columns are NaN in the returned arrays, every other column keeps its result: one bad column does not cost the batch).
     work_columns: columns whose intermediates are resident on the device at a time (0: sized by the library); batches
     larger than that are solved window by window (include/rtd.h: rtd_plan_create_windowed).
     All columns share NQuad, NLeg, NFourier and the layer count.  Returns (mu_arr, BatchSolution)."""
@@ -137,7 +140,10 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
         prep["M"] = len(modes)
         prep["mode_shard"] = (r, G, NFourier)
         NT_cor = NT_cor and r == 0
+    if numeric_errors not in ("raise", "nan"):
+        raise ValueError('numeric_errors must be "raise" or "nan".')
     plan = Plan(prep, device=device, work_columns=work_columns)
+    plan.numeric_errors = numeric_errors
     if bdrf_samples is not None:
         plan.set_bdrf_samples(bdrf_samples[0], bdrf_samples[1] if np.any(I0 > 0) else None)
     if not _defer_solve:
@@ -152,7 +158,7 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
     return sol.mu_arr, sol
 
 
-def solve_columns_streamed(cfg, tau, phi, chunk_columns=0, device=0, only_flux=False, out=None):
+def solve_columns_streamed(cfg, tau, phi, chunk_columns=0, device=0, only_flux=False, out=None, numeric_errors="raise"):
     """Throughput form for large column counts: ONE plan holds the inputs and the results of all columns, the
     intermediates of the solve (~8 MB per cfg4 column) live for `chunk_columns` columns at a time (0: ~8 192 (column,
     mode) chains per window) and the device-to-host copies of a window overlap the kernels of the next (``Plan.run_fetch``).
@@ -162,6 +168,7 @@ def solve_columns_streamed(cfg, tau, phi, chunk_columns=0, device=0, only_flux=F
           mu0, I0, phi0, optional f_arr, b_pos, b_neg, s_poly_coeffs, bdrf_q, bdrf_q0, NLeg, NFourier); NQuad scalar.
     tau : [C, ntau] evaluation depths; phi : [nphi].
     out : optional dict of preallocated C-contiguous float64 result arrays to fill (the same keys and shapes).
+    numeric_errors : as in ``pydisort_batch`` ("nan": failed columns come back as NaN, the rest of the batch is kept).
     Returns dict(u [C, NQuad, ntau, nphi] (absent when only_flux), u0, flux_up, flux_down_diffuse, flux_down_direct)."""
     tau = np.ascontiguousarray(np.asarray(tau, float))
     C, ntau = tau.shape
@@ -172,7 +179,7 @@ def solve_columns_streamed(cfg, tau, phi, chunk_columns=0, device=0, only_flux=F
         modes = 1 if only_flux else int(cfg.get("NFourier") or cfg.get("NLeg") or nq)
         chunk_columns = max(64, 8192 // max(modes, 1))
     _, sol = pydisort_batch(only_flux=only_flux, device=device, work_columns=chunk_columns, device_prepare=True,
-                            _defer_solve=True, **cfg)
+                            numeric_errors=numeric_errors, _defer_solve=True, **cfg)
     plan = sol.plan
     try:
         sol._tau(tau)  # range check on the host, with the reference's message

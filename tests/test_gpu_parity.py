@@ -395,6 +395,67 @@ def test_plans_on_concurrent_host_threads(amd):
     assert not bad, bad
 
 
+def test_failure_in_a_higher_fourier_mode_leaves_fluxes_and_u0(amd):
+    """A phase function whose 4-moment truncation is not positive (g = 0.89, 4 streams, no delta-M; found by
+    tools/fuzz_parity.py, seed 1153 of the random family): the eigenvalue problem of Fourier mode 1 fails in one layer
+    (the reference's sqrt gives NaN, _solve_for_gen_and_part_sols.py:186).  The reference returns valid fluxes and u0 --
+    they come from mode 0 -- and a NaN intensity; so does the device path, except that `u` raises LinAlgError instead."""
+    from oracle import disort_oracle as O
+    import test_gpu_random_parity as R
+    kw = R.make_case(1153)
+    tau, phi = R.eval_points("random", 1153, kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = O.pydisort(**kw)
+        got = amd.pydisort(**kw)
+        assert not np.all(np.isfinite(ref[4](tau, phi)))  # the reference algorithm: NaN in u
+    scale = np.max(np.abs(ref[3](tau)))
+    assert np.max(np.abs(got[3](tau) - ref[3](tau))) / scale < 1e-9
+    assert np.allclose(got[1](tau), ref[1](tau), rtol=1e-9)
+    assert np.allclose(got[2](tau)[0], ref[2](tau)[0], rtol=1e-9, atol=1e-12 * scale)
+    with pytest.raises(np.linalg.LinAlgError, match="m > 0"):
+        got[4](tau, phi)
+    assert np.allclose(got[1](tau), ref[1](tau), rtol=1e-9)  # (and again after the failed call)
+    st = int(got[1].__self__.plan.column_status()[0])
+    assert st & 0xFF == 0 and st & (4 << 8)  # non-finite eigenvalue, raised by a mode m > 0 only
+
+
+def test_a_failed_column_does_not_touch_the_rest_of_the_batch(amd):
+    """The same atmosphere between benign ones in a batch (4 streams: sixteen (column, mode) chains share a wavefront in
+    the boundary-condition kernel -- a chain that has gone NaN used to write outside its group's LDS and spoil its
+    neighbours, found by tools/fuzz_parity.py): the benign columns and the failed column's mode 0 equal the oracle,
+    `column_status` names the column, numeric_errors="nan" returns the batch with that column's intensity NaN."""
+    from oracle import disort_oracle as O
+    import test_gpu_random_parity as R
+    bad = R.make_case(1153)
+    bad.pop("BDRF_Fourier_modes")
+    good = dict(bad)
+    leg = bad["Leg_coeffs_all"].copy()
+    leg[1] = 0.6 ** np.arange(leg.shape[1])
+    good["Leg_coeffs_all"] = leg
+    tau, phi = R.eval_points("random", 1153, bad)
+    order = [good, bad, good, good, bad]
+    cfg = dict(tau_arr=np.stack([k["tau_arr"] for k in order]), omega_arr=np.stack([k["omega_arr"] for k in order]), NQuad=bad["NQuad"],
+               Leg_coeffs_all=np.stack([k["Leg_coeffs_all"] for k in order]), mu0=np.full(5, bad["mu0"]), I0=np.full(5, bad["I0"]),
+               phi0=np.full(5, bad["phi0"]), b_neg=bad["b_neg"])
+    taub = np.tile(tau, (5, 1))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rg, rb = O.pydisort(**good), O.pydisort(**bad)
+        _, sol = amd.pydisort_batch(**cfg)
+        u0 = sol.u0(taub)
+        for i, k in enumerate(order):
+            assert np.allclose(u0[i], (rb if k is bad else rg)[3](tau), rtol=1e-9, atol=1e-12), i
+        with pytest.raises(np.linalg.LinAlgError, match=r"2 of 5 columns \(1, 4\)"):
+            sol.u(taub, phi)
+        st = sol.plan.column_status()
+        assert np.array_equal(st != 0, [False, True, False, False, True]) and np.all(st[[1, 4]] & 0xFF == 0)
+        _, soln = amd.pydisort_batch(numeric_errors="nan", **cfg)
+        u = soln.u(taub, phi)
+        assert np.all(np.isnan(u[[1, 4]])) and np.allclose(u[[0, 2, 3]], rg[4](tau, phi), rtol=1e-9, atol=1e-12)
+        assert np.allclose(soln.flux_up(taub)[1], rb[1](tau), rtol=1e-9)  # fluxes of the failed column: mode 0, valid
+
+
 def test_tensors_match_oracle_invariants(amd):
     """The exported reference-layout tensors: K sorted, B, and the gauge-invariant product GC exp(K dtau)."""
     from oracle import disort_oracle as O

@@ -11,8 +11,9 @@ import pydisort_amd
 from oracle import disort_oracle as O
 import test_gpu_random_parity as T
 warnings.simplefilter("ignore")
-fams = [("random", T.make_case, range(100, 500)), ("random32", T.make_case_many_streams, range(100, 260)),
-        ("random64", T.make_case_64_streams, range(100, 160)), ("random128", T.make_case_128_streams, range(100, 140))]
+K = int(os.environ.get("FUZZ_SCALE", "1"))  # FUZZ_SCALE=10: ten times the seeds
+fams = [("random", T.make_case, range(100, 100 + 400 * K)), ("random32", T.make_case_many_streams, range(100, 100 + 160 * K)),
+        ("random64", T.make_case_64_streams, range(100, 100 + 60 * K)), ("random128", T.make_case_128_streams, range(100, 100 + 40 * K))]
 worst = {}
 t00 = time.time()
 for fam, mk, seeds in fams:
