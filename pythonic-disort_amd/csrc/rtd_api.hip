@@ -421,6 +421,7 @@ int check_status(rtd_plan* p, const bool all_modes = true) {
           if (n < 8) first += (n ? ", " : "") + std::to_string(c);
           ++n;
         }
+      if (n > 0 && !what.empty() && what.back() == ';') what.pop_back();
       if (n > 0) what += "; " + std::to_string(n) + " of " + std::to_string(cs.size()) + " columns (" + first + (n > 8 ? ", ..." : "") + ")";
     }
   }
