@@ -456,6 +456,19 @@ def test_a_failed_column_does_not_touch_the_rest_of_the_batch(amd):
         assert np.allclose(soln.flux_up(taub)[1], rb[1](tau), rtol=1e-9)  # fluxes of the failed column: mode 0, valid
 
 
+@pytest.mark.parametrize("tool,count", [("fuzz_batch.py", "120"), ("fuzz_plan_reuse.py", "80")])
+def test_random_sweeps_of_the_batch_entry_points_find_nothing(tool, count):
+    """tools/fuzz_batch.py (a batch = its columns one by one = its windowed plan = the streamed raw path = the oracle, over
+    random stream counts, sources, windows and evaluation points) and tools/fuzz_plan_reuse.py (random call sequences on one
+    long-lived plan against fresh plans: cached tables, stream forks, hand-off slots, status words), a few seconds each."""
+    import subprocess
+    import sys
+    root = os.path.dirname(goldens.HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", tool), count], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ", 0 findings" in r.stdout.strip().splitlines()[-1], r.stdout[-3000:]
+
+
 def test_tensors_match_oracle_invariants(amd):
     """The exported reference-layout tensors: K sorted, B, and the gauge-invariant product GC exp(K dtau)."""
     from oracle import disort_oracle as O
