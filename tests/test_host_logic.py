@@ -3,6 +3,7 @@ symbols, synthetic generators, and that nothing in the product imports the oracl
 import ctypes
 import os
 import re
+import warnings
 
 import numpy as np
 import pytest
@@ -105,6 +106,35 @@ def test_input_checks_raise_like_the_reference(override, msg):
     kw.update(override)
     with pytest.raises(ValueError, match=re.escape(msg)):
         pydisort_amd.pydisort(**kw)
+
+
+def _frontend_error_cases():
+    import json
+    import frontend_mutations as F
+    table = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frontend_errors.json")))
+    return [(name, seed, table[f"{name}|{seed}"]) for name in F.MUTATIONS for seed in F.SEEDS]
+
+
+@pytest.mark.parametrize("name,seed,want", _frontend_error_cases())
+def test_invalid_inputs_raise_what_the_reference_raises(name, seed, want):
+    """31 kinds of invalid input x 3 atmospheres: the exception type AND text of the reference (recorded from the reference
+    itself by tests/golden/make_frontend_error_goldens.py; pydisort.py:222-291), raised before any device work.  Inputs the
+    reference accepts (negative boundary sources, a zeroth moment other than 1 ...) must pass the drop-in's checks too: what
+    then fails here, without a GPU, is the device layer, not a ValueError."""
+    import frontend_mutations as F
+    import pydisort_amd
+    kw = F.case(name, seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        try:
+            pydisort_amd.pydisort(**kw)
+            got = ["accepted", ""]
+        except Exception as e:  # noqa: BLE001
+            got = [type(e).__name__, str(e)]
+    if want[0] == "accepted":
+        assert got[0] != "ValueError", got
+    else:
+        assert got == want
 
 
 def test_synthetic_columns_are_deterministic_and_independent_of_batch():
