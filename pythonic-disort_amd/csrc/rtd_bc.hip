@@ -830,6 +830,25 @@ struct GjFast<NB, 16> {
   static __device__ __forceinline__ void run(double (&)[4], double (&)[4], double&, int&, const int) {}
 };
 
+// A chain whose result hangs on the last digits of its coefficients: the thermal (polynomial) particular solution of a layer with
+// a tiny eigenvalue k is ~ 1/k^(order + 1) times the source and is cancelled by the homogeneous part -- at k = 1.4e-3 (omega =
+// 1 - 1e-6) seventeen orders of magnitude above the field, which is then as good as the RELATIVE accuracy of C.  The speculative
+// elimination accepts multipliers up to 64 (1e6 in the tiled kernel) and loses two to three digits against the pivoted one
+// there (9e-2 against 3e-4 of the field scale on the case of DESIGN.md section 8, the reference: 2e-4); such chains -- mode 0
+// with a thermal source and an eigenvalue below RTD_BC_CAREFUL_K somewhere -- take the pivoted elimination throughout.
+#ifndef RTD_BC_CAREFUL_K
+#define RTD_BC_CAREFUL_K 0.02
+#endif
+__device__ __forceinline__ int chain_needs_pivoting(const RtdDev& d, const bool iso, const double* kk, const int L, const int np) {
+  int careful = d.flags & 1;  // test hook (RTD_BC_FORCE_PIVOT): every elimination takes the pivoted redo
+  if (iso && !careful) {
+    double kmin = 1e300;
+    for (int i = 0; i < L * np; ++i) kmin = fmin(kmin, kk[i]);  // wave-uniform: scalar loads; mode 0 of thermal runs only
+    careful = kmin < RTD_BC_CAREFUL_K ? 1 : 0;
+  }
+  return careful;
+}
+
 // Four wavefronts per SIMD: <= 128 registers and <= 10 KB of LDS each, so the kernel prefetches one layer ahead, forms the
 // interface products one after the other (one accumulator set live), takes exp(-k dtau) from memory, saves t^T once and
 // rotates two operand sets in the backward sweep (128 VGPRs, 29 of them spilled outside the two loops; 9.8 KB).  The kernel
@@ -861,6 +880,7 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
   const bool iso = d.Ns > 0 && mg == 0;
   const bool beam = d.beam != 0;
   const double mu0 = beam ? d.mu0[c] : 1.0;
+  const int careful = chain_needs_pivoting(d, iso, kk, L, NP);
   auto vpoly = [&](int l, double t, int idx) {
     double a = 0.0, tp = 1.0;
     for (int q = 0; q < d.Ns; ++q) {
@@ -1113,7 +1133,7 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
       int bad = 0;
       GjFast<4, 0>::run(ta, tb, tv, bad, col);
       bad |= (fabs(tv) + fabs(tb[0]) + fabs(tb[1]) + fabs(tb[2]) + fabs(tb[3]) < 1e300) ? 0 : 1;  // zero pivot: inf / nan
-      bad |= d.flags & 1;
+      bad |= careful;
       if (__any(bad)) {  // some diagonal pivot was too small: pivoted elimination of the saved inputs
         pivoted_lds(true);
         const int src = sPerm[col];  // unknown `col` sits in the column that was the pivot of step `col`
@@ -1297,7 +1317,7 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
       int bad = 0;
       GjFast<0, 0>::run(mt, none, rhs, bad, col);
       bad |= (fabs(rhs) < 1e300) ? 0 : 1;
-      bad |= d.flags & 1;
+      bad |= careful;
       if (__any(bad)) {
         pivoted_lds(false);
         rhs = sSave[8][sPerm[col]];
@@ -1656,6 +1676,7 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
   const bool iso = d.Ns > 0 && mg == 0;
   const bool beam = d.beam != 0;
   const double mu0 = beam ? d.mu0[c] : 1.0;
+  const int careful = chain_needs_pivoting(d, iso, kk, L, NP);
   if ((d.flags & 2) && m % 3 == 0) {  // test hook (RTD_BC_FORCE_HANDOVER): every third Fourier mode's chain goes to the pivoted
     //                                    kernels (by mode, not by chain index: the choice must not depend on the windowing)
     if (lane == 0) {
@@ -1908,7 +1929,7 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
         return chk < 1e300;
       };
       bad |= finite() ? 0 : 1;  // zero pivot: inf / nan
-      bad |= d.flags & 1;       // test hook (RTD_BC_FORCE_PIVOT): every elimination takes the pivoted redo
+      bad |= careful;  // (RTD_BC_FORCE_PIVOT, or a chain that hangs on the last digits: chain_needs_pivoting)
       if (__any(bad)) {  // some diagonal pivot was too small: the pivoted elimination from the saved inputs
         const bool ok = pivoted_redo(tb, tv, kq, col);
         if (__any(!ok || !finite())) {
@@ -2155,7 +2176,7 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
         return chk < 1e300;
       };
       bad |= finite() ? 0 : 1;
-      bad |= d.flags & 1;
+      bad |= careful;
       if (__any(bad)) {
         const bool ok = pivoted_redo(none, rhs, kq, col);
         if (__any(!ok || !finite())) {
