@@ -839,6 +839,9 @@ struct GjFast<NB, 16> {
 #ifndef RTD_BC_CAREFUL_K
 #define RTD_BC_CAREFUL_K 0.02
 #endif
+#ifndef RTD_BC_CAREFUL_ALL_MODE0
+#define RTD_BC_CAREFUL_ALL_MODE0 0  /* 1: every mode-0 chain with such an eigenvalue, thermal source or not (A/B below) */
+#endif
 __device__ __forceinline__ int chain_needs_pivoting(const RtdDev& d, const bool iso, const double* kk, const int L, const int np) {
   int careful = d.flags & 1;  // test hook (RTD_BC_FORCE_PIVOT): every elimination takes the pivoted redo
   if (iso && !careful) {
@@ -880,7 +883,7 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
   const bool iso = d.Ns > 0 && mg == 0;
   const bool beam = d.beam != 0;
   const double mu0 = beam ? d.mu0[c] : 1.0;
-  const int careful = chain_needs_pivoting(d, iso, kk, L, NP);
+  const int careful = chain_needs_pivoting(d, RTD_BC_CAREFUL_ALL_MODE0 ? mg == 0 : iso, kk, L, NP);
   auto vpoly = [&](int l, double t, int idx) {
     double a = 0.0, tp = 1.0;
     for (int q = 0; q < d.Ns; ++q) {
@@ -1676,7 +1679,7 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
   const bool iso = d.Ns > 0 && mg == 0;
   const bool beam = d.beam != 0;
   const double mu0 = beam ? d.mu0[c] : 1.0;
-  const int careful = chain_needs_pivoting(d, iso, kk, L, NP);
+  const int careful = chain_needs_pivoting(d, RTD_BC_CAREFUL_ALL_MODE0 ? mg == 0 : iso, kk, L, NP);
   if ((d.flags & 2) && m % 3 == 0) {  // test hook (RTD_BC_FORCE_HANDOVER): every third Fourier mode's chain goes to the pivoted
     //                                    kernels (by mode, not by chain index: the choice must not depend on the windowing)
     if (lane == 0) {
