@@ -26,11 +26,15 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
+// (a failed runtime call also leaves its code in HIP's per-thread "last error": it is taken out here, or the launch check of
+//  the next, unrelated, call on this thread -- hipGetLastError after its kernels -- would report it)
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \
     hipError_t e_ = (expr);                                                                    \
-    if (e_ != hipSuccess)                                                                      \
+    if (e_ != hipSuccess) {                                                                    \
+      (void)hipGetLastError();                                                                 \
       return fail(RTD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+    }                                                                                          \
   } while (0)
 
 int pad_pow2(int n) {
@@ -273,6 +277,7 @@ RtdNt window_nt(const rtd_plan* p, int64_t c0) {
 // queued (rtd_plan_run_fetch hangs its device-to-host copies there).
 template <typename F>
 int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt, F&& after_window, bool allow_fused = true) {
+  (void)hipGetLastError();  // (a stale code of this thread -- another library's, an earlier failed call's -- is not this launch's)
   hipStream_t s = p->stream;
   const bool tm = p->timing;
   auto mark = [&](int k) {
@@ -1411,6 +1416,7 @@ int layer_segments(rtd_plan* p, LayerSeg seg[7]) {
 }  // namespace
 
 int rtd_plan_solve_layers(rtd_plan* p, int32_t first, int32_t count) {
+  (void)hipGetLastError();  // (as launch_windows: a stale code of this thread is not this call's)
   if (!p) return fail(RTD_ERR_ARG, "null plan");
   p->fork_needed = true;  // works on the hand-off buffers from the plan's own stream
   if (!p->have_quad || !p->have_cols) return fail(RTD_ERR_STATE, "set_quadrature and set_columns must precede solve");
@@ -1479,6 +1485,7 @@ int rtd_comm_allgather_layers(rtd_plan* p, int32_t count) {
 }
 
 int rtd_plan_solve_bc(rtd_plan* p) {
+  (void)hipGetLastError();  // (as launch_windows: a stale code of this thread is not this call's)
   if (!p) return fail(RTD_ERR_ARG, "null plan");
   if (!p->have_quad || !p->have_cols) return fail(RTD_ERR_STATE, "inputs missing");
   if (p->nwin != 1) return fail(RTD_ERR_STATE, "layer shards need a plan of one window");

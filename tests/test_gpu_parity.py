@@ -469,6 +469,20 @@ def test_random_sweeps_of_the_batch_entry_points_find_nothing(tool, count):
     assert ", 0 findings" in r.stdout.strip().splitlines()[-1], r.stdout[-3000:]
 
 
+def test_a_failed_runtime_call_does_not_poison_the_next_one(amd):
+    """A plan on a device that does not exist fails with the HIP error text -- and leaves nothing behind: HIP keeps the code
+    of a failed call as the thread's "last error", which the launch check of the next, valid, solve used to report as its own
+    ("kernel launch: invalid device ordinal")."""
+    kw = goldens.load("9c")[0]["kwargs"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(RuntimeError, match="invalid device ordinal"):
+            amd.pydisort(device=99, **kw)
+        res = amd.pydisort(**kw)
+        want = amd.pydisort(**kw)[1](0.5)
+    assert np.array_equal(res[1](0.5), want)
+
+
 def test_tensors_match_oracle_invariants(amd):
     """The exported reference-layout tensors: K sorted, B, and the gauge-invariant product GC exp(K dtau)."""
     from oracle import disort_oracle as O
