@@ -267,6 +267,21 @@ def test_near_conservative_case_found_by_the_random_sweep(family, seed):
     arbitrated(family, seed, got[4](tau, phi), ref[4](tau, phi), tol_scale=2e-9)
 
 
+def test_largest_well_conditioned_disagreement_of_the_random_sweep_is_the_oracles():
+    """random64/2197 (64 streams, 8 layers, no layer near omega = 1): 1.2e-8 between HIP and oracle, the largest of the
+    33 000-seed sweep among the well-conditioned cases; its 40-digit solution puts it on the oracle's account."""
+    import pydisort_amd
+    from oracle import disort_oracle as O
+    kw = make_case_64_streams(2197)
+    tau, phi = eval_points("random64", 2197, kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = O.pydisort(**kw)
+        got = pydisort_amd.pydisort(**kw)
+    assert not np.any(kw["omega_arr"] > 1 - 1e-5)
+    arbitrated("random64", 2197, got[4](tau, phi), ref[4](tau, phi), tol_scale=2e-9)
+
+
 def test_thermal_polynomial_in_a_near_conservative_thin_layer_is_as_good_as_the_reference():
     """The one input of the 41 000-seed sweeps on which the HIP path was FURTHER from the truth than the reference (seed 3736 of
     the 32-stream family): a single layer of optical depth 5.6e-4 with omega = 1 - 1e-6 and a quadratic thermal source, no
