@@ -292,7 +292,8 @@ def case_of(family, key):
     """(kwargs, tau, phi) of a random case exactly as its parity test builds them."""
     import test_gpu_random_parity as T
     seed = int(key)
-    kw = {"random": T.make_case, "random32": T.make_case_many_streams, "random64": T.make_case_64_streams}[family](seed)
+    kw = {"random": T.make_case, "random32": T.make_case_many_streams, "random64": T.make_case_64_streams,
+          "random128": T.make_case_128_streams}[family](seed)
     tau, phi = T.eval_points(family, seed, kw)
     return kw, tau, phi
 
