@@ -128,6 +128,13 @@ int rtd_plan_set_bdrf_samples(rtd_plan* plan, int32_t nphi, const double* rho_qq
  * shards gives the full result: rtd_comm_allreduce_results.  Default: first 0, stride 1, total = nfourier. */
 int rtd_plan_set_mode_shard(rtd_plan* plan, int32_t first, int32_t stride, int32_t total);
 
+/* Declares the uploaded inputs NEW without uploading them again: the next solve recomputes everything that depends on
+ * them -- the per-column associated-Legendre tables at -mu0 and the beam attenuations, which a plan otherwise keeps from run
+ * to run while its inputs are unchanged (the reference recomputes them in every call, _solve_for_gen_and_part_sols.py:96-109)
+ * -- and starts behind everything queued on the plan's stream, as after rtd_plan_set_columns.  For measurements of the
+ * fresh-input rate with inputs resident in HBM (bench.py: `value`; repeated inputs: `value_cached_tables`). */
+int rtd_plan_invalidate_tables(rtd_plan* plan);
+
 /* --- solve: _solve_for_gen_and_part_sols + _solve_for_coeffs on the device ---------------- */
 /* Asynchronous on the plan's stream. */
 int rtd_plan_solve(rtd_plan* plan);
@@ -270,6 +277,18 @@ enum {
                              np.linalg.solve / returns NaN in these cases (_solve_for_gen_and_part_sols.py:186, :226-231) */
 };
 
+/* --- environment read by the library (the complete list; tests/test_host_logic.py greps the sources against it) ---------
+ * None of these changes a result beyond rounding: they select between implementations that the test suite holds to the same
+ * parity (tests/test_gpu_parity.py runs the suite under each), size buffers, or print diagnostics.  Timing experiments whose
+ * results are NOT valid (e.g. the aliased hand-off reads of DESIGN.md section 7a) exist only behind compile-time -D flags.
+ *   RTD_WORK_BYTES        bytes of solve intermediates per plan (default 24 GiB): sizes the automatic column window
+ *   RTD_NO_PIPELINE       windows one after the other on one stream (no second hand-off slot, no eigen stream)
+ *   RTD_BC_FORCE_PIVOT    fused boundary-condition kernels: every elimination takes the column-pivoted redo
+ *   RTD_BC_FORCE_HANDOVER tiled (64-stream) kernel: every third chain goes to the pivoted row-per-lane kernels
+ *   RTD_BC_TILED          32 streams through the tiled kernel's T = 1 instance instead of rtd_bc_mfma_kernel
+ *   RTD_EIG_MFMA          eigen stage with its assembly GEMMs on the matrix cores (measured slower; a tested variant)
+ *   RTD_DEBUG             diagnostics on stderr
+ */
 #ifdef __cplusplus
 }
 #endif

@@ -133,6 +133,12 @@ struct rtd_plan {
   bool pipelined = false;
   bool fork_needed = true;               // inputs were (re)uploaded on `stream` since the last solve: the eigen stream must wait for them
   bool bc_recorded[2] = {false, false};  // ev_bc[slot] has been recorded by some earlier window (possibly of an earlier run)
+  // Pipelined plans keep the device status words (status, col_status, sweeps) twice and alternate between them from solve to
+  // solve: back-to-back runs overlap (the eigen stream starts run r + 1 while the boundary-condition and evaluation kernels of
+  // run r still raise bits on the plan's stream), so run r + 1 clears and fills the other set; the set it clears was last
+  // touched by run r - 1, which the eigen stream's first wait (ev_bc of run r) has behind it.
+  int *status2[2] = {nullptr, nullptr}, *col_status2[2] = {nullptr, nullptr}, *sweeps2[2] = {nullptr, nullptr};
+  int stat_idx = 0;
   hipStream_t eig_stream = nullptr;
   hipEvent_t ev_eig[2] = {nullptr, nullptr}, ev_bc[2] = {nullptr, nullptr}, ev_fork = nullptr;
   std::vector<void*> allocs;
@@ -167,6 +173,7 @@ struct rtd_plan {
   hipStream_t comm_stream = nullptr, copy_stream = nullptr;
   hipEvent_t ev_results = nullptr, ev_gathered = nullptr;
   bool gather_inflight = false;
+  bool gathered_here = false;  // the last results collective left the gathered arrays of ALL ranks on this rank
   // host-to-host pipeline (rtd_plan_run_fetch): two pinned staging slabs, one per window in flight
   char* stage[2] = {nullptr, nullptr};
   size_t stage_bytes = 0;
@@ -294,21 +301,35 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
     HIP_TRY(hipStreamWaitEvent(se, p->ev_fork, 0));
     p->fork_needed = false;
   }
+  // the device status words of this solve, cleared on the stream its first eigen kernel runs on (that kernel raises bits and
+  // sweep counts behind the clear).  Bits raised by an earlier solve whose results were never fetched must not be reported
+  // against this one (this solve's own evaluation, queued behind the clear, raises the tau bit again).
+  auto clear_status = [&](hipStream_t st) -> hipError_t {
+    hipError_t e = hipMemsetAsync(p->d.sweeps, 0, sizeof(int), st);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d.status, 0, sizeof(int), st);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d.col_status, 0, sizeof(int) * (size_t)p->d.C, st);
+    return e;
+  };
   if (with_solve) {
-    // (on the stream the first eigen kernel of this solve runs on: it raises bits and sweep counts behind these)
-    hipError_t e = hipMemsetAsync(p->d.sweeps, 0, sizeof(int), se);
-    // the device status word too: bits raised by an earlier solve whose results were never fetched must not be
-    // reported against this one (this solve's own evaluation, queued behind the memset, raises the tau bit again)
-    if (e == hipSuccess) e = hipMemsetAsync(p->d.status, 0, sizeof(int), se);
-    if (e == hipSuccess) e = hipMemsetAsync(p->d.col_status, 0, sizeof(int) * (size_t)p->d.C, se);
-    if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+    if (p->status2[1]) {  // pipelined plan: the other set of status words (see rtd_plan::status2)
+      p->stat_idx ^= 1;
+      p->d.status = p->status2[p->stat_idx];
+      p->d.col_status = p->col_status2[p->stat_idx];
+      p->d.sweeps = p->sweeps2[p->stat_idx];
+    }
+    if (!pipe) {
+      hipError_t e = clear_status(s);
+      if (e != hipSuccess) return fail(RTD_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+    }  // (pipelined: inside the first eigen stage, behind its wait for the previous run)
     p->numeric_status = 0;  // a new solve starts clean
   }
+  RtdDev all = p->d;
+  const RtdDev* all_tables = nullptr;
   if (with_solve && p->tables_cached && !p->tables_valid) {  // the tables of all columns, once per change of the inputs
-    RtdDev all = p->d;
     all.Y0 = p->Y0_all;
     all.att = p->att_all;
-    rtd_launch_tables(all, se, true);
+    if (pipe) all_tables = &all;  // launched by the first eigen stage, behind its wait: the previous run may still read them
+    else rtd_launch_tables(all, se, true);
     p->tables_valid = true;
   }
   const bool per_window_tables = !p->tables_cached;
@@ -318,6 +339,11 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
     const int slot = w & 1;
     RtdDev d = window_dev(p, c0, cnt, slot);
     if (p->bc_recorded[slot]) (void)hipStreamWaitEvent(se, p->ev_bc[slot], 0);  // the slot's previous tenant has been consumed
+    if (w == 0) (void)clear_status(se);  // (a failure here shows up as the launch error checked below)
+    if (w == 0 && all_tables) {
+      rtd_launch_tables(*all_tables, se, true);
+      all_tables = nullptr;
+    }
     if (per_window_tables) rtd_launch_tables(d, se, w == 0);
     rtd_launch_eig(d, se, 1);
     (void)hipEventRecord(p->ev_eig[slot], se);
@@ -467,26 +493,45 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   d.C = (int)C; d.L = (int)L; d.N = N; d.NP = (int)NP; d.P = (int)P; d.M = (int)M; d.Ns = (int)Ns;
   d.NBDRF = (int)NB; d.beam = dims->beam ? 1 : 0;
   d.flags = (getenv("RTD_BC_FORCE_PIVOT") ? 1 : 0) | (getenv("RTD_BC_FORCE_HANDOVER") ? 2 : 0);
-  if (const char* al = getenv("RTD_BC_ALIAS")) d.flags |= (atoi(al) & 3) << 2;  // timing experiment only (rtd_bc.hip)
   d.m0 = 0; d.mstep = 1; d.mtot = (int)M;
   d.l0 = 0; d.ln = (int)L;
-  // window of columns whose intermediates are resident: bytes of intermediates per column
+  // window of columns whose intermediates are resident: bytes of intermediates per column.  A plan of more than one window
+  // that pipelines them holds the eigen stage's hand-off buffers twice; a one-window (or RTD_NO_PIPELINE) plan once.
   const int64_t handoff_col = 8 * (M * P + (L + 1) + 2 * M * L * NP * NP + 2 * M * L * NP + M * L * Q2 + L * Ns * Q2 + L * NP);
-  const int64_t per_col = 2 * handoff_col + 8 * (M * L * Q2 + M * (L - 1) * Q2 * Q2);  // (hand-off buffers twice: window pipeline)
-  int64_t Cw = C;
-  if (work_columns > 0) {
-    Cw = std::min<int64_t>(C, work_columns);
-  } else {
-    const char* env = getenv("RTD_WORK_BYTES");
-    const double budget = env ? atof(env) : 24.0 * (double)(1ull << 30);
-    int64_t fit = (int64_t)(budget / (double)per_col);
+  const int64_t rest_col = 8 * (M * L * Q2 + M * (L - 1) * Q2 * Q2);
+  const bool may_pipeline = !getenv("RTD_NO_PIPELINE");
+  const int64_t per_col_one = handoff_col + rest_col, per_col_win = (may_pipeline ? 2 : 1) * handoff_col + rest_col;
+  const char* env = getenv("RTD_WORK_BYTES");
+  const double budget = env ? atof(env) : 24.0 * (double)(1ull << 30);
+  auto fit_window = [&](double bytes) {  // columns per window of a multi-window plan within `bytes`
+    int64_t fit = (int64_t)(bytes / (double)per_col_win);
     if (fit < 1) fit = 1;
     if (fit > 256) fit -= fit % 256;
-    Cw = std::min<int64_t>(C, fit);
+    return fit;
+  };
+  int64_t Cw = C;
+  if (work_columns > 0) {
+    // The caller's window is honoured while it fits: RTD_WORK_BYTES when set, else 80 % of the device memory that is free
+    // now (the 24 GiB default is the automatic path's choice, not a limit on an explicit request).  hipMemGetInfo is only
+    // asked when the request is large: one-column plans are created per pydisort() call.
+    Cw = std::min<int64_t>(C, work_columns);
+    const double want = (double)Cw * (double)(Cw < C ? per_col_win : per_col_one);
+    if (env ? want > budget : want > 4.0 * (double)(1ull << 30)) {
+      double cap = budget;
+      if (!env) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        cap = 0.8 * (double)free_b;
+      }
+      if (want > cap) Cw = std::min<int64_t>(Cw, fit_window(cap));
+    }
+  } else if ((double)C * (double)per_col_one > budget) {  // (a batch that fits one window pays for one hand-off slot only)
+    Cw = std::min<int64_t>(C, fit_window(budget));
   }
   p->Cw = (int)Cw;
   p->nwin = (int)((C + Cw - 1) / Cw);
-  p->pipelined = p->nwin > 1 && !getenv("RTD_NO_PIPELINE");
+  p->pipelined = p->nwin > 1 && may_pipeline;
   rtd_plan::HandOff& h1 = p->slot1;
   double *mu = nullptr, *w = nullptr, *invmu = nullptr, *S = nullptr, *T = nullptr, *omega = nullptr, *tau = nullptr,
          *taus0 = nullptr, *scale = nullptr, *wleg = nullptr, *mu0 = nullptr, *I0 = nullptr, *phi0 = nullptr,
@@ -521,6 +566,7 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
     if (p->pipelined) {
       A(h1.Y0, Cw * M * P) A(h1.att, Cw * (L + 1)) A(h1.Ym, Cw * M * L * NP * NP) A(h1.Am, Cw * M * L * NP * NP)
       A(h1.kk, Cw * M * L * NP) A(h1.Bv, Cw * M * L * Q2) A(h1.dq, Cw * L * Ns * Q2) A(h1.zneg, Cw * L * NP) A(h1.Ek, Cw * M * L * NP)
+      A(p->status2[1], 1) A(p->col_status2[1], C) A(p->sweeps2[1], 1)
     }
 #undef A
     if (pass == 0) {
@@ -552,6 +598,12 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   HIP_TRY(hipMemsetAsync(d.status, 0, sizeof(int), p->stream));
   HIP_TRY(hipMemsetAsync(d.col_status, 0, sizeof(int) * (size_t)C, p->stream));
   HIP_TRY(hipMemsetAsync(d.sweeps, 0, sizeof(int), p->stream));
+  if (p->pipelined) {
+    p->status2[0] = d.status; p->col_status2[0] = d.col_status; p->sweeps2[0] = d.sweeps;
+    HIP_TRY(hipMemsetAsync(p->status2[1], 0, sizeof(int), p->stream));
+    HIP_TRY(hipMemsetAsync(p->col_status2[1], 0, sizeof(int) * (size_t)C, p->stream));
+    HIP_TRY(hipMemsetAsync(p->sweeps2[1], 0, sizeof(int), p->stream));
+  }
   HIP_TRY(hipMemsetAsync(d.split_any, 0, sizeof(int), p->stream));
   HIP_TRY(hipMemsetAsync(d.Bv, 0, (size_t)(Cw * M * L * Q2) * 8, p->stream));
   if (Ns > 0) HIP_TRY(hipMemsetAsync(d.dq, 0, (size_t)(Cw * L * Ns * Q2) * 8, p->stream));
@@ -871,6 +923,13 @@ int rtd_plan_set_mode_shard(rtd_plan* p, int32_t first, int32_t stride, int32_t 
   return 0;
 }
 
+int rtd_plan_invalidate_tables(rtd_plan* p) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  p->tables_valid = false;
+  p->fork_needed = true;  // as after an upload: the next solve starts behind everything queued on the plan's stream
+  return 0;
+}
+
 int rtd_plan_solve(rtd_plan* p) {
   if (!p) return fail(RTD_ERR_ARG, "null plan");
   if (!p->have_quad || !p->have_cols) return fail(RTD_ERR_STATE, "set_quadrature and set_columns must precede solve");
@@ -1030,13 +1089,12 @@ int rtd_plan_evaluate(rtd_plan* p, int32_t ntau, const double* tau, int32_t nphi
   // intended entry point for such batches).
   rc = launch_windows(p, p->nwin > 1, &e, p->have_nt && !skip_nt, [](int, int64_t, int) { return 0; }, false);
   if (rc) return rc;
-  rc = rtd_plan_fetch(p, u, u0, flux_up, fdn, fdir);
-  if (rc) return rc;
-  if (ulast) {
+  if (ulast) {  // queued before the fetch, whose status check drains the stream: a numerical failure of SOME columns must not
+    //             leave the healthy columns' ulast unwritten (numeric_errors = "nan" keeps them)
     const int64_t C = p->d.C, Qr = 2 * p->d.N;
-    HIP_TRY(hipMemcpy(ulast, p->ev_u0 + C * Qr * ntau, (size_t)(C * Qr * ntau) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(ulast, p->ev_u0 + C * Qr * ntau, (size_t)(C * Qr * ntau) * 8, hipMemcpyDeviceToHost, p->stream));
   }
-  return 0;
+  return rtd_plan_fetch(p, u, u0, flux_up, fdn, fdir);
 }
 
 int rtd_plan_set_nt(rtd_plan* p, int32_t nleg_all, const double* weighted_leg_all, const double* f_arr,
@@ -1319,6 +1377,7 @@ int rtd_comm_allgather_results(rtd_plan* p) {
   if (nr != ncclSuccess) return fail(RTD_ERR_HIP, std::string("ncclAllGather: ") + r->GetErrorString(nr));
   HIP_TRY(hipEventRecord(p->ev_gathered, p->comm_stream));
   p->gather_inflight = true;
+  p->gathered_here = true;
   return 0;
 }
 
@@ -1366,6 +1425,7 @@ int rtd_comm_gather_results(rtd_plan* p, int32_t root) {
   if (nr != ncclSuccess) return fail(RTD_ERR_HIP, std::string("ncclSend / ncclRecv: ") + r->GetErrorString(nr));
   HIP_TRY(hipEventRecord(p->ev_gathered, cs));
   p->gather_inflight = true;
+  p->gathered_here = is_root;  // (a non-root rank may still hold full-size buffers of an earlier all-gather: they are stale now)
   return 0;
 }
 
@@ -1374,8 +1434,8 @@ int rtd_comm_fetch_gathered_results(rtd_plan* p, double* u, double* fluxes) {
   HIP_TRY(hipSetDevice(p->device));
   const int64_t C = p->d.C, Qr = 2 * p->d.N, nt = p->ev_ntau, np = p->ev_nphi;
   const int64_t nu = np > 0 ? C * Qr * nt * np : 0, nfl = 3 * C * nt;
-  if (p->cap_gathered_fl < nfl * p->comm_size || (u && nu > 0 && p->cap_gathered_u < nu * p->comm_size))
-    return fail(RTD_ERR_STATE, "this rank holds no gathered arrays (rtd_comm_gather_results: only the root does)");
+  if (!p->gathered_here || p->cap_gathered_fl < nfl * p->comm_size || (u && nu > 0 && p->cap_gathered_u < nu * p->comm_size))
+    return fail(RTD_ERR_STATE, "this rank holds no gathered arrays of the last collective (rtd_comm_gather_results: only the root does)");
   hipStream_t s = p->comm_stream;
   if (u && nu > 0) HIP_TRY(hipMemcpyAsync(u, p->gathered_u, (size_t)(nu * p->comm_size) * 8, hipMemcpyDeviceToHost, s));
   if (fluxes) HIP_TRY(hipMemcpyAsync(fluxes, p->gathered_fl, (size_t)(nfl * p->comm_size) * 8, hipMemcpyDeviceToHost, s));

@@ -854,7 +854,7 @@ __device__ __forceinline__ int chain_needs_pivoting(const RtdDev& d, const bool 
 
 // Four wavefronts per SIMD: <= 128 registers and <= 10 KB of LDS each, so the kernel prefetches one layer ahead, forms the
 // interface products one after the other (one accumulator set live), takes exp(-k dtau) from memory, saves t^T once and
-// rotates two operand sets in the backward sweep (128 VGPRs, 29 of them spilled outside the two loops; 9.8 KB).  The kernel
+// rotates two operand sets in the backward sweep (128 VGPRs, 36 dwords spilled outside the two loops -- profiles/*_kernel_resources.json; 9.8 KB).  The kernel
 // is bound by the latency of its dependent chains: a three-wavefront form (two layers of prefetch, the products side by
 // side, exp(-k dtau) in the LDS window: 168 VGPRs, 12.7 KB; removed in round 3) took 4.19-4.25 ms per 2 048 cfg4 columns
 // against this form's 4.08-4.11 ms, and padded to 7 / 9 / 12 wavefronts per CU 5.46 / 4.82 / 4.33 ms.
@@ -864,12 +864,18 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
   const long cm = blockIdx.x;
   const int m = (int)(cm % d.M), c = (int)(cm / d.M);
   const int L = d.L, Lm1 = L - 1;
-  // Timing experiment (RTD_BC_ALIAS=1 | 2 | 3, results are garbage): the chains read the eigen stage's hand-off of only 32
-  // chains (bit 0: 2.6 MB, served by the L2s) or of 2 048 chains (bit 1: 168 MB, served by the Infinity Cache); with both
-  // bits the factors H, s, rho_b of the forward sweep are aliased to 32 chains as well.  What the kernel takes then is
-  // the floor that any scheme for cutting its HBM traffic can approach (profiles/r03_experiments.json: bc_traffic_floor).
-  const long cmr = (d.flags & 4) ? cm % 32 : (d.flags & 8) ? cm % 2048 : cm;
-  const long cmw = ((d.flags & 12) == 12) ? cm % 32 : cm;
+#ifdef RTD_BC_ALIAS_EXPERIMENT
+  // Timing experiment of a PROFILING build only (-DRTD_BC_ALIAS_EXPERIMENT=1 | 2 | 3 through RTD_EXTRA_FLAGS; results are
+  // garbage; never part of the shipped library: tests/test_host_logic.py checks that no result-changing switch is read from
+  // the environment): the chains read the eigen stage's hand-off of only 32 chains (bit 0: 2.6 MB, served by the L2s) or of
+  // 2 048 chains (bit 1: 168 MB, served by the Infinity Cache); with both bits the factors H, s, rho_b of the forward sweep
+  // are aliased to 32 chains as well.  What the kernel takes then is the floor that any scheme for cutting its HBM traffic
+  // can approach (profiles/r03_experiments.json: bc_traffic_floor).
+  const long cmr = (RTD_BC_ALIAS_EXPERIMENT & 1) ? cm % 32 : (RTD_BC_ALIAS_EXPERIMENT & 2) ? cm % 2048 : cm;
+  const long cmw = ((RTD_BC_ALIAS_EXPERIMENT & 3) == 3) ? cm % 32 : cm;
+#else
+  const long cmr = cm, cmw = cm;
+#endif
   const double* Ym = d.Ym + cmr * L * NN;
   const double* Am = d.Am + cmr * L * NN;
   const double* kk = d.kk + cmr * L * NP;

@@ -91,10 +91,10 @@ __device__ __forceinline__ double approx_rcp(double x) {
 #endif
 
 #ifndef RTD_EIGEN32_WAVES
-#define RTD_EIGEN32_WAVES 2  /* waves per SIMD of the 64-stream eigen kernel (256 VGPRs, 23 spilled dwords; 1: 278 VGPRs) */
+#define RTD_EIGEN32_WAVES 2  /* waves per SIMD of the 64-stream eigen kernel (256 VGPRs; the spill counts of every kernel: profiles/*_kernel_resources.json, tools/kernel_resources.py; 1: 278 VGPRs) */
 #endif
 #ifndef RTD_EIGEN_WAVES
-#define RTD_EIGEN_WAVES 3  /* waves per SIMD the fused eigen kernel is compiled for at NP <= 16 (145 VGPRs, no spills, LDS 10.75 KB per
+#define RTD_EIGEN_WAVES 3  /* waves per SIMD the fused eigen kernel is compiled for at NP <= 16 (149 VGPRs, no spills, LDS 10.5 KB per
                               wavefront).  4 (128 VGPRs, 21-41 dwords spilled in the once-per-wavefront stages, packed L): 2 % slower (A/B) */
 #endif
 

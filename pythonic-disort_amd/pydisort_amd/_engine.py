@@ -177,6 +177,11 @@ class Plan:
         _lib.check(self._lib.rtd_plan_run(self._h))
         self.solved = True
 
+    def invalidate_tables(self):
+        """Treat the resident inputs as new: the next solve recomputes the per-column Legendre tables at -mu0 and the beam
+        attenuations it would otherwise keep from run to run (include/rtd.h: rtd_plan_invalidate_tables)."""
+        _lib.check(self._lib.rtd_plan_invalidate_tables(self._h))
+
     def windows(self):
         """(columns per window, number of windows) of the plan's work arena."""
         a, b = C.c_int32(), C.c_int32()

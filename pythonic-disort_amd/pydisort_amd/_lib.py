@@ -42,6 +42,7 @@ SIGNATURES = {
     "rtd_plan_set_columns_raw": (C.c_int, [_vp, _dp, _dp, _dp, C.c_int32] + [_dp] * 9),
     "rtd_plan_set_bdrf_samples": (C.c_int, [_vp, C.c_int32, _dp, _dp]),
     "rtd_plan_set_mode_shard": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32]),
+    "rtd_plan_invalidate_tables": (C.c_int, [_vp]),
     "rtd_plan_solve": (C.c_int, [_vp]),
     "rtd_solve_batch": (C.c_int, [C.POINTER(rtd_dims), C.c_int32, C.POINTER(rtd_inputs), C.c_int32, _dp, C.c_int32, _dp]
                         + [_dp] * 5),

@@ -174,7 +174,8 @@ def solve_columns_streamed(cfg, tau, phi, chunk_columns=0, device=0, only_flux=F
     C, ntau = tau.shape
     if chunk_columns <= 0:
         # windows of ~8 192 (column, mode) chains: the two-stream window pipeline of the library does best there (256 cfg4
-        # columns: +4 % over windows of 2 048); the library caps it by its memory budget
+        # columns: +4 % over windows of 2 048); the library shrinks a window that does not fit the
+        # device (RTD_WORK_BYTES when set, else 80 % of the free device memory: rtd_api.hip plan_build)
         nq = int(cfg["NQuad"])
         modes = 1 if only_flux else int(cfg.get("NFourier") or cfg.get("NLeg") or nq)
         chunk_columns = max(64, 8192 // max(modes, 1))
