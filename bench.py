@@ -13,8 +13,11 @@ outputs of all ranks, on its own stream so that it overlap
                             solved in windows of --columns columns (256; the eigen kernel of window w + 1 runs beside the boundary-
                             condition kernel of window w on two streams): a step = the whole batch, 100000/N per GPU
   weak scaling            : --total-columns 0: every GPU solves --columns columns per step
-  --gather all|root|none  : what happens to the results of a step when N > 1 -- ncclAllGather to every rank (default),
-                            ncclSend/ncclRecv to rank 0 only, or nothing (compute scaling alone)
+  --gather auto|all|root|none : what happens to the results of a step when N > 1 -- ncclAllGather to every rank, ncclSend/ncclRecv to
+                            rank 0 only, or nothing (compute scaling alone); auto (default) takes the all-gather unless it is >= 3 %
+                            slower than root-only.  Whatever is gathered is VERIFIED before the line is printed (every rank's slot
+                            against a local solve of the same columns, bit for bit; exit 4 on a mismatch), and the line carries the
+                            compute-only / all-gather / root-only rates of the same run (`gather_rates`).
 
 Launch: `python bench.py --gpus N ...` starts N fresh rank processes itself (one per GPU, before anything in
 this process has touched a GPU) unless it already runs under torch.distributed.run (RANK / WORLD_SIZE set),
@@ -39,7 +42,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "pythonic-disort_amd")]
 
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector = matrix peak (vendor figure)
 L, NQUAD, NTAU, NPHI = 20, 32, 21, 3
-EXIT_RANKS, EXIT_RCCL, EXIT_TIMEOUT = 2, 3, 124
+EXIT_RANKS, EXIT_RCCL, EXIT_VERIFY, EXIT_TIMEOUT = 2, 3, 4, 124
 
 
 def algorithmic_flops(nlayers=L, nquad=NQUAD, nmodes=None, ntau=NTAU):
@@ -509,6 +512,63 @@ def shard_columns(rank, world, columns_per_gpu, total_columns=0):
     return rank * columns_per_gpu, columns_per_gpu
 
 
+def verification_columns(count, rank, per_rank=4):
+    """Which columns of a rank's shard the gathered results are checked on: the first, the last and seeded interior ones
+    (different windows of the shard)."""
+    rng = np.random.default_rng([2024, rank, count])
+    picks = {0, count - 1} | {int(i) for i in rng.integers(0, count, size=max(0, per_rank - 2))}
+    for i in range(count):  # (tiny shards: fill up deterministically)
+        if len(picks) >= min(per_rank, count):
+            break
+        picks.add(i)
+    return sorted(picks)
+
+
+def shard_config(rank, world, columns_per_gpu, total_columns):
+    """The synthetic inputs of a rank's shard, exactly as that rank generates them (deterministic in the shard)."""
+    from pydisort_amd import synthetic
+    first, count = shard_columns(rank, world, columns_per_gpu, total_columns)
+    cfg = synthetic.cfg4_columns_block(count, first=first) if total_columns > 0 else synthetic.cfg4_columns(count, first=first)
+    return cfg, first, count
+
+
+def prepare_cfg4(cfg):
+    from pydisort_amd._prepare import prepare_columns
+    C, N = cfg["tau_arr"].shape[0], NQUAD // 2
+    return prepare_columns(cfg["tau_arr"], cfg["omega_arr"], NQUAD, cfg["Leg_coeffs_all"], cfg["mu0"], cfg["I0"],
+                           cfg["phi0"], NQUAD, NQUAD, None, None,  # no Dirichlet sources: nothing to allocate or upload
+                           cfg["f_arr"], np.zeros((C, L, 0)), np.zeros((C, 0, N, N)), np.zeros((C, 0, N)))
+
+
+def verify_gathered(plan, device, world, columns_per_gpu, total_columns, per_rank=4):
+    """The gathered arrays against the truth, on a rank that holds them: for EVERY rank's shard, regenerate its inputs, solve
+    `per_rank` of its columns here on their own (a small one-window plan) and compare them bit for bit with that rank's
+    slot of the gathered u and fluxes.  Catches wrong offsets, rank order, stale or torn slots.  Returns (ok, ranks, detail)."""
+    from pydisort_amd._engine import Plan
+    detail = []
+    ok = True
+    for r in range(world):
+        cfg, _, count = shard_config(r, world, columns_per_gpu, total_columns)
+        idx = verification_columns(count, r, per_rank)
+        sub = {k: (v[idx] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == count else v) for k, v in cfg.items()}
+        small = Plan(prepare_cfg4(sub), device=device)
+        try:
+            small.set_eval_points(np.concatenate((np.zeros((len(idx), 1)), sub["tau_arr"]), axis=1), np.array([0.0, np.pi / 2, np.pi]))
+            small.run()
+            want = small.fetch()
+        finally:
+            small.close()
+        bad = 0
+        for j, i in enumerate(idx):
+            gu, gf = plan.fetch_gathered_columns(r, i, 1)
+            same = (np.array_equal(gu[0], want["u"][j]) and np.array_equal(gf[0, 0], want["flux_up"][j])
+                    and np.array_equal(gf[1, 0], want["flux_down_diffuse"][j]) and np.array_equal(gf[2, 0], want["flux_down_direct"][j]))
+            bad += 0 if same else 1
+        ok = ok and bad == 0
+        detail.append({"rank": r, "columns": idx, "mismatches": bad})
+    return ok, world, detail
+
+
 def reduce_max_seconds(dist, seconds):
     """Max over ranks of a host-side duration through the (gloo) control plane."""
     import torch
@@ -625,11 +685,8 @@ def run_rank(a, rank, world, local):
                   "contract (check ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES and --gpus)", file=sys.stderr)
             sys.stderr.flush()
             os._exit(EXIT_RANKS)
-        cfg = synthetic.cfg4_columns_block(C, first=first) if strong else synthetic.cfg4_columns(C, first=first)
-        N = NQUAD // 2
-        prep = prepare_columns(cfg["tau_arr"], cfg["omega_arr"], NQUAD, cfg["Leg_coeffs_all"], cfg["mu0"], cfg["I0"],
-                               cfg["phi0"], NQUAD, NQUAD, None, None,  # no Dirichlet sources: nothing to allocate or upload
-                               cfg["f_arr"], np.zeros((C, L, 0)), np.zeros((C, 0, N, N)), np.zeros((C, 0, N)))
+        cfg, _, _ = shard_config(rank, world, a.columns, a.total_columns)
+        prep = prepare_cfg4(cfg)
         if multi:
             Plan.comm_preload()  # bind RCCL to librtd's HIP runtime before torch (gloo control plane) is imported
         plan = Plan(prep, device=local, work_columns=a.columns)  # uploads: inputs now resident in HBM
@@ -638,6 +695,8 @@ def run_rank(a, rank, world, local):
 
     dist = None
     gather = None
+    gather_calls = {}
+    chosen = "none"
     collective = "none (single rank)"
     watchdog = None
     if multi:
@@ -668,14 +727,15 @@ def run_rank(a, rank, world, local):
                     err = e
             dist.broadcast_object_list(uid, src=0)
             ok = uid[0] is not None
+            gather_calls = {"all": plan.allgather_results, "root": lambda: plan.gather_results(0), "none": None}
             if ok:
-                gather_call = {"all": plan.allgather_results, "root": lambda: plan.gather_results(0), "none": None}[a.gather]
                 try:
                     plan.comm_init(uid[0], rank, world)
-                    plan.run()
-                    if gather_call:
-                        gather_call()
-                    plan.synchronize()
+                    for mode in (("all", "root") if a.gather == "auto" else (a.gather,)):  # every collective the run may use, once
+                        plan.run()
+                        if gather_calls[mode]:
+                            gather_calls[mode]()
+                        plan.synchronize()
                 except Exception as e:
                     ok, err = False, e
             if not ok:
@@ -685,11 +745,6 @@ def run_rank(a, rank, world, local):
             if not everyone:
                 sys.stderr.flush()
                 os._exit(EXIT_RCCL)  # no clean-up through a communicator that may be half-built
-            gather = gather_call
-            collective = {
-                "all": f"rccl ncclAllGather of u + fluxes per step, nranks = {world}, on its own stream (overlaps the next step)",
-                "root": f"rccl ncclSend/ncclRecv of u + fluxes to rank 0 per step, nranks = {world}, on its own stream",
-                "none": f"rccl communicator of {world} ranks initialised, no data-path collective (--gather none)"}[a.gather]
 
     def barrier():
         if plan is not None:
@@ -697,27 +752,53 @@ def run_rank(a, rank, world, local):
         if dist is not None:
             dist.barrier()
 
-    def step():
+    def timed(nsteps, gather_fn, fresh):
+        """nsteps steps between barriers + device synchronisation on both sides -> seconds, max over the ranks.
+        fresh: every step treats the resident inputs as new (the per-column Legendre tables at -mu0 and the beam attenuations
+        are recomputed: what the reference does in every call, _solve_for_gen_and_part_sols.py:96-109)."""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            if plan is not None:
+                if fresh:
+                    plan.invalidate_tables()
+                plan.run()
+                if gather_fn:
+                    gather_fn()
+            else:
+                time.sleep(0.001)
         if plan is not None:
-            plan.run()
-            if gather:
-                gather()
-        else:
-            time.sleep(0.001)
+            plan.synchronize()
+        el = time.perf_counter() - t0
+        barrier()
+        return reduce_max_seconds(dist, el) if dist is not None else el
 
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    if plan is not None:
-        plan.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
+    # which collective the timed region uses.  --gather auto (the default): ncclAllGather to every rank unless it costs the
+    # step >= 3 % more than gathering on rank 0 alone (SURVEY 8(e) allows root-only "if only rank 0 needs results"); decided
+    # from max-over-ranks times of short trial regions, so every rank decides alike.
+    gather_rates = {}
+    probe = max(2, min(a.steps, 3))
+    if multi and not stub:
+        chosen = a.gather
+        if a.gather == "auto":
+            trial = {}
+            for mode in ("all", "root"):
+                timed(1, gather_calls[mode], True)
+                trial[mode] = timed(probe, gather_calls[mode], True)
+            chosen = "root" if trial["all"] > 1.03 * trial["root"] else "all"
+        gather = gather_calls[chosen]
+        collective = {
+            "all": f"rccl ncclAllGather of u + fluxes per step, nranks = {world}, on its own stream (overlaps the next step)",
+            "root": f"rccl ncclSend/ncclRecv of u + fluxes to rank 0 per step, nranks = {world}, on its own stream",
+            "none": f"rccl communicator of {world} ranks initialised, no data-path collective (--gather none)"}[chosen]
+        if a.gather == "auto":
+            collective += " [--gather auto: chosen from trial regions, all-gather unless >= 3 % slower than root-only]"
+
+    timed(a.warmup, gather, True) if a.warmup > 0 else barrier()
+    elapsed = timed(a.steps, gather, True)          # THE timed region: exactly --steps steps, fresh inputs every step
+    elapsed_cached = timed(a.steps, gather, False)  # the same on repeated inputs (tables kept from run to run)
     joined = world
     if dist is not None:
-        elapsed = reduce_max_seconds(dist, elapsed)
         import torch
         cnt = torch.tensor([C], dtype=torch.int64)
         dist.all_reduce(cnt)
@@ -730,6 +811,36 @@ def run_rank(a, rank, world, local):
     if joined != world:
         print(f"[bench] only {joined} of {world} ranks took part", file=sys.stderr)
         os._exit(EXIT_RANKS)
+
+    # N > 1 (or --force-dist): the gathered arrays are CHECKED before any number is reported -- every rank that holds them
+    # compares >= 4 columns of every rank's slot with a local solve of the same columns, bit for bit -- and the compute-only and
+    # per-collective rates of the same run go into the line, so that one scaling run separates compute scaling from the
+    # cost of the collective.
+    verified = None
+    if multi and not stub:
+        holds = chosen == "all" or (chosen == "root" and rank == 0)
+        ok, detail = True, None
+        if chosen != "none":
+            timed(1, gather, True)  # (a fresh gather of a known step; its results are what is checked)
+            if holds:
+                try:
+                    ok, nver, detail = verify_gathered(plan, local, world, a.columns, a.total_columns)
+                except Exception as e:
+                    ok, detail = False, repr(e)
+                if not ok:
+                    print(f"[bench] rank {rank}: gathered results differ from a local solve of the same columns: {detail}", file=sys.stderr)
+            if not all_ranks_ok(dist, ok):
+                sys.stderr.flush()
+                os._exit(EXIT_VERIFY)
+            verified = {"gather_verified": True, "ranks_verified": world, "columns_per_rank": 4,
+                        "verified_on": "every rank" if chosen == "all" else "rank 0", "how": "bit-for-bit against a local one-window solve of "
+                        "the same regenerated columns (u and the three fluxes)", "detail": detail}
+        for mode in ("none", "all", "root"):
+            if mode == chosen:
+                gather_rates[mode] = total_cols * a.steps / elapsed
+            elif mode in gather_calls and (a.gather == "auto" or mode == "none"):
+                timed(1, gather_calls[mode], True)
+                gather_rates[mode] = total_cols * probe / timed(probe, gather_calls[mode], True)
 
     # per-kernel HIP-event times from a separate short pass (events + a stream sync per window would otherwise sit
     # inside the timed region; the timed region above is the free-running pipeline)
@@ -755,6 +866,12 @@ def run_rank(a, rank, world, local):
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64",
             "timed_seconds": elapsed,
+            "value_means": "fresh inputs every step: inputs resident in HBM, nothing kept from step to step -- the per-column "
+                           "Legendre tables at -mu0 and the beam attenuations are recomputed like everything else (the reference "
+                           "computes them in every call)",
+            "value_cached_tables": total_cols * a.steps / elapsed_cached,
+            "value_cached_tables_means": "the same steps on REPEATED inputs: a plan keeps those per-column tables while its inputs are "
+                                         "unchanged (rtd_tables_mu0_kernel runs once; a serving optimisation, not the headline)",
             "data": "synthetic",
             "config": {"workload": "cfg4: synthetic Henyey-Greenstein, 20 layers, 32 streams, 32 Fourier modes, "
                                    "delta-M on, beam source, u at 21 interfaces x 3 azimuths + fluxes",
@@ -764,6 +881,16 @@ def run_rank(a, rank, world, local):
                        "parallelism": f"column-sharded x{world}", "collective": collective,
                        "max_jacobi_sweeps": sweeps},
         }
+        if verified is not None:
+            out["config"].update(gather_verified=verified["gather_verified"], ranks_verified=verified["ranks_verified"])
+            out["gather_verification"] = verified
+        elif multi and not stub:
+            out["config"].update(gather_verified=None, ranks_verified=0)  # --gather none: nothing is gathered
+        if gather_rates:
+            out["gather_rates"] = {"unit": "column-solves/sec, whole job", "chosen": chosen, "compute_only": gather_rates.get("none"),
+                                   "allgather": gather_rates.get("all"), "root_only": gather_rates.get("root"),
+                                   "what": "the same run with no data-path collective, with ncclAllGather to every rank and with "
+                                           "ncclSend/ncclRecv to rank 0: compute scaling and the cost of the collective, separately"}
         if stage is not None:
             fl = algorithmic_flops()
             nwin = max(1, -(-C // a.columns))
@@ -787,8 +914,7 @@ def run_rank(a, rank, world, local):
                             "achieved = algorithmic FLOPs of the kernel x columns per launch / its HIP-event duration (separate "
                             "timing pass after the timed region, windows one after the other; the timed region itself runs the "
                             "eigen kernel of window w + 1 beside the boundary-condition kernel of window w on two streams); "
-                            "traffic = HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes at this "
-                            "window size (profiles/r03_pmc_traffic.json), not measured in this run")
+                            "traffic = HBM bytes per launch of that kernel: see traffic_source")
             out["roofline"] = roof
             ev = north_star_evidence(a.columns, elapsed / a.steps / max(nwin, 1), live)
             if ev:
@@ -814,8 +940,9 @@ def main():
     ap.add_argument("--total-columns", type=int, default=100_000,
                     help="strong scaling (default, BASELINE's literal batch: 100000): this many columns in total per step, "
                          "split over the GPUs; 0 = weak scaling, --columns per GPU per step")
-    ap.add_argument("--gather", choices=("all", "root", "none"), default="all",
-                    help="N > 1: results of a step to every rank (ncclAllGather), to rank 0 only (ncclSend/ncclRecv), or nowhere")
+    ap.add_argument("--gather", choices=("auto", "all", "root", "none"), default="auto",
+                    help="N > 1: results of a step to every rank (ncclAllGather), to rank 0 only (ncclSend/ncclRecv), or nowhere; "
+                         "auto (default): all-gather unless trial regions show it >= 3 %% slower than root-only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the parity, only_flux and end-to-end legs (profiling runs: every kernel launch is then the workload)")

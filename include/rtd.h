@@ -247,6 +247,10 @@ int rtd_comm_gather_results(rtd_plan* plan, int32_t root);
 /* host copies of the gathered results: u [nranks][C][NQuad][ntau][nphi] (= all nranks * C columns in rank order),
  * fluxes [nranks][3][C][ntau]; either may be NULL */
 int rtd_comm_fetch_gathered_results(rtd_plan* plan, double* u, double* fluxes);
+/* A slice of the gathered results: the columns [first, first + count) of rank `rank`'s shard -- u [count][NQuad][ntau][nphi],
+ * fluxes [3][count][ntau]; either may be NULL.  What a consumer (or a verification: bench.py checks every rank's slot
+ * against a local solve of the same columns) reads without copying all nranks * C columns to the host. */
+int rtd_comm_fetch_gathered_columns(rtd_plan* plan, int32_t rank, int32_t first, int32_t count, double* u, double* fluxes);
 /* Layer shards (the north star's variant "(layer x mode x column) instances sharded, a single
  * all-gather to stitch the boundary-condition system"): the eigen stage is independent per layer
  * (_solve_for_gen_and_part_sols.py:114), the boundary-condition solve couples the layers (_solve_for_coeffs.py:296-323).

@@ -1443,6 +1443,26 @@ int rtd_comm_fetch_gathered_results(rtd_plan* p, double* u, double* fluxes) {
   return 0;
 }
 
+int rtd_comm_fetch_gathered_columns(rtd_plan* p, int32_t rank, int32_t first, int32_t count, double* u, double* fluxes) {
+  if (!p || !p->gathered_fl) return fail(RTD_ERR_STATE, "nothing gathered");
+  HIP_TRY(hipSetDevice(p->device));
+  const int64_t C = p->d.C, Qr = 2 * p->d.N, nt = p->ev_ntau, np = p->ev_nphi;
+  const int64_t per_u = np > 0 ? Qr * nt * np : 0, nu = C * per_u, nfl = 3 * C * nt;
+  if (rank < 0 || rank >= p->comm_size || first < 0 || count < 1 || (int64_t)first + count > C)
+    return fail(RTD_ERR_ARG, "gathered columns: rank or column range outside the gathered arrays");
+  if (!p->gathered_here || p->cap_gathered_fl < nfl * p->comm_size || (u && nu > 0 && p->cap_gathered_u < nu * p->comm_size))
+    return fail(RTD_ERR_STATE, "this rank holds no gathered arrays of the last collective (rtd_comm_gather_results: only the root does)");
+  hipStream_t s = p->comm_stream;  // behind the collective
+  if (u && per_u > 0)
+    HIP_TRY(hipMemcpyAsync(u, p->gathered_u + rank * nu + first * per_u, (size_t)(count * per_u) * 8, hipMemcpyDeviceToHost, s));
+  if (fluxes)
+    for (int f = 0; f < 3; ++f)
+      HIP_TRY(hipMemcpyAsync(fluxes + (int64_t)f * count * nt, p->gathered_fl + rank * nfl + f * C * nt + (int64_t)first * nt,
+                             (size_t)(count * nt) * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
 namespace {
 // [CM][L][E] <-> layer-major staging [L'][CM][E] for the layers [l0, l0 + ln): to_stage packs, else unpacks
 __global__ void rtd_layer_stage_kernel(double* arr, double* stage, long CM, int L, int E, int l0, int ln, int to_stage) {

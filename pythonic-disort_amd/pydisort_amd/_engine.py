@@ -276,6 +276,15 @@ class Plan:
         _lib.check(self._lib.rtd_comm_fetch_gathered_results(self._h, _lib.dptr(u), _lib.dptr(fl)))
         return u, fl
 
+    def fetch_gathered_columns(self, rank, first, count, want_u=True):
+        """-> (u [count, Q, ntau, nphi] or None, fluxes [3, count, ntau]): the columns [first, first + count) of rank
+        `rank`'s shard in the gathered arrays of the last allgather_results() / gather_results()."""
+        ntau, nphi = self._ev_shape
+        u = np.empty((count, self.Q, ntau, nphi)) if want_u else None
+        fl = np.empty((3, count, ntau))
+        _lib.check(self._lib.rtd_comm_fetch_gathered_columns(self._h, int(rank), int(first), int(count), _lib.dptr(u), _lib.dptr(fl)))
+        return u, fl
+
     def fetch_gathered(self):
         out = np.empty((self._nranks, 3, self.C, self._ev_shape[0]))
         _lib.check(self._lib.rtd_comm_fetch_gathered(self._h, _lib.dptr(out)))

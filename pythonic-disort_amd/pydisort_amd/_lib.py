@@ -71,6 +71,7 @@ SIGNATURES = {
     "rtd_comm_allgather_results": (C.c_int, [_vp]),
     "rtd_comm_gather_results": (C.c_int, [_vp, C.c_int32]),
     "rtd_comm_fetch_gathered_results": (C.c_int, [_vp, _dp, _dp]),
+    "rtd_comm_fetch_gathered_columns": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
     "rtd_comm_fetch_gathered": (C.c_int, [_vp, _dp]),
     "rtd_comm_destroy": (C.c_int, [_vp]),
 }
