@@ -196,27 +196,36 @@ def cpu_baseline_subprocess():
 # live HBM traffic: rocprofv3 --pmc passes over a short child run of the same workload (before this process touches a GPU)
 # ---------------------------------------------------------------------------------------------------------
 def pmc_child(columns):
-    """The workload of the traffic passes: one warm-up and one measured step of 32 windows, windows one after the other
-    (a kernel's counters are its own).  No output."""
+    """The workload of the traffic passes: for the headline config (32 windows of `columns` cfg4 columns) and for BASELINE's other
+    configs (cfg5: 2 windows of 128 columns; cfg3 at both sizes: 1 024 columns) one warm-up and one measured pass each, windows one
+    after the other (RTD_NO_PIPELINE: a kernel's counters are its own).  The configs use different kernel instances (NP = 16,
+    32, 8, 4), so one profiler pass serves them all.  No output."""
+    import pydisort_amd
     from pydisort_amd import synthetic
     from pydisort_amd._engine import Plan
-    from pydisort_amd._prepare import prepare_columns
-    C, N = 32 * columns, NQUAD // 2
+    C = 32 * columns
     cfg = synthetic.cfg4_columns_block(C, first=0)
-    prep = prepare_columns(cfg["tau_arr"], cfg["omega_arr"], NQUAD, cfg["Leg_coeffs_all"], cfg["mu0"], cfg["I0"], cfg["phi0"], NQUAD,
-                           NQUAD, None, None, cfg["f_arr"], np.zeros((C, L, 0)), np.zeros((C, 0, N, N)), np.zeros((C, 0, N)))
-    plan = Plan(prep, device=0, work_columns=columns)
+    plan = Plan(prepare_cfg4(cfg), device=0, work_columns=columns)
     plan.set_eval_points(np.concatenate((np.zeros((C, 1)), cfg["tau_arr"]), axis=1), np.array([0.0, np.pi / 2, np.pi]))
     for _ in range(2):
         plan.run()
     plan.synchronize()
     plan.close()
+    for maker, kw, cols, win in (("cfg5_columns", {}, 256, 128), ("cfg3_columns", {"big": True}, 1024, 0), ("cfg3_columns", {"big": False}, 1024, 0)):
+        cfg = getattr(synthetic, maker)(cols, **kw)
+        _, sol = pydisort_amd.pydisort_batch(device=0, work_columns=win, _defer_solve=True, **cfg)
+        sol.plan.set_eval_points(np.concatenate((np.zeros((cols, 1)), cfg["tau_arr"]), axis=1), np.array([0.0, np.pi / 2, np.pi]))
+        for _ in range(2):
+            sol.plan.run()
+        sol.plan.synchronize()
+        sol.plan.close()
 
 
-def live_traffic(columns, timeout=150):
-    """HBM bytes per launch of the two main kernels, measured NOW: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE cannot
-    share one) of `bench.py --pmc-child`, corrected as MI355X_MICROARCH.md prescribes (KiB units; FETCH_SIZE doubled on
-    gfx950).  Returns {kernel: bytes per launch} or None when rocprofv3 is not usable here."""
+def live_traffic(columns, timeout=240):
+    """HBM bytes per launch of every kernel of the headline config and of BASELINE's other configs, measured NOW: two rocprofv3
+    passes (FETCH_SIZE and WRITE_SIZE cannot share one) of `bench.py --pmc-child`, corrected as MI355X_MICROARCH.md prescribes
+    (KiB units; FETCH_SIZE doubled on gfx950).  Returns {kernel name with its template arguments: bytes per launch} -- the
+    plain name too where only one instance of a kernel ran -- or None when rocprofv3 is not usable here."""
     import csv
     import re
     import shutil
@@ -242,11 +251,11 @@ def live_traffic(columns, timeout=150):
                 acc = {}
                 with open(files[0]) as f:
                     for row in csv.DictReader(f):
-                        m = re.search(r"rtd_\w+", row["Kernel_Name"])
+                        m = re.search(r"rtd_\w+(<[^>]*>)?", row["Kernel_Name"])
                         if m and row["Counter_Name"] == counter:
-                            acc.setdefault(m.group(0), []).append(float(row["Counter_Value"]))
+                            acc.setdefault(m.group(0).replace(", ", ","), []).append(float(row["Counter_Value"]))
                 for k, v in acc.items():
-                    v = v[len(v) // 2:]  # the second (measured) step
+                    v = v[len(v) // 2:]  # the second (measured) pass
                     got.setdefault(k, {})[counter] = sum(v) / len(v)
             finally:
                 shutil.rmtree(out, ignore_errors=True)
@@ -254,8 +263,16 @@ def live_traffic(columns, timeout=150):
         print(f"[bench] live traffic unavailable: {e!r}", file=sys.stderr)
         return None
     # (the table kernels run once per change of the inputs, not per window: they are not part of a window's traffic)
-    return {k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in got.items()
-            if len(v) == 2 and not k.startswith("rtd_tables")} or None
+    res = {k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in got.items() if len(v) == 2 and not k.startswith("rtd_tables")}
+    return res or None
+
+
+def traffic_of(live, names):
+    """Sum of the measured bytes per launch of the kernel instances in `names` ("rtd_eigen_kernel<16,2>" ...), None if unmeasured."""
+    if not live:
+        return None
+    vals = [live.get(n.replace(", ", ",")) for n in names]
+    return None if any(v is None for v in vals) else float(sum(vals))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -297,7 +314,7 @@ def golden_parity(name, maker, kwargs, device):
             "against": f"reference-computed goldens tests/golden/synth/{name}.npz"}
 
 
-def config_leg(name, golden, maker, kwargs, columns, window, device, passes):
+def config_leg(name, golden, maker, kwargs, columns, window, device, passes, live=None):
     """One of BASELINE's other configs through the same path: resident rate (plan.run over all windows), host-to-host
     rate (run_fetch: D2H of a window overlapped with the next window's kernels), HIP-event kernel times -> roofline,
     parity of the first columns against the reference-computed goldens."""
@@ -321,7 +338,19 @@ def config_leg(name, golden, maker, kwargs, columns, window, device, passes):
     t0 = time.perf_counter()
     out_arrays = plan.run_fetch()
     e2e = columns / (time.perf_counter() - t0)
-    assert np.all(np.isfinite(out_arrays["flux_up"]))
+    assert np.all(np.isfinite(out_arrays["flux_up"])) and np.all(np.isfinite(out_arrays["u"]))
+    # the batch's first columns ARE the reference-computed golden columns (the generators are deterministic per column): the
+    # results of the timed, windowed, pipelined pass itself against the reference at the interfaces
+    z = np.load(os.path.join(ROOT, "tests", "golden", "synth", golden + ".npz"))
+    in_batch = in_batch_pw = 0.0
+    for i in range(int(z["ncol"])):
+        pts = np.searchsorted(z[f"c{i}.tau_pts"], tau[i])
+        assert np.array_equal(z[f"c{i}.tau_pts"][pts], tau[i])
+        want = z[f"c{i}.u"][:, pts, :3]
+        diff = np.abs(out_arrays["u"][i] - want)
+        sig = np.abs(want) > 1e-8 * np.max(np.abs(want))
+        in_batch = max(in_batch, float(diff.max() / np.max(np.abs(want))))
+        in_batch_pw = max(in_batch_pw, float((diff[sig] / np.abs(want[sig])).max()))
     plan.enable_timing(True)
     plan.timing(reset=True)
     for _ in range(2):
@@ -336,11 +365,18 @@ def config_leg(name, golden, maker, kwargs, columns, window, device, passes):
     roof, ms = roofline_of(stage, fl, columns / nwin, names)
     roof["whole_path_tflops"] = fl["total"] * rate / 1e12
     roof["whole_path_frac"] = roof["whole_path_tflops"] / FP64_PEAK_TFLOPS
-    roof["traffic"] = None
+    # measured HBM bytes per launch of the dominant kernel(s) (the live rocprofv3 passes of this run; cfg5's child runs windows of
+    # the same 128 columns, cfg3's the same 1 024 columns in one launch)
+    dom_names = [k.strip() for k in roof["kernel"].split("+")]
+    roof["traffic"] = traffic_of(live, dom_names)
+    roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation" if roof["traffic"] is not None
+                              else "not measured (no profiler in this run)")
     plan.close()
     return {"value": rate, "unit": "column-solves/sec", "workload": name, "columns": columns, "columns_per_window": cw,
             "windows": nwin, "host_to_host": e2e, "mflop_per_column": fl["total"] / 1e6, "roofline": roof,
-            "parity": golden_parity(golden, maker, kwargs, device)}
+            "parity": golden_parity(golden, maker, kwargs, device),
+            "parity_in_batch": {"max_scale_rel": in_batch, "max_rel_dI": in_batch_pw, "columns_checked": int(z["ncol"]),
+                                "against": f"the same goldens, taken from the results of the full {columns}-column windowed pass (run_fetch) at the interfaces"}}
 
 
 def single_column_leg(device, calls=30):
@@ -411,7 +447,7 @@ def many_stream_leg(device, columns=32):
                        "columns_checked": 1, "against": "reference-computed golden tests/golden/synth/q128.npz (128 streams, 2 layers, 64 modes)"}}
 
 
-def extra_measurements(device, main_cfg=None, window=2048):
+def extra_measurements(device, main_cfg=None, window=2048, live=None):
     """max |dI| of the HIP path against the oracle on the sample columns of the cpu_baseline leg, the only_flux
     throughput, the host-to-host rate of the main batch, and BASELINE's other configs."""
     import pydisort_amd
@@ -452,11 +488,12 @@ def extra_measurements(device, main_cfg=None, window=2048):
     out["other_configs"] = {
         "cfg2_cloudC1_Q32_single_column": single_column_leg(device),
         "cfg3_L6_Q8_x1024": config_leg("cfg3: Test Problem 9c (6 layers, 8 streams, thermal + beam + Lambertian surface) x 1024 perturbed columns",
-                                       "cfg3_small", "cfg3_columns", {"big": False}, 1024, 0, device, 50),
+                                       "cfg3_small", "cfg3_columns", {"big": False}, 1024, 0, device, 50, live),
         "cfg3_L8_Q16_x1024": config_leg("cfg3 at BASELINE's size (8 layers, 16 streams) x 1024 perturbed columns",
-                                        "cfg3_big", "cfg3_columns", {"big": True}, 1024, 0, device, 50),
-        "cfg5_L50_Q64_x1024": config_leg("cfg5: 50 layers, 64 streams, 64 Fourier modes, 2-mode BDRF surface, thermal source; 1024 columns in windows",
-                                         "cfg5", "cfg5_columns", {}, 1024, 128, device, 2),
+                                        "cfg3_big", "cfg3_columns", {"big": True}, 1024, 0, device, 50, live),
+        "cfg5_L50_Q64_x10000": config_leg("cfg5 at BASELINE's literal size: 50 layers, 64 streams, 64 Fourier modes, 2-mode BDRF surface, thermal "
+                                          "source; 10^4 columns in 79 windows of 128",
+                                          "cfg5", "cfg5_columns", {}, 10_000, 128, device, 2, live),
         "cfg5alt_L50_Q128_M64_x32": many_stream_leg(device),
     }
     return out
@@ -858,7 +895,7 @@ def run_rank(a, rank, world, local):
     if rank == 0 and world == 1 and not a.no_extras and not stub:
         plan.close()  # the extras build their own plans: give the arena back first
         plan = None
-        extras = extra_measurements(local, cfg if strong else None, a.columns)
+        extras = extra_measurements(local, cfg if strong else None, a.columns, live)
     if rank == 0:
         value = total_cols * a.steps / elapsed
         out = {
@@ -900,12 +937,16 @@ def run_rank(a, rank, world, local):
             cols_per_launch = C / nwin  # average over the windows of a step (the last one may be short)
             roof, ms = roofline_of(stage, fl, cols_per_launch, names)
             tkey = {"rtd_eigen_kernel<16, 2>": "rtd_eigen_kernel", "rtd_bc_mfma_kernel": "rtd_bc_mfma_kernel"}.get(roof["kernel"], "rtd_sweep_kernel")
-            roof["traffic"] = live.get(tkey) if live and tkey in live else measured_traffic(tkey, a.columns)
+            live_main = None
+            if live:  # the headline config's kernels among everything the profiler passes saw
+                live_main = {k: live[n] for k, n in (("rtd_eigen_kernel", "rtd_eigen_kernel<16,2>"), ("rtd_bc_mfma_kernel", "rtd_bc_mfma_kernel"),
+                                                     ("rtd_fourier_kernel", "rtd_fourier_kernel<16>")) if n in live}
+            roof["traffic"] = live_main.get(tkey) if live_main and tkey in live_main else measured_traffic(tkey, a.columns)
             roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation (child process, "
-                                      "32 windows, windows one after the other)" if live and tkey in live else
+                                      "32 windows, windows one after the other)" if live_main and tkey in live_main else
                                       "profiles/r03_pmc_traffic.json (committed passes)")
-            if live:
-                roof["traffic_all_kernels_per_window"] = float(sum(live.values()))
+            if live_main:
+                roof["traffic_all_kernels_per_window"] = float(sum(live_main.values()))
             roof["launches_per_step"] = nwin
             roof["whole_path_tflops"] = fl["total"] * value / world / 1e12
             roof["whole_path_frac"] = fl["total"] * value / world / 1e12 / FP64_PEAK_TFLOPS
@@ -916,7 +957,7 @@ def run_rank(a, rank, world, local):
                             "eigen kernel of window w + 1 beside the boundary-condition kernel of window w on two streams); "
                             "traffic = HBM bytes per launch of that kernel: see traffic_source")
             out["roofline"] = roof
-            ev = north_star_evidence(a.columns, elapsed / a.steps / max(nwin, 1), live)
+            ev = north_star_evidence(a.columns, elapsed / a.steps / max(nwin, 1), live_main)
             if ev:
                 out["measured_hbm_and_mfma"] = ev
         out["cpu_baseline"] = cpu
