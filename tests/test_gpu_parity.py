@@ -1114,7 +1114,8 @@ def test_cfg5_batch_of_2560_columns_at_occupancy(amd):
     from pydisort_amd._prepare import double_gauss
     mu, w = double_gauss(32)
     assert np.allclose(res["flux_up"], 2 * pi * np.einsum("cit,i->ct", res["u0"][:, :32], mu * w), rtol=1e-12)
-    assert np.allclose(res["flux_down_diffuse"], 2 * pi * np.einsum("cit,i->ct", res["u0"][:, 32:], mu * w), rtol=1e-12)
+    # (the downward diffuse flux of a delta-M scaled column also carries the difference of the scaled and the true direct beam,
+    #  _assemble_intensity_and_fluxes.py:527-613: not a plain quadrature of u0)
     worst = worst_pw = 0.0
     for i in range(8):
         pts = np.searchsorted(z[f"c{i}.tau_pts"], tau[at[i]])
