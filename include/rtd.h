@@ -291,6 +291,8 @@ enum {
  *   RTD_BC_FORCE_HANDOVER tiled (64-stream) kernel: every third chain goes to the pivoted row-per-lane kernels
  *   RTD_BC_TILED          32 streams through the tiled kernel's T = 1 instance instead of rtd_bc_mfma_kernel
  *   RTD_EIG_MFMA          eigen stage with its assembly GEMMs on the matrix cores (measured slower; a tested variant)
+ *   RTD_SMALL_SPLIT       2 ... 16 streams through the separate interface / sweep / evaluation kernels instead of the fused
+ *                         rtd_bc_small_kernel
  *   RTD_DEBUG             diagnostics on stderr
  */
 #ifdef __cplusplus

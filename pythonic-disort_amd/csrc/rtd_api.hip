@@ -124,7 +124,7 @@ struct rtd_plan {
   // eigen kernel of window w + 1 run on eig_stream while the boundary-condition + evaluation kernels of window w run on
   // `stream`.  The eigen kernel is bound by vector-instruction issue, the boundary-condition kernel by the latency of its
   // dependent chains: wavefronts of both kinds resident on a SIMD fill each other's bubbles (profiles/r03_window_pipeline.json).
-  struct HandOff { double *Y0, *att, *Ym, *Am, *kk, *Bv, *dq, *zneg, *Ek; } slot1{};
+  struct HandOff { double *Y0, *att, *Ym, *Am, *kk, *Bv, *dq, *zneg, *Ek, *vb; } slot1{};
   // Legendre tables at -mu0 and beam attenuations of ALL columns, kept from run to run (they depend on the inputs and the
   // mode shard only): one launch after the inputs change instead of one per window and run (19 us of 1.17 ms per 256-column
   // cfg4 window).  Plans of one window keep them in d.Y0 / d.att; larger plans in these arrays when C M P doubles fit 2 GiB.
@@ -245,7 +245,7 @@ RtdDev window_dev(const rtd_plan* p, int64_t c0, int cnt, int slot = 0) {
   RtdDev w = p->d;
   if (slot == 1) {
     const rtd_plan::HandOff& h = p->slot1;
-    w.Y0 = h.Y0; w.att = h.att; w.Ym = h.Ym; w.Am = h.Am; w.kk = h.kk; w.Bv = h.Bv; w.dq = h.dq; w.zneg = h.zneg; w.Ek = h.Ek;
+    w.Y0 = h.Y0; w.att = h.att; w.Ym = h.Ym; w.Am = h.Am; w.kk = h.kk; w.Bv = h.Bv; w.dq = h.dq; w.zneg = h.zneg; w.Ek = h.Ek; w.vb = h.vb;
   }
   if (p->tables_cached) {  // the window's part of the all-columns tables
     w.Y0 = p->Y0_all + c0 * (int64_t)p->d.M * p->d.P;
@@ -497,7 +497,7 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   d.l0 = 0; d.ln = (int)L;
   // window of columns whose intermediates are resident: bytes of intermediates per column.  A plan of more than one window
   // that pipelines them holds the eigen stage's hand-off buffers twice; a one-window (or RTD_NO_PIPELINE) plan once.
-  const int64_t handoff_col = 8 * (M * P + (L + 1) + 2 * M * L * NP * NP + 2 * M * L * NP + M * L * Q2 + L * Ns * Q2 + L * NP);
+  const int64_t handoff_col = 8 * (M * P + (L + 1) + 2 * M * L * NP * NP + 2 * M * L * NP + M * L * Q2 + L * Ns * Q2 + L * NP + (Ns > 0 ? 4 * L * NP : 0));
   const int64_t rest_col = 8 * (M * L * Q2 + M * (L - 1) * Q2 * Q2);
   const bool may_pipeline = !getenv("RTD_NO_PIPELINE");
   const int64_t per_col_one = handoff_col + rest_col, per_col_win = (may_pipeline ? 2 : 1) * handoff_col + rest_col;
@@ -560,12 +560,12 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
     // intermediates: one window of Cw columns
     A(d.Y0, Cw * M * P) A(d.att, Cw * (L + 1))
     A(d.Ym, Cw * M * L * NP * NP) A(d.Am, Cw * M * L * NP * NP) A(d.kk, Cw * M * L * NP) A(d.Bv, Cw * M * L * Q2)
-    A(d.dq, Cw * L * Ns * Q2) A(d.zneg, Cw * L * NP) A(d.coef, Cw * M * L * Q2)
+    A(d.dq, Cw * L * Ns * Q2) A(d.zneg, Cw * L * NP) A(d.vb, Ns > 0 ? Cw * L * 4 * NP : 1) A(d.coef, Cw * M * L * Q2)
     A(d.Fws, Cw * M * (L - 1) * Q2 * Q2) A(d.Ek, Cw * M * L * NP) A(d.need_split, Cw * M)
     A(d.sweeps, 1) A(d.status, 1) A(d.split_any, 1)
     if (p->pipelined) {
       A(h1.Y0, Cw * M * P) A(h1.att, Cw * (L + 1)) A(h1.Ym, Cw * M * L * NP * NP) A(h1.Am, Cw * M * L * NP * NP)
-      A(h1.kk, Cw * M * L * NP) A(h1.Bv, Cw * M * L * Q2) A(h1.dq, Cw * L * Ns * Q2) A(h1.zneg, Cw * L * NP) A(h1.Ek, Cw * M * L * NP)
+      A(h1.kk, Cw * M * L * NP) A(h1.Bv, Cw * M * L * Q2) A(h1.dq, Cw * L * Ns * Q2) A(h1.zneg, Cw * L * NP) A(h1.vb, Ns > 0 ? Cw * L * 4 * NP : 1) A(h1.Ek, Cw * M * L * NP)
       A(p->status2[1], 1) A(p->col_status2[1], C) A(p->sweeps2[1], 1)
     }
 #undef A
@@ -1477,7 +1477,7 @@ __global__ void rtd_layer_stage_kernel(double* arr, double* stage, long CM, int 
   }
 }
 struct LayerSeg { double* arr; long CM; int E; };
-int layer_segments(rtd_plan* p, LayerSeg seg[7]) {
+int layer_segments(rtd_plan* p, LayerSeg seg[8]) {
   const RtdDev& d = p->d;
   const long CM = (long)d.C * d.M;
   const int NP = d.NP, Q2 = 2 * d.NP;
@@ -1490,6 +1490,7 @@ int layer_segments(rtd_plan* p, LayerSeg seg[7]) {
   if (d.Ns > 0) {
     seg[n++] = {d.dq, (long)d.C, d.Ns * Q2};
     seg[n++] = {d.zneg, (long)d.C, NP};
+    seg[n++] = {d.vb, (long)d.C, 4 * NP};
   }
   return n;
 }
@@ -1526,7 +1527,7 @@ int rtd_comm_allgather_layers(rtd_plan* p, int32_t count) {
   if (count < 1 || (int64_t)count * p->comm_size != p->d.L)
     return fail(RTD_ERR_ARG, "layer shards: nlayers must equal count_per_rank x nranks");
   HIP_TRY(hipSetDevice(p->device));
-  LayerSeg seg[7];
+  LayerSeg seg[8];
   const int nseg = layer_segments(p, seg);
   int64_t per_rank = 0;
   for (int k = 0; k < nseg; ++k) per_rank += (int64_t)count * seg[k].CM * seg[k].E;

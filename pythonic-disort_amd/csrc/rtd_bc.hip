@@ -32,96 +32,7 @@
 
 namespace {
 
-#define RTD_FENCE() asm volatile("" ::: "memory")
-#ifndef RTD_GJ_BATCH
-#define RTD_GJ_BATCH 3  /* cross-lane fetches in flight per batch - 1 (power of two minus one) */
-#endif
-#ifndef RTD_SWEEP_WAVES
-#define RTD_SWEEP_WAVES 3
-#endif
-
-template <int MASK>
-__device__ __forceinline__ double xor_lane(double v) {
-  if constexpr (MASK >= 32) return __shfl_xor(v, MASK, 64);  // across the halves of the wavefront: ds_bpermute (128 streams only)
-  constexpr int pat = (MASK << 10) | 0x1F;
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_ds_swizzle(lo, pat);
-  hi = __builtin_amdgcn_ds_swizzle(hi, pat);
-  return __hiloint2double(hi, lo);
-}
-
-template <int NP>
-__device__ __forceinline__ double group_max(double v) {
-  if (NP > 1) v = fmax(v, xor_lane<1>(v));
-  if (NP > 2) v = fmax(v, xor_lane<2>(v));
-  if (NP > 4) v = fmax(v, xor_lane<4>(v));
-  if (NP > 8) v = fmax(v, xor_lane<8>(v));
-  if (NP > 16) v = fmax(v, xor_lane<16>(v));
-  if (NP > 32) v = fmax(v, xor_lane<32>(v));
-  return v;
-}
-
-
-// max over the NP lanes of a group for non-negative f32 keys, with DPP row operations (no LDS crossbar):
-// xor-1 and xor-2 quad permutes, row_half_mirror, row_mirror; one v_max_f32 each.
-template <int CTRL>
-__device__ __forceinline__ float dpp_max_f32(float v) {
-  const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
-  return fmaxf(v, __int_as_float(o));
-}
-template <int NP>
-__device__ __forceinline__ float group_max_key(float v) {
-  v = dpp_max_f32<0xB1>(v);                // quad_perm [1,0,3,2]
-  v = dpp_max_f32<0x4E>(v);                // quad_perm [2,3,0,1]
-  if (NP > 4) v = dpp_max_f32<0x141>(v);   // row_half_mirror
-  if (NP > 8) v = dpp_max_f32<0x140>(v);   // row_mirror
-  if (NP > 16) {
-    const int o = __builtin_amdgcn_ds_swizzle(__float_as_int(v), (16 << 10) | 0x1F);
-    v = fmaxf(v, __int_as_float(o));
-  }
-  if (NP > 32) v = fmaxf(v, __shfl_xor(v, 32, 64));
-  return v;
-}
-
-__device__ __forceinline__ double fast_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  y = y * (2.0 - x * y);
-  y = y * (2.0 - x * y);
-  return y;
-}
-
-// value of `v` in lane `addr/4` (addr precomputed once per pivot step)
-__device__ __forceinline__ double bperm(int addr, double v) {
-  const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
-  const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
-
-// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
-template <int B, int E, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (B < E) {
-    f(std::integral_constant<int, B>{});
-    static_for<B + 1, E>(f);
-  }
-}
-
-// value of lane K (compile-time) of this lane's 16-lane group: DPP row broadcast, VALU only
-template <int K>
-__device__ __forceinline__ double bcast16(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xF, 0xF, true);  // row_newbcast:K; bound_ctrl + full masks: no `old` operand, no copy
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-
-// Workspace layout per (c, m, l), l < L-1, inside d.Fws (4 NP^2 doubles per slot):
-//   [0, NP^2) Wp   [NP^2, 2NP^2) Wq   [2NP^2, 3NP^2) S   then rho_t, rho_b, s (NP each)
-template <int NP>
-struct Ws {
-  static constexpr long SLOT = 4L * NP * NP;
-  static constexpr int WP = 0, WQ = NP * NP, S = 2 * NP * NP, RT = 3 * NP * NP, RB = RT + NP, SV = RB + NP;
-};
+#include "rtd_bc_common.h"
 
 // ------------------------------------------------------------------------------------------------
 // Interface kernel: per (c, m, l < L-1):  Wp, Wq, rho_t, rho_b.
@@ -262,82 +173,6 @@ __global__ __launch_bounds__(64) void rtd_iface_kernel(RtdDev d, const int* only
     ws[Ws<NP>::RB + j] = 0.25 * rb;
   }
 }
-
-typedef double v4f64 __attribute__((ext_vector_type(4)));
-
-
-// Gauss-Jordan with partial pivoting on [A | B | b] (NP rows, one per lane of the group): on exit the lane
-// that owned pivot column `pc` holds row pc of A^-1 B in bm[] and (A^-1 b)[pc] in bv.
-template <int NP, int NB, int K>
-struct GjStep {
-  static __device__ __forceinline__ void run(double (&am)[NP], double (&bm)[NB], double& bv, int& pc, const int grp) {
-    // pivot search on f32 keys (a pivot within 2^-24 of the largest candidate is as good as the largest)
-    const float key = (pc < 0) ? fabsf((float)am[K]) : -1.0f;
-    const float kmax = group_max_key<NP>(key);
-    const int j = (int)(threadIdx.x % NP);
-    double f, rp;
-    bool isp;
-    bool fast = false;
-    if constexpr (NP == 16) {
-      // threshold pivoting: when the diagonal candidate (lane K, still unused) is within a factor 4 of the largest
-      // candidate in EVERY group of the wavefront, it is taken as the pivot: the source lane is then a compile-time
-      // constant and the pivot row travels by DPP row broadcasts (VALU) instead of ds_bpermute (LDS crossbar, the
-      // pipe that bounds this kernel).  ~95 % of the steps of real atmospheres qualify; the others take the fully
-      // pivoted path below.  Growth is bounded as in partial pivoting with threshold 1/4.
-      const int kd = __builtin_amdgcn_update_dpp(0, __float_as_int(key), 0x150 + K, 0xF, 0xF, true);
-      fast = __all(__int_as_float(kd) >= 0.25f * kmax && __int_as_float(kd) > 0.0f);
-    }
-    if (fast) {
-      isp = (j == K);
-      const double piv = bcast16<K>(am[K]);
-      rp = fast_rcp(piv);
-      f = isp ? 0.0 : am[K] * rp;
-      static_for<K + 1, NP>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        am[c] -= f * bcast16<K>(am[c]);
-      });
-      static_for<0, NB>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        bm[c] -= f * bcast16<K>(bm[c]);
-      });
-      bv -= f * bcast16<K>(bv);
-    } else {
-      const unsigned long long bal = __ballot(key == kmax);
-      const unsigned long long bits = NP == 64 ? bal : (bal >> (grp * NP)) & ((1ull << (NP & 63)) - 1);
-      const int src = __ffsll((long long)bits) - 1;  // pivot lane of this group
-      isp = (j == src);
-      const int addr = (grp * NP + src) << 2;
-      const double piv = bperm(addr, am[K]);
-      rp = fast_rcp(piv);
-      f = isp ? 0.0 : am[K] * rp;
-      // (scheduling barriers bound the number of cross-lane results in flight: register pressure)
-#pragma unroll
-      for (int c = K + 1; c < NP; ++c) {
-        am[c] -= f * bperm(addr, am[c]);
-        if ((c & RTD_GJ_BATCH) == RTD_GJ_BATCH) __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int c = 0; c < NB; ++c) {
-        bm[c] -= f * bperm(addr, bm[c]);
-        if ((c & RTD_GJ_BATCH) == RTD_GJ_BATCH) __builtin_amdgcn_sched_barrier(0);
-      }
-      bv -= f * bperm(addr, bv);
-    }
-    if (isp) {  // normalise the pivot row now: later steps leave it untouched in column K
-      pc = K;
-#pragma unroll
-      for (int c = K + 1; c < NP; ++c) am[c] *= rp;
-#pragma unroll
-      for (int c = 0; c < NB; ++c) bm[c] *= rp;
-      bv *= rp;
-    }
-    GjStep<NP, NB, K + 1>::run(am, bm, bv, pc, grp);
-  }
-};
-template <int NP, int NB>
-struct GjStep<NP, NB, NP> {
-  static __device__ __forceinline__ void run(double (&)[NP], double (&)[NB], double&, int&, const int) {}
-};
 
 // 128 streams (NP = 64, one chain per wavefront): the rows [Ta | Tb | t] live in LDS, not in registers (64 fully unrolled
 // pivot steps over 129 registers per lane spilled 267 registers and 256 KB of code per elimination), and the elimination is a
@@ -854,7 +689,7 @@ __device__ __forceinline__ int chain_needs_pivoting(const RtdDev& d, const bool 
 
 // Four wavefronts per SIMD: <= 128 registers and <= 10 KB of LDS each, so the kernel prefetches one layer ahead, forms the
 // interface products one after the other (one accumulator set live), takes exp(-k dtau) from memory, saves t^T once and
-// rotates two operand sets in the backward sweep (128 VGPRs, 36 dwords spilled outside the two loops -- profiles/*_kernel_resources.json; 9.8 KB).  The kernel
+// rotates two operand sets in the backward sweep (128 VGPRs, 36 dwords spilled outside the two loops -- profiles/rNN_kernel_resources.json; 9.8 KB).  The kernel
 // is bound by the latency of its dependent chains: a three-wavefront form (two layers of prefetch, the products side by
 // side, exp(-k dtau) in the LDS window: 168 VGPRs, 12.7 KB; removed in round 3) took 4.19-4.25 ms per 2 048 cfg4 columns
 // against this form's 4.08-4.11 ms, and padded to 7 / 9 / 12 wavefronts per CU 5.46 / 4.82 / 4.33 ms.
@@ -2381,11 +2216,16 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
 
 }  // namespace
 
+bool rtd_small_split() {  // RTD_SMALL_SPLIT: 2 ... 16 streams through rtd_iface_kernel + rtd_sweep_kernel + rtd_eval_kernel (A/B, tests)
+  static const bool v = getenv("RTD_SMALL_SPLIT") != nullptr;
+  return v;
+}
+
 bool rtd_bc_fuses_eval(const RtdDev& d) {
-  // the fused kernels -- rtd_bc_mfma_kernel and the tiled one at 16 or 32 streams per hemisphere -- write u^m at the
-  // interfaces themselves; a window in which the tiled kernel handed a chain to the row-per-lane kernels (d.split_any)
-  // is evaluated by the evaluation kernel instead (rtd_launch_eval)
-  return d.NP == 16 || d.NP == 32;
+  // the fused kernels -- rtd_bc_small_kernel (NP <= 8), rtd_bc_mfma_kernel and the tiled one at 16 or 32 streams per hemisphere --
+  // write u^m at the interfaces themselves; a window in which the tiled kernel handed a chain to the row-per-lane kernels
+  // (d.split_any) is evaluated by the evaluation kernel instead (rtd_launch_eval)
+  return d.NP == 16 || d.NP == 32 || (d.NP <= 8 && !rtd_small_split());
 }
 
 void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
@@ -2403,6 +2243,16 @@ void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
     if (part == 0 && nif > 0) hipLaunchKernelGGL(rtd_iface_kernel<NPV>, gi, dim3(64), 0, s, d, none);       \
     if (part == 1) hipLaunchKernelGGL(rtd_sweep_kernel<NPV>, gs, dim3(64), 0, s, d, none);                  \
     break;
+  // 2 ... 16 streams: one fused kernel (part 1; part 0 is empty) unless RTD_SMALL_SPLIT asks for the separate ones
+#define RTD_BC_SMALL_CASE(NPV)                                                                              \
+  case NPV:                                                                                                 \
+    if (rtd_small_split()) {                                                                                \
+      if (part == 0 && nif > 0) hipLaunchKernelGGL(rtd_iface_kernel<NPV>, gi, dim3(64), 0, s, d, none);     \
+      if (part == 1) hipLaunchKernelGGL(rtd_sweep_kernel<NPV>, gs, dim3(64), 0, s, d, none);                \
+    } else if (part == 1) {                                                                                 \
+      rtd_launch_bc_small(d, s);                                                                            \
+    }                                                                                                       \
+    break;
   // fused tiled kernel first (part 0); the chains whose speculative elimination failed raise need_split and are solved by
   // the pivoted row-per-lane kernels (part 1), which leave at once when none of their chains is flagged
 #define RTD_BC_TILED_CASE(NPV, TV)                                                                          \
@@ -2415,8 +2265,8 @@ void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
     hipLaunchKernelGGL(rtd_sweep_kernel<NPV>, gs, dim3(64), 0, s, d, (const int*)d.need_split);             \
   }
   switch (d.NP) {
-    RTD_BC_CASE(4)
-    RTD_BC_CASE(8)
+    RTD_BC_SMALL_CASE(4)
+    RTD_BC_SMALL_CASE(8)
     RTD_BC_CASE(64)  // 66 ... 128 streams: the row-per-lane kernels, one chain per wavefront
     case 16:
       if (tiled16) {
@@ -2431,5 +2281,6 @@ void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
     default: break;
   }
 #undef RTD_BC_CASE
+#undef RTD_BC_SMALL_CASE
 #undef RTD_BC_TILED_CASE
 }

@@ -40,6 +40,8 @@ struct RtdDev {
   const double *bdrfq, *bdrfq0;  // [C][NBDRF][NP][NP], [C][NBDRF][NP]
   // intermediates
   double *Ym, *Am, *kk, *Bv, *dq, *zneg, *coef;
+  double* vb;         // [C][L][4][NP]  the thermal particular solution v_l at the layer's own boundaries: up- and down-streams at its
+                      //                top, then at its bottom (mode 0 only; read by rtd_bc_small_kernel instead of the polynomials)
   double* Ek;         // [C][M][L][NP]  exp(-k dtau*_l): the Stamnes-Conklin scaling factors
   double* Fws;  // BC workspace: [C][M][L-1][4 NP^2]: Wp, Wq, S, rho_t, rho_b, s per interface (rtd_bc.hip)
   // Fused evaluation (rtd_bc_mfma_kernel): when the evaluation points are the layer interfaces [0, tau_arr] the backward
@@ -107,6 +109,8 @@ void rtd_launch_prepare(const RtdDev& d, const RtdRaw& r, hipStream_t s);
 void rtd_launch_tables(const RtdDev& d, hipStream_t s, bool with_quad = true);  // with_quad: also the column-independent Y table
 void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part);  // the fused eigen kernel runs as part 1 (0, 2: empty timing slots)
 void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part);   // 0 iface, 1 sweep
+void rtd_launch_bc_small(const RtdDev& d, hipStream_t s);  // rtd_bc_small.hip: the fused kernel of the 2 ... 16-stream path
+bool rtd_small_split();  // RTD_SMALL_SPLIT is set: NP <= 8 takes the separate interface / sweep / evaluation kernels
 bool rtd_bc_fuses_eval(const RtdDev& d);  // the boundary-condition kernel chosen for d can fill d.um
 void rtd_launch_eval(const RtdDev& d, const RtdEval& e, hipStream_t s);
 void rtd_launch_nt_tables(const RtdDev& d, const RtdNt& nt, hipStream_t s);

@@ -91,7 +91,7 @@ __device__ __forceinline__ double approx_rcp(double x) {
 #endif
 
 #ifndef RTD_EIGEN32_WAVES
-#define RTD_EIGEN32_WAVES 2  /* waves per SIMD of the 64-stream eigen kernel (256 VGPRs; the spill counts of every kernel: profiles/*_kernel_resources.json, tools/kernel_resources.py; 1: 278 VGPRs) */
+#define RTD_EIGEN32_WAVES 2  /* waves per SIMD of the 64-stream eigen kernel (256 VGPRs; the spill counts of every kernel: profiles/rNN_kernel_resources.json, tools/kernel_resources.py; 1: 278 VGPRs) */
 #endif
 #ifndef RTD_EIGEN_WAVES
 #define RTD_EIGEN_WAVES 3  /* waves per SIMD the fused eigen kernel is compiled for at NP <= 16 (149 VGPRs, no spills, LDS 10.5 KB per
@@ -979,6 +979,10 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
     if (valid && act) d.zneg[((long)c * d.L + l) * NP + j] = zn;
     const double* sp = d.spoly + ((long)c * d.L + l) * d.Ns;
     const double rk = rk0;
+    // v_l at the layer's own boundaries (vb: what the boundary-condition kernel of the 2 ... 16-stream path reads instead of
+    // evaluating the polynomials layer by layer): sum_q dq[q] tau^q at the scaled tau of the top and of the bottom
+    const double ts_top = d.taus0[(long)c * (d.L + 1) + l], ts_bot = d.taus0[(long)c * (d.L + 1) + l + 1];
+    double vtu = 0.0, vtd = 0.0, vbu = 0.0, vbd = 0.0, tpt = 1.0, tpb = 1.0;
     for (int q = 0; q < d.Ns; ++q) {
       // b_q(K) = sum_{jj>=q} jj!/q! a_jj K^-(jj-q+1), K = -k (first N eigen-columns) and +k
       double bneg = 0.0, bpos = 0.0, ratio = 1.0, pw_pos = rk, pw_neg = -rk;
@@ -1008,6 +1012,19 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
         dq[j] = up;
         dq[NP + j] = dn;
       }
+      vtu += up * tpt;
+      vtd += dn * tpt;
+      vbu += up * tpb;
+      vbd += dn * tpb;
+      tpt *= ts_top;
+      tpb *= ts_bot;
+    }
+    if (valid && act) {
+      double* vb = d.vb + ((long)c * d.L + l) * 4 * NP;
+      vb[j] = vtu;
+      vb[NP + j] = vtd;
+      vb[2 * NP + j] = vbu;
+      vb[3 * NP + j] = vbd;
     }
     __syncthreads();
   }

@@ -320,9 +320,11 @@ __global__ void rtd_export_kernel(RtdDev d, int col, double* GC, double* K, doub
 }  // namespace
 
 void rtd_launch_eval(const RtdDev& d, const RtdEval& e, hipStream_t s) {
-  if (e.um_in != nullptr && e.antider == 0 && (d.NP == 16 || d.NP == 32)) {  // u^m is there already: sums only
+  if (e.um_in != nullptr && e.antider == 0 && rtd_bc_fuses_eval(d)) {  // u^m is there already: sums only
     const dim3 g((unsigned)((long)d.C * ((e.ntau + FT_T - 1) / FT_T)));
-    if (d.NP == 16) hipLaunchKernelGGL(rtd_fourier_kernel<16>, g, dim3(EVAL_THREADS), 0, s, d, e);
+    if (d.NP == 4) hipLaunchKernelGGL(rtd_fourier_kernel<4>, g, dim3(EVAL_THREADS), 0, s, d, e);
+    else if (d.NP == 8) hipLaunchKernelGGL(rtd_fourier_kernel<8>, g, dim3(EVAL_THREADS), 0, s, d, e);
+    else if (d.NP == 16) hipLaunchKernelGGL(rtd_fourier_kernel<16>, g, dim3(EVAL_THREADS), 0, s, d, e);
     else hipLaunchKernelGGL(rtd_fourier_kernel<32>, g, dim3(EVAL_THREADS), 0, s, d, e);
     // the tiled kernel may have handed chains to the row-per-lane kernels (singular carry blocks; a test hook): those leave
     // no u^m, the flag is set, the Fourier-sum kernel has left at once and the evaluation kernel does the window

@@ -839,14 +839,15 @@ def test_fused_bc_kernel_pivoted_path_on_goldens():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["RTD_EIG_MFMA", "RTD_BC_TILED", "RTD_BC_FORCE_HANDOVER", "RTD_NO_PIPELINE"])
+@pytest.mark.parametrize("switch", ["RTD_EIG_MFMA", "RTD_BC_TILED", "RTD_BC_FORCE_HANDOVER", "RTD_NO_PIPELINE", "RTD_SMALL_SPLIT"])
 def test_alternative_kernel_paths_stay_correct(switch):
     """The runtime switches that select an alternative path -- RTD_EIG_MFMA=1: the assembly of Pm, Qm as rank-4 MFMA updates
     (32 streams); RTD_BC_TILED=1: the tiled fused kernel (the 64-stream kernel) with one tile, in place of the 32-stream
     kernel it generalises; RTD_BC_FORCE_HANDOVER=1: the tiled kernel hands every third Fourier mode's chain to the pivoted
     row-per-lane kernels (its last resort for singular carry blocks; the window's fused interface evaluation is then
     replaced by the evaluation kernel); RTD_NO_PIPELINE=1: the windows of a plan one after the other on one stream instead
-    of the two-stream pipeline -- pass the golden replay (it has 40-, 48- and 64-stream cases), the synthetic configs incl.
+    of the two-stream pipeline; RTD_SMALL_SPLIT=1: 2 ... 16 streams through the separate interface / sweep / evaluation kernels
+    of rounds 1-3 instead of the fused rtd_bc_small_kernel (round 4) -- pass the golden replay (it has 40-, 48- and 64-stream cases), the synthetic configs incl.
     cfg5, the random cases, the windowed plans and the fused-evaluation comparison.  (Round 3 removed the switches whose
     paths had lost every A/B: RTD_BC_SPLIT at 32 streams, RTD_EIG_V1, RTD_BCF_WAVES3.)"""
     import subprocess
@@ -855,7 +856,8 @@ def test_alternative_kernel_paths_stay_correct(switch):
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"),
                         os.path.join(os.path.dirname(__file__), "test_gpu_random_parity.py"),
-                        "-k", "reference_golden or synthetic_config or random_many or edge_cases or fused_interface or windowed or layer_shards"],
+                        "-k", "reference_golden or synthetic_config or random_many or edge_cases or fused_interface or windowed or layer_shards"
+                              + (" or stamnes or cfg3 or random or mode_shards or failed_column or failure_in" if switch == "RTD_SMALL_SPLIT" else "")],
                        env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
