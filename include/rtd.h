@@ -287,7 +287,9 @@ enum {
  * results are NOT valid (e.g. the aliased hand-off reads of DESIGN.md section 7a) exist only behind compile-time -D flags.
  *   RTD_WORK_BYTES        bytes of solve intermediates per plan (default 24 GiB): sizes the automatic column window
  *   RTD_NO_PIPELINE       windows one after the other on one stream (no second hand-off slot, no eigen stream)
- *   RTD_BC_FORCE_PIVOT    fused boundary-condition kernels: every elimination takes the column-pivoted redo
+ *   RTD_BC_FORCE_PIVOT    fused boundary-condition kernels: =1 every elimination is redone by the column-pivoted LDS path (the
+ *                         path of a failed speculation); =2 every chain of the 32-stream kernel takes the register-resident
+ *                         column-pivoted elimination throughout (the path of near-conservative mode-0 chains)
  *   RTD_BC_FORCE_HANDOVER tiled (64-stream) kernel: every third chain goes to the pivoted row-per-lane kernels
  *   RTD_BC_TILED          32 streams through the tiled kernel's T = 1 instance instead of rtd_bc_mfma_kernel
  *   RTD_EIG_MFMA          eigen stage with its assembly GEMMs on the matrix cores (measured slower; a tested variant)

@@ -492,7 +492,10 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
                 Ns = dims->nscoeffs, NB = dims->nbdrf, Q2 = 2 * NP;
   d.C = (int)C; d.L = (int)L; d.N = N; d.NP = (int)NP; d.P = (int)P; d.M = (int)M; d.Ns = (int)Ns;
   d.NBDRF = (int)NB; d.beam = dims->beam ? 1 : 0;
-  d.flags = (getenv("RTD_BC_FORCE_PIVOT") ? 1 : 0) | (getenv("RTD_BC_FORCE_HANDOVER") ? 2 : 0);
+  // RTD_BC_FORCE_PIVOT=1: every speculative elimination of the fused kernels is redone by the LDS pivoted path (bit 0);
+  // =2: every chain takes the register-resident pivoted elimination of rtd_bc_mfma_kernel throughout (bit 2)
+  const char* fp = getenv("RTD_BC_FORCE_PIVOT");
+  d.flags = (fp ? (atoi(fp) == 2 ? 4 : 1) : 0) | (getenv("RTD_BC_FORCE_HANDOVER") ? 2 : 0);
   d.m0 = 0; d.mstep = 1; d.mtot = (int)M;
   d.l0 = 0; d.ln = (int)L;
   // window of columns whose intermediates are resident: bytes of intermediates per column.  A plan of more than one window

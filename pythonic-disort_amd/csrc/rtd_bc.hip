@@ -665,6 +665,55 @@ struct GjFast<NB, 16> {
   static __device__ __forceinline__ void run(double (&)[4], double (&)[4], double&, int&, const int) {}
 };
 
+// Column-pivoted Gauss-Jordan on the same registers as GjFast (round 4: the elimination of the chains that are pivoted
+// THROUGHOUT -- chain_needs_pivoting -- used to be the rolled LDS loop `pivoted_lds`, ~10 x a speculative elimination: a
+// batch with a conservative cloud layer in every column ran 3 x slower).  Step K makes row K of Ta^T a unit vector; the pivot
+// is the largest unused column of that row, with threshold 1/4 in favour of the diagonal (the rule of pivoted_lds: partial
+// pivoting with threshold 1/4 bounds the growth like LAPACK's, _solve_for_coeffs.py:326-333).  One chain per wavefront: the
+// pivot column is wave-uniform, its row entry comes by v_readlane, its column by ds_bpermute (a run-time lane: no DPP
+// broadcast); 18 cross-lane fetches + 9 FMAs per step, no LDS memory, no barrier.  Afterwards the column that was the
+// pivot of step c holds column c of Tb^T Ta^-T and t^T Ta^-T (perm[c], written to sPerm): the caller moves them back.
+__device__ __forceinline__ double readlane_f64(const double v, const int lane_uniform) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane_uniform), __builtin_amdgcn_readlane(__double2loint(v), lane_uniform));
+}
+template <int NB, int K>
+struct GjPiv {
+  static __device__ __forceinline__ void run(double (&ta)[4], double (&tb)[4], double& tv, unsigned& used, int* sPerm, const int col,
+                                             const int rowbase, const int lane) {
+    constexpr int QK = K >> 2, RK = K & 3;
+    const double x = bcast_row<RK>(ta[QK], col);  // row K of Ta^T, replicated over the lane-rows
+    const float key = ((used >> col) & 1u) ? -1.0f : fabsf((float)x);
+    const float kmax = group_max_key<16>(key);
+    const float kd = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(key), 0x150 + K, 0xF, 0xF, true));
+    int pcol = K;
+    if (!(kd >= 0.25f * kmax && kd > 0.0f)) {  // (wave-uniform: the four lane-rows hold the same row)
+      const unsigned long long bal = __ballot(key == kmax) & 0xFFFFull;
+      pcol = bal ? __ffsll((long long)bal) - 1 : K;  // (a chain that has gone NaN has no candidate: the diagonal, NaN stays NaN)
+    }
+    pcol = __builtin_amdgcn_readfirstlane(pcol);
+    const double xp = readlane_f64(x, pcol);
+    const double rp = fast_rcp(xp);
+    // the pivot column is scaled by 1 / pivot EXACTLY (one multiplication): the speculative form's v - (1 - 1/p) v loses
+    // |1 - 1/p| / |1/p| ulps, harmless for its growth-limited pivots, not for the chains that are here because their result
+    // hangs on the last digits (random32/3736: 1.6e-2 of the field scale with that form, 1.9e-4 -- the reference's level -- so)
+    const bool isp = col == pcol;
+    const double f = x * rp;
+    const int addr = (rowbase | pcol) << 2;
+    auto upd = [&](double& v) {
+      const double bp = bperm(addr, v);
+      v = isp ? bp * rp : fma(-f, bp, v);
+    };
+    static_for<QK, 4>([&](auto qc) {  // rows below 4 QK are finished: unit vectors with a zero in every unused column
+      upd(ta[decltype(qc)::value]);
+    });
+    static_for<0, NB>([&](auto qc) { upd(tb[decltype(qc)::value]); });
+    upd(tv);
+    used |= 1u << pcol;
+    if (lane == 0) sPerm[K] = pcol;
+    if constexpr (K + 1 < 16) GjPiv<NB, K + 1>::run(ta, tb, tv, used, sPerm, col, rowbase, lane);
+  }
+};
+
 // A chain whose result hangs on the last digits of its coefficients: the thermal (polynomial) particular solution of a layer with
 // a tiny eigenvalue k is ~ 1/k^(order + 1) times the source and is cancelled by the homogeneous part -- at k = 1.4e-3 (omega =
 // 1 - 1e-6) seventeen orders of magnitude above the field, which is then as good as the RELATIVE accuracy of C.  The speculative
@@ -675,11 +724,15 @@ struct GjFast<NB, 16> {
 #define RTD_BC_CAREFUL_K 0.02
 #endif
 #ifndef RTD_BC_CAREFUL_ALL_MODE0
-#define RTD_BC_CAREFUL_ALL_MODE0 0  /* 1: every mode-0 chain with such an eigenvalue, thermal source or not (A/B below) */
+#define RTD_BC_CAREFUL_ALL_MODE0 1  /* 32 streams (rtd_bc_mfma_kernel): every mode-0 chain with such an eigenvalue, thermal source or
+                                       not.  Round 3 measured what it buys -- the near-conservative beam cases go from <= 1.5e-9 to
+                                       <= 5e-12 of their 40-digit solutions -- and what it cost with the LDS redo: 219 k -> 71 k col/s on a
+                                       batch with a conservative cloud layer in every column; with GjPiv (registers) it is the default.
+                                       The tiled 64-stream kernel keeps the thermal-only rule (its pivoted path is the LDS redo). */
 #endif
 __device__ __forceinline__ int chain_needs_pivoting(const RtdDev& d, const bool iso, const double* kk, const int L, const int np) {
-  int careful = d.flags & 1;  // test hook (RTD_BC_FORCE_PIVOT): every elimination takes the pivoted redo
-  if (iso && !careful) {
+  int careful = 0;
+  if (iso) {
     double kmin = 1e300;
     for (int i = 0; i < L * np; ++i) kmin = fmin(kmin, kk[i]);  // wave-uniform: scalar loads; mode 0 of thermal runs only
     careful = kmin < RTD_BC_CAREFUL_K ? 1 : 0;
@@ -724,7 +777,11 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
   const bool iso = d.Ns > 0 && mg == 0;
   const bool beam = d.beam != 0;
   const double mu0 = beam ? d.mu0[c] : 1.0;
-  const int careful = chain_needs_pivoting(d, RTD_BC_CAREFUL_ALL_MODE0 ? mg == 0 : iso, kk, L, NP);
+  // careful: this chain takes the column-pivoted elimination throughout (GjPiv, registers) -- the rule of chain_needs_pivoting,
+  // or the test hook RTD_BC_FORCE_PIVOT=2 for every chain.  force_redo (RTD_BC_FORCE_PIVOT=1): every speculative elimination is
+  // declared failed and redone by pivoted_lds, the path of the rare real failures (the suite runs under both).
+  const int careful = chain_needs_pivoting(d, RTD_BC_CAREFUL_ALL_MODE0 ? mg == 0 : iso, kk, L, NP) | ((d.flags >> 2) & 1);
+  const int force_redo = d.flags & 1;
   auto vpoly = [&](int l, double t, int idx) {
     double a = 0.0, tp = 1.0;
     for (int q = 0; q < d.Ns; ++q) {
@@ -967,7 +1024,16 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
     RTD_STAMP();  // 4 l + 1: loop top (register rotation, loads issued)
     const int r0 = l - wb, r1 = ln - wb;
     // ---- elimination (speculative: the diagonal as pivot; see GjFast)
-    {
+    if (careful) {  // (wave-uniform) pivoted throughout, in registers
+      unsigned used = 0;
+      GjPiv<4, 0>::run(ta, tb, tv, used, sPerm, col, rowbase, lane);
+      __syncthreads();
+      const int addr = (rowbase | sPerm[col]) << 2;  // unknown `col` sits in the column that was the pivot of step `col`
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tb[q] = bperm(addr, tb[q]);
+      tv = bperm(addr, tv);
+      __syncthreads();
+    } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         sSave[q][lane] = ta[q];
@@ -977,7 +1043,7 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
       int bad = 0;
       GjFast<4, 0>::run(ta, tb, tv, bad, col);
       bad |= (fabs(tv) + fabs(tb[0]) + fabs(tb[1]) + fabs(tb[2]) + fabs(tb[3]) < 1e300) ? 0 : 1;  // zero pivot: inf / nan
-      bad |= careful;
+      bad |= force_redo;
       if (__any(bad)) {  // some diagonal pivot was too small: pivoted elimination of the saved inputs
         pivoted_lds(true);
         const int src = sPerm[col];  // unknown `col` sits in the column that was the pivot of step `col`
@@ -1154,14 +1220,20 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
     }
     double rhs = br - col_dot(bat, col_to_row(tv, rowbase, kq));
     double none[4] = {0.0, 0.0, 0.0, 0.0};
-    {
+    if (careful) {
+      unsigned used = 0;
+      GjPiv<0, 0>::run(mt, none, rhs, used, sPerm, col, rowbase, lane);
+      __syncthreads();
+      rhs = bperm((rowbase | sPerm[col]) << 2, rhs);
+      __syncthreads();
+    } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) sSave[q][lane] = mt[q];
       if (kq == 0) sSave[8][col] = rhs;
       int bad = 0;
       GjFast<0, 0>::run(mt, none, rhs, bad, col);
       bad |= (fabs(rhs) < 1e300) ? 0 : 1;
-      bad |= careful;
+      bad |= force_redo;
       if (__any(bad)) {
         pivoted_lds(false);
         rhs = sSave[8][sPerm[col]];
@@ -1520,7 +1592,7 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
   const bool iso = d.Ns > 0 && mg == 0;
   const bool beam = d.beam != 0;
   const double mu0 = beam ? d.mu0[c] : 1.0;
-  const int careful = chain_needs_pivoting(d, RTD_BC_CAREFUL_ALL_MODE0 ? mg == 0 : iso, kk, L, NP);
+  const int careful = chain_needs_pivoting(d, iso, kk, L, NP) | (d.flags & 1) | ((d.flags >> 2) & 1);  // (RTD_BC_FORCE_PIVOT: either value)
   if ((d.flags & 2) && m % 3 == 0) {  // test hook (RTD_BC_FORCE_HANDOVER): every third Fourier mode's chain goes to the pivoted
     //                                    kernels (by mode, not by chain index: the choice must not depend on the windowing)
     if (lane == 0) {

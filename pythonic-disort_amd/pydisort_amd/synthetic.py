@@ -38,6 +38,17 @@ def cfg4_columns_block(C, first=0, L=20, NQuad=32, seed=4):
                 phi0=np.zeros(C), f_arr=g**NQuad)
 
 
+def cfg4_cloud_columns(C, first=0, L=20, NQuad=32, cloud_layer=7, omega_cloud=1.0 - 1e-6):
+    """cfg4 with a conservative cloud in EVERY column: layer `cloud_layer` has omega = 1 - 1e-6 (its smallest eigenvalue is
+    ~1e-3: every Fourier-mode-0 chain of the batch takes the pivoted elimination of the boundary-condition kernel).  The
+    near-conservative regime the benchmark distribution (omega <= 0.99) never touches; bench.py reports its rate beside the
+    headline so that the cost of the careful path is driver-visible."""
+    cfg = cfg4_columns_block(C, first=first, L=L, NQuad=NQuad)
+    cfg["omega_arr"] = cfg["omega_arr"].copy()
+    cfg["omega_arr"][:, cloud_layer] = omega_cloud
+    return cfg
+
+
 def cfg3_columns(C, first=0, big=True, seed=9):
     """Test-Problem-9-like multi-layer atmospheres with every layer different, replicated with a
     per-column perturbation of omega.  big=True: L=8, NQuad=16 (BASELINE wording); False: L=6, NQuad=8."""

@@ -823,13 +823,16 @@ def test_device_bdrf_modes_equal_host_cosine_sums(amd):
 
 
 @pytest.mark.gpu
-def test_fused_bc_kernel_pivoted_path_on_goldens():
+@pytest.mark.parametrize("how", ["1", "2"])
+def test_fused_bc_kernel_pivoted_path_on_goldens(how):
     """The fused boundary-condition kernel eliminates speculatively (diagonal pivots) and falls back to the fully
     pivoted elimination when a pivot is small.  RTD_BC_FORCE_PIVOT=1 sends EVERY elimination through the fallback
-    (and its column un-permutation): the golden replay and the random cases with 18..32 streams must still pass."""
+    (the LDS redo and its column un-permutation); =2 sends every chain of the 32-stream kernel through the register-resident
+    column-pivoted elimination that near-conservative mode-0 chains take (GjPiv, round 4): the golden replay and the
+    random cases with 18..32 streams must still pass."""
     import subprocess
     import sys
-    env = dict(os.environ, RTD_BC_FORCE_PIVOT="1")
+    env = dict(os.environ, RTD_BC_FORCE_PIVOT=how)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"),
                         os.path.join(os.path.dirname(__file__), "test_gpu_random_parity.py"),
