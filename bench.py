@@ -361,7 +361,7 @@ def config_leg(name, golden, maker, kwargs, columns, window, device, passes, liv
     fl = algorithmic_flops(nl, nq, nq, nl + 1)
     np_ = 4 if nq <= 8 else 8 if nq <= 16 else 16 if nq <= 32 else 32
     names = {"eigen": f"rtd_eigen_kernel<{np_}, 2>",
-             "bc": "rtd_bc_tile_kernel<2>" if np_ == 32 else "rtd_bc_mfma_kernel" if np_ == 16 else f"rtd_iface_kernel<{np_}> + rtd_sweep_kernel<{np_}>"}
+             "bc": "rtd_bc_tile_kernel<2>" if np_ == 32 else "rtd_bc_mfma_kernel" if np_ == 16 else f"rtd_bc_small_kernel<{np_}>"}
     roof, ms = roofline_of(stage, fl, columns / nwin, names)
     roof["whole_path_tflops"] = fl["total"] * rate / 1e12
     roof["whole_path_frac"] = roof["whole_path_tflops"] / FP64_PEAK_TFLOPS

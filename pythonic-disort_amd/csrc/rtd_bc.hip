@@ -539,62 +539,8 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
 #ifndef RTD_BCF_WIN
 #define RTD_BCF_WIN 20  // layers of small vectors resident in LDS (12.6 KB per wavefront with the save area: 12 per CU)
 #endif
-__device__ __forceinline__ v4f64 mm_t(const v4f64& X, const v4f64& Y) {  // X^T Y
-  v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[0], Y[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[1], Y[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[2], Y[2], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[3], Y[3], acc, 0, 0, 0);
-  return acc;
-}
-// value held by lane-row R (compile-time) in the same column, for every lane-row
-template <int R>
-__device__ __forceinline__ double bcast_row(double v, const int col) {
-  return bperm(((R << 4) | col) << 2, v);
-}
-// sum over the four lane-rows (kq) of the wavefront; the result is replicated over them
-__device__ __forceinline__ double sum_kq(double p) {
-  p += xor_lane<16>(p);
-  p += __shfl_xor(p, 32, 64);
-  return p;
-}
-// sum_rows X[r][col] v[r]  with v in row form (register q = v[4 q + kq]); result in column form
-__device__ __forceinline__ double col_dot(const v4f64& X, const v4f64& vr) {
-  return sum_kq(X[0] * vr[0] + X[1] * vr[1] + X[2] * vr[2] + X[3] * vr[3]);
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_add(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-  return v + __hiloint2double(hi, lo);
-}
-// sum over the 16 lanes of a lane-row (replicated over them): quad permutes, half mirror, mirror
-__device__ __forceinline__ double row_sum16(double v) {
-  v = dpp_add<0xB1>(v);
-  v = dpp_add<0x4E>(v);
-  v = dpp_add<0x141>(v);
-  v = dpp_add<0x140>(v);
-  return v;
-}
-// sum_cols X[row][c] u[c]  with u in column form; result in row form
-__device__ __forceinline__ v4f64 row_dot(const v4f64& X, const double uc) {
-  v4f64 r;
-  r[0] = row_sum16(X[0] * uc);
-  r[1] = row_sum16(X[1] * uc);
-  r[2] = row_sum16(X[2] * uc);
-  r[3] = row_sum16(X[3] * uc);
-  return r;
-}
-// column form -> row form of a 16-vector
-__device__ __forceinline__ v4f64 col_to_row(const double vc, const int rowbase, const int kq) {
-  v4f64 r;
-  r[0] = bperm((rowbase | kq) << 2, vc);
-  r[1] = bperm((rowbase | (4 + kq)) << 2, vc);
-  r[2] = bperm((rowbase | (8 + kq)) << 2, vc);
-  r[3] = bperm((rowbase | (12 + kq)) << 2, vc);
-  return r;
-}
+#include "rtd_bc_tile_common.h"
+
 // Speculative, branch-free form of the same elimination with the diagonal as pivot at every step: straight-line
 // code (the 16 steps schedule into each other), no pivot search.  A step whose diagonal candidate is more than a
 // factor RTD_GJ_GROWTH smaller than another unused entry of its row raises `bad` (a zero pivot leaves inf / nan in the
@@ -673,9 +619,6 @@ struct GjFast<NB, 16> {
 // pivot column is wave-uniform, its row entry comes by v_readlane, its column by ds_bpermute (a run-time lane: no DPP
 // broadcast); 18 cross-lane fetches + 9 FMAs per step, no LDS memory, no barrier.  Afterwards the column that was the
 // pivot of step c holds column c of Tb^T Ta^-T and t^T Ta^-T (perm[c], written to sPerm): the caller moves them back.
-__device__ __forceinline__ double readlane_f64(const double v, const int lane_uniform) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane_uniform), __builtin_amdgcn_readlane(__double2loint(v), lane_uniform));
-}
 template <int NB, int K>
 struct GjPiv {
   static __device__ __forceinline__ void run(double (&ta)[4], double (&tb)[4], double& tv, unsigned& used, int* sPerm, const int col,
@@ -713,32 +656,6 @@ struct GjPiv {
     if constexpr (K + 1 < 16) GjPiv<NB, K + 1>::run(ta, tb, tv, used, sPerm, col, rowbase, lane);
   }
 };
-
-// A chain whose result hangs on the last digits of its coefficients: the thermal (polynomial) particular solution of a layer with
-// a tiny eigenvalue k is ~ 1/k^(order + 1) times the source and is cancelled by the homogeneous part -- at k = 1.4e-3 (omega =
-// 1 - 1e-6) seventeen orders of magnitude above the field, which is then as good as the RELATIVE accuracy of C.  The speculative
-// elimination accepts multipliers up to 64 (1e6 in the tiled kernel) and loses two to three digits against the pivoted one
-// there (9e-2 against 3e-4 of the field scale on the case of DESIGN.md section 8, the reference: 2e-4); such chains -- mode 0
-// with a thermal source and an eigenvalue below RTD_BC_CAREFUL_K somewhere -- take the pivoted elimination throughout.
-#ifndef RTD_BC_CAREFUL_K
-#define RTD_BC_CAREFUL_K 0.02
-#endif
-#ifndef RTD_BC_CAREFUL_ALL_MODE0
-#define RTD_BC_CAREFUL_ALL_MODE0 1  /* 32 streams (rtd_bc_mfma_kernel): every mode-0 chain with such an eigenvalue, thermal source or
-                                       not.  Round 3 measured what it buys -- the near-conservative beam cases go from <= 1.5e-9 to
-                                       <= 5e-12 of their 40-digit solutions -- and what it cost with the LDS redo: 219 k -> 71 k col/s on a
-                                       batch with a conservative cloud layer in every column; with GjPiv (registers) it is the default.
-                                       The tiled 64-stream kernel keeps the thermal-only rule (its pivoted path is the LDS redo). */
-#endif
-__device__ __forceinline__ int chain_needs_pivoting(const RtdDev& d, const bool iso, const double* kk, const int L, const int np) {
-  int careful = 0;
-  if (iso) {
-    double kmin = 1e300;
-    for (int i = 0; i < L * np; ++i) kmin = fmin(kmin, kk[i]);  // wave-uniform: scalar loads; mode 0 of thermal runs only
-    careful = kmin < RTD_BC_CAREFUL_K ? 1 : 0;
-  }
-  return careful;
-}
 
 // Four wavefronts per SIMD: <= 128 registers and <= 10 KB of LDS each, so the kernel prefetches one layer ahead, forms the
 // interface products one after the other (one accumulator set live), takes exp(-k dtau) from memory, saves t^T once and
@@ -1448,130 +1365,6 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
 // chains, 15 ms), 1e3: 189, 1e5: 4 (2.8 ms), 1e8: none; the error against the reference goldens is 2.19e-10 of the field
 // scale at every one of them (the row-per-lane path alone: 2.1e-9).  1e6 bounds the relative perturbation of a step by
 // ~1e-10; zero pivots and overflow still go to the pivoted kernels through the non-finite check.
-#ifndef RTD_GJ_GROWTH_TILED
-#define RTD_GJ_GROWTH_TILED 1e6
-#endif
-#ifndef RTD_BCT_WIN
-#define RTD_BCT_WIN 24  // layers of small vectors resident in LDS (T = 2: 18 KB next to the 17 KB save area, 4 wavefronts per CU)
-#endif
-template <int T> struct MatT { v4f64 t[T][T]; };  // t[I][J][q] at lane (kq, col) = element [16 I + 4 q + kq][16 J + col]
-template <int T> struct RowT { v4f64 r[T]; };     // vector in row form:    r[I][q] = v[16 I + 4 q + kq], same in every column
-template <int T> struct ColT { double c[T]; };    // vector in column form: c[J] = v[16 J + col], same in every lane-row
-
-template <int T>
-__device__ __forceinline__ MatT<T> mmT(const MatT<T>& X, const MatT<T>& Y) {  // X^T Y
-  MatT<T> R;
-#pragma unroll
-  for (int I = 0; I < T; ++I)
-#pragma unroll
-    for (int J = 0; J < T; ++J) {
-      v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int K = 0; K < T; ++K)
-#pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X.t[K][I][sidx], Y.t[K][J][sidx], acc, 0, 0, 0);
-      R.t[I][J] = acc;
-    }
-  return R;
-}
-template <int T>
-__device__ __forceinline__ ColT<T> col_dotT(const MatT<T>& X, const RowT<T>& v) {  // X^T v
-  ColT<T> o;
-#pragma unroll
-  for (int J = 0; J < T; ++J) {
-    double a = 0.0;
-#pragma unroll
-    for (int I = 0; I < T; ++I) a += X.t[I][J][0] * v.r[I][0] + X.t[I][J][1] * v.r[I][1] + X.t[I][J][2] * v.r[I][2] + X.t[I][J][3] * v.r[I][3];
-    o.c[J] = sum_kq(a);
-  }
-  return o;
-}
-template <int T>
-__device__ __forceinline__ RowT<T> row_dotT(const MatT<T>& X, const ColT<T>& v) {  // X v
-  RowT<T> o;
-#pragma unroll
-  for (int I = 0; I < T; ++I)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      double a = 0.0;
-#pragma unroll
-      for (int J = 0; J < T; ++J) a += X.t[I][J][q] * v.c[J];
-      o.r[I][q] = row_sum16(a);
-    }
-  return o;
-}
-template <int T>
-__device__ __forceinline__ RowT<T> col_to_rowT(const ColT<T>& v, const int rowbase, const int kq) {
-  RowT<T> o;
-#pragma unroll
-  for (int I = 0; I < T; ++I) o.r[I] = col_to_row(v.c[I], rowbase, kq);
-  return o;
-}
-
-template <int T, int K>
-struct GjFastT {
-  static __device__ __forceinline__ void run(MatT<T>& ta, MatT<T>& tb, ColT<T>& tv, int& bad, const int col) {
-    constexpr int KI = K >> 4, K16 = K & 15, QK = K16 >> 2, RK = K16 & 3;
-    double x[T], f[T];
-#pragma unroll
-    for (int J = 0; J < T; ++J) x[J] = bcast_row<RK>(ta.t[KI][J][QK], col);  // row K of Ta^T, replicated over the lane-rows
-    const double xk = bcast16<K16>(x[KI]);
-    const double r0 = __builtin_amdgcn_rcp(xk);
-    const double rp = r0 * (2.0 - xk * r0);
-#pragma unroll
-    for (int J = 0; J < T; ++J) {
-      f[J] = (J == KI && col == K16) ? 1.0 - rp : x[J] * rp;
-      bad |= (16 * J + col > K && fabs(f[J]) > RTD_GJ_GROWTH_TILED) ? 1 : 0;
-    }
-    // v[J] -= f[J] bcast(v[KI]) for every register row v of [Ta^T ; Tb^T ; t^T] that is not finished, the pivot tile column
-    // last (it is the source of the others); one v_fmac_f64_dpp each (see GjFast for the hazard notes)
-    // (ext-vector elements cannot be bound to asm operands by reference: copy in, update, copy out -- registers all the way)
-#define RTD_UPD(VEC, Q, SRC, FJ)                                                                                              \
-  {                                                                                                                           \
-    double t_ = VEC[Q];                                                                                                       \
-    const double s_ = SRC;                                                                                                    \
-    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(t_) : "v"(s_), "v"(FJ), "n"(K16)); \
-    VEC[Q] = t_;                                                                                                              \
-  }
-#define RTD_UPD_SELF(VEC, Q, FJ)                                                                                              \
-  {                                                                                                                           \
-    double t_ = VEC[Q];                                                                                                       \
-    asm volatile("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(t_) : "v"(FJ), "n"(K16));    \
-    VEC[Q] = t_;                                                                                                              \
-  }
-#pragma unroll
-    for (int I = KI; I < T; ++I)
-#pragma unroll
-      for (int q = (I == KI ? QK : 0); q < 4; ++q) {
-#pragma unroll
-        for (int J = 0; J < T; ++J)
-          if (J != KI) RTD_UPD(ta.t[I][J], q, ta.t[I][KI][q], f[J])
-        RTD_UPD_SELF(ta.t[I][KI], q, f[KI])
-      }
-#pragma unroll
-    for (int I = 0; I < T; ++I)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int J = 0; J < T; ++J)
-          if (J != KI) RTD_UPD(tb.t[I][J], q, tb.t[I][KI][q], f[J])
-        RTD_UPD_SELF(tb.t[I][KI], q, f[KI])
-      }
-#pragma unroll
-    for (int J = 0; J < T; ++J)
-      if (J != KI) RTD_UPD(tv.c, J, tv.c[KI], f[J])
-    {
-      double t_ = tv.c[KI];
-      asm volatile("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(t_) : "v"(f[KI]), "n"(K16));
-      tv.c[KI] = t_;
-    }
-#undef RTD_UPD
-#undef RTD_UPD_SELF
-    if constexpr (K + 1 < 16 * T) GjFastT<T, K + 1>::run(ta, tb, tv, bad, col);
-  }
-};
-
 template <int T>
 __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDev d, int* need_split) {
   constexpr int NP = 16 * T, Q = 2 * NP, NN = NP * NP;
@@ -2347,9 +2140,18 @@ void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
         hipLaunchKernelGGL(rtd_bc_mfma_kernel, gc, dim3(64), 0, s, d);
       }
       break;
-    case 32:
-      RTD_BC_TILED_CASE(32, 2)
+    case 32: {
+      // the lean two-wavefronts-per-SIMD kernel (rtd_bc_tile2.hip) unless RTD_BC_TILE_V1 asks for rtd_bc_tile_kernel<2>
+      static const bool tile_v1 = getenv("RTD_BC_TILE_V1") != nullptr;
+      if (part == 0 && !tile_v1) {
+        (void)hipMemsetAsync(d.need_split, 0, sizeof(int) * (size_t)d.C * d.M, s);
+        (void)hipMemsetAsync(d.split_any, 0, sizeof(int), s);
+        rtd_launch_bc_tile2(d, s);
+      } else {
+        RTD_BC_TILED_CASE(32, 2)
+      }
       break;
+    }
     default: break;
   }
 #undef RTD_BC_CASE

@@ -71,3 +71,35 @@ def test_arts_thermal_case_reference_is_5e_5_pointwise_from_the_truth():
         worst = max(worst, goldens.max_rel_err(ev["out"], z[f"c{ci}.u"])[1])
     assert 1e-5 < worst < 1e-4
     assert abs(worst - float(z["reference_u_pointwise_rel"])) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["1a", "9c", "8b", "6d"])
+def test_arbiter_agrees_with_the_reference_itself_on_well_conditioned_goldens(name):
+    """The 40-digit machinery against outputs the builder did not write: PythonicDISORT's own captured results
+    (tests/golden/ref, made by importing the reference in the build container).  tools/arbiter_check.py does this for every
+    captured call of all golden cases (profiles/r04_arbiter_vs_reference.json: 34 cases within 8e-11 of the reference, the other
+    seven are the omega = 1 - 1e-6 / conservative test problems where the reference's float64 result is itself at 1e-9 ... 4e-8);
+    four quick ones here: isotropic beam case, the 6-layer mixed-source case, a thermal case, a BDRF flux-only case."""
+    import importlib.util
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    sys.path.insert(0, tools)
+    try:
+        spec = importlib.util.spec_from_file_location("arbiter_check", os.path.join(tools, "arbiter_check.py"))
+        A = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(A)
+    finally:
+        sys.path.remove(tools)
+    for call in goldens.load(name):
+        kw = call["kwargs"]
+        ev_u = next((e for e in call["evals"] if e["name"] == "u" and not e["kwargs"] and len(e["args"]) == 2), None)
+        ev_f = next(e for e in call["evals"] if e["name"] == "flux_up" and not e["kwargs"] and len(e["args"]) == 1)
+        use_u = ev_u is not None and not kw.get("NT_cor", False) and not kw.get("only_flux", False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            u, fup, _ = A._one((kw, ev_u["args"][0] if use_u else None, ev_u["args"][1] if use_u else None, np.atleast_1d(ev_f["args"][0])))
+        ref_f = np.atleast_1d(np.asarray(ev_f["out"], float))
+        assert np.max(np.abs(ref_f - fup)) <= 1e-11 * max(np.max(np.abs(fup)), 1e-300), name
+        if use_u:
+            ref_u = np.asarray(ev_u["out"], float)
+            assert np.max(np.abs(ref_u - u.reshape(ref_u.shape))) <= 1e-11 * np.max(np.abs(u)), name

@@ -304,6 +304,11 @@ def case_synth(key):
     from pydisort_amd import synthetic
     name, col = key.rsplit("_", 1)
     col = int(col)
+    if name == "cfg4cloud":  # cfg4 with a conservative cloud layer in every column (bench.py's all-cloud leg): own points
+        cfg = synthetic.cfg4_cloud_columns(col + 1)
+        kw = synthetic.column_kwargs(cfg, col)
+        t = np.concatenate(([0.0], cfg["tau_arr"][col]))
+        return kw, np.sort(np.concatenate((t, 0.5 * (t[1:] + t[:-1])))), np.array([0.0, np.pi / 2, np.pi, 2.5])
     cfg = {"cfg4": synthetic.cfg4_columns, "cfg5": synthetic.cfg5_columns}[name](col + 1)
     kw = synthetic.column_kwargs(cfg, col)
     if "bdrf_q" in cfg:
