@@ -60,11 +60,11 @@ def algorithmic_flops(nlayers=L, nquad=NQUAD, nmodes=None, ntau=NTAU):
 
 
 def measured_traffic(kernel, columns_per_launch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this round (profiles/r03_pmc_traffic.json:
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this round (profiles/r04_pmc_traffic.json:
     FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as read; separate passes), or None when that file was taken at
     another window size than this run's."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as f:
             rec = json.load(f)
         if int(rec.get("columns_per_launch", 0)) != int(columns_per_launch):
             return None
@@ -78,14 +78,14 @@ def north_star_evidence(columns_per_launch, seconds_per_window, live=None):
     path is compute-bound) of all kernels of a window from the committed PMC passes over this run's time per
     window, and the matrix-pipe / vector-issue busy fractions of the two main kernels from the same passes."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as f:
             rec = json.load(f)
         if int(rec.get("columns_per_launch", 0)) != int(columns_per_launch):
             return None
         total = float(sum(live.values())) if live else float(rec["total_hbm_bytes_per_step"])
         out = {"hbm_bytes_per_window": total, "traffic_measured_in_this_run": bool(live), "hbm_GB_per_s": total / seconds_per_window / 1e9,
                "frac_of_8_TB_per_s": total / seconds_per_window / 8e12,
-               "what": "measured traffic (FETCH_SIZE x 2 + WRITE_SIZE of every kernel of a window, profiles/r03_pmc_traffic.json) / "
+               "what": "measured traffic (FETCH_SIZE x 2 + WRITE_SIZE of every kernel of a window, profiles/r04_pmc_traffic.json) / "
                        "this run's time per window; NOT algorithmic bytes (22.5 KB per column: 0.003 % of 8 TB/s)"}
         for k, name in (("rtd_eigen_kernel", "eigen"), ("rtd_bc_mfma_kernel", "bc")):
             v = rec["kernels"][k]
@@ -361,7 +361,7 @@ def config_leg(name, golden, maker, kwargs, columns, window, device, passes, liv
     fl = algorithmic_flops(nl, nq, nq, nl + 1)
     np_ = 4 if nq <= 8 else 8 if nq <= 16 else 16 if nq <= 32 else 32
     names = {"eigen": f"rtd_eigen_kernel<{np_}, 2>",
-             "bc": "rtd_bc_tile_kernel<2>" if np_ == 32 else "rtd_bc_mfma_kernel" if np_ == 16 else f"rtd_bc_small_kernel<{np_}>"}
+             "bc": "rtd_bc_tile2_kernel" if np_ == 32 else "rtd_bc_mfma_kernel" if np_ == 16 else f"rtd_bc_small_kernel<{np_}>"}
     roof, ms = roofline_of(stage, fl, columns / nwin, names)
     roof["whole_path_tflops"] = fl["total"] * rate / 1e12
     roof["whole_path_frac"] = roof["whole_path_tflops"] / FP64_PEAK_TFLOPS
@@ -447,6 +447,54 @@ def many_stream_leg(device, columns=32):
                        "columns_checked": 1, "against": "reference-computed golden tests/golden/synth/q128.npz (128 streams, 2 layers, 64 modes)"}}
 
 
+def all_cloud_leg(device, columns=16384, window=256, passes=3):
+    """cfg4 with a conservative cloud layer (omega = 1 - 1e-6) in EVERY column: the near-conservative regime the benchmark
+    distribution (omega <= 0.99) never touches.  Every Fourier-mode-0 chain then takes the column-pivoted elimination of the
+    boundary-condition kernel (register-resident since round 4); the rate beside the headline makes that cost driver-visible,
+    and two columns with 40-digit solutions (tests/golden/hp/synth_cfg4cloud_*.npz), spliced into different windows of the
+    timed batch, are checked at the interfaces."""
+    from pydisort_amd import synthetic
+    from pydisort_amd._engine import Plan
+    cfg = synthetic.cfg4_cloud_columns(columns)
+    at = (100, 3000)
+    truths = []
+    for k, pos in enumerate(at):
+        one = synthetic.cfg4_cloud_columns(k + 1)
+        for key, v in one.items():
+            if isinstance(v, np.ndarray) and v.shape[:1] == (k + 1,):
+                cfg[key][pos] = v[k]
+        truths.append(np.load(os.path.join(ROOT, "tests", "golden", "hp", f"synth_cfg4cloud_{k}.npz")))
+    plan = Plan(prepare_cfg4(cfg), device=device, work_columns=window)
+    tau = np.concatenate((np.zeros((columns, 1)), cfg["tau_arr"]), axis=1)
+    plan.set_eval_points(tau, np.array([0.0, np.pi / 2, np.pi]))
+    plan.run()
+    plan.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        plan.invalidate_tables()
+        plan.run()
+    plan.synchronize()
+    rate = passes * columns / (time.perf_counter() - t0)
+    res = plan.fetch()
+    plan.close()
+    worst = worst_pw = ref = ref_pw = 0.0
+    for z, pos in zip(truths, at):
+        pts = np.searchsorted(z["tau"], tau[pos])
+        assert np.array_equal(z["tau"][pts], tau[pos])
+        want = z["u"][:, pts, :3]
+        diff = np.abs(res["u"][pos] - want)
+        sig = np.abs(want) > 1e-8 * np.max(np.abs(want))
+        worst = max(worst, float(diff.max() / np.max(np.abs(want))))
+        worst_pw = max(worst_pw, float((diff[sig] / np.abs(want[sig])).max()))
+        ref, ref_pw = max(ref, float(z["oracle_u_scale_rel"])), max(ref_pw, float(z["oracle_u_pointwise_rel"]))
+    return {"value": rate, "unit": "column-solves/sec", "columns": columns, "columns_per_window": window,
+            "workload": "cfg4 with an omega = 1 - 1e-6 layer in every column (fresh inputs every pass): every mode-0 chain is pivoted throughout",
+            "parity": {"max_scale_rel": worst, "max_rel_dI": worst_pw, "columns_checked": len(at),
+                       "against": "40-digit solutions tests/golden/hp/synth_cfg4cloud_{0,1}.npz, taken from the timed batch at the interfaces",
+                       "reference_algorithm_vs_truth": {"max_scale_rel": ref, "max_rel_dI": ref_pw,
+                                                        "note": "the float64 oracle (= the reference's algorithm) on the same two columns"}}}
+
+
 def extra_measurements(device, main_cfg=None, window=2048, live=None):
     """max |dI| of the HIP path against the oracle on the sample columns of the cpu_baseline leg, the only_flux
     throughput, the host-to-host rate of the main batch, and BASELINE's other configs."""
@@ -495,6 +543,7 @@ def extra_measurements(device, main_cfg=None, window=2048, live=None):
                                           "source; 10^4 columns in 79 windows of 128",
                                           "cfg5", "cfg5_columns", {}, 10_000, 128, device, 2, live),
         "cfg5alt_L50_Q128_M64_x32": many_stream_leg(device),
+        "cfg4_all_cloud_x16384": all_cloud_leg(device),
     }
     return out
 
@@ -944,7 +993,7 @@ def run_rank(a, rank, world, local):
             roof["traffic"] = live_main.get(tkey) if live_main and tkey in live_main else measured_traffic(tkey, a.columns)
             roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation (child process, "
                                       "32 windows, windows one after the other)" if live_main and tkey in live_main else
-                                      "profiles/r03_pmc_traffic.json (committed passes)")
+                                      "profiles/r04_pmc_traffic.json (committed passes)")
             if live_main:
                 roof["traffic_all_kernels_per_window"] = float(sum(live_main.values()))
             roof["launches_per_step"] = nwin

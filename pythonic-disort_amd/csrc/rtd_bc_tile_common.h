@@ -83,9 +83,12 @@ __device__ __forceinline__ double readlane_f64(const double v, const int lane_un
 #endif
 __device__ __forceinline__ int chain_needs_pivoting(const RtdDev& d, const bool iso, const double* kk, const int L, const int np) {
   int careful = 0;
-  if (iso) {
+  if (iso) {  // (wave-uniform condition: one chain per wavefront.  The scan is lane-parallel -- one memory latency, then a wave
+    //           reduction: a scalar loop over the L np eigenvalues cost a mode-0 chain L np dependent loads, 6 % of its life)
     double kmin = 1e300;
-    for (int i = 0; i < L * np; ++i) kmin = fmin(kmin, kk[i]);  // wave-uniform: scalar loads; mode 0 of thermal runs only
+    for (int i = (int)threadIdx.x; i < L * np; i += 64) kmin = fmin(kmin, kk[i]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) kmin = fmin(kmin, __shfl_xor(kmin, o, 64));
     careful = kmin < RTD_BC_CAREFUL_K ? 1 : 0;
   }
   return careful;
