@@ -941,16 +941,11 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
     RTD_STAMP();  // 4 l + 1: loop top (register rotation, loads issued)
     const int r0 = l - wb, r1 = ln - wb;
     // ---- elimination (speculative: the diagonal as pivot; see GjFast)
-    if (careful) {  // (wave-uniform) pivoted throughout, in registers
-      unsigned used = 0;
-      GjPiv<4, 0>::run(ta, tb, tv, used, sPerm, col, rowbase, lane);
-      __syncthreads();
-      const int addr = (rowbase | sPerm[col]) << 2;  // unknown `col` sits in the column that was the pivot of step `col`
-#pragma unroll
-      for (int q = 0; q < 4; ++q) tb[q] = bperm(addr, tb[q]);
-      tv = bperm(addr, tv);
-      __syncthreads();
-    } else {
+    {
+      // (the speculative elimination stays unconditional and in ONE basic block with the products above: its dependent steps
+      //  leave the issue slots the MFMAs fill.  A chain that is pivoted throughout pays for it as well -- straight-line, cheap --
+      //  and then redoes the elimination from the saved inputs; wrapping the two forms in if / else split the block and cost
+      //  the kernel 4 %)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         sSave[q][lane] = ta[q];
@@ -960,14 +955,32 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
       int bad = 0;
       GjFast<4, 0>::run(ta, tb, tv, bad, col);
       bad |= (fabs(tv) + fabs(tb[0]) + fabs(tb[1]) + fabs(tb[2]) + fabs(tb[3]) < 1e300) ? 0 : 1;  // zero pivot: inf / nan
-      bad |= force_redo;
-      if (__any(bad)) {  // some diagonal pivot was too small: pivoted elimination of the saved inputs
-        pivoted_lds(true);
-        const int src = sPerm[col];  // unknown `col` sits in the column that was the pivot of step `col`
+      bad |= force_redo | careful;
+      if (__any(bad)) {  // some diagonal pivot was too small, or the chain is pivoted throughout: the saved inputs once more
+        if (careful) {  // (wave-uniform) in registers
+          __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) tb[q] = sSave[4 + q][16 * kq + src];
-        tv = sSave[8][src];
-        __syncthreads();
+          for (int q = 0; q < 4; ++q) {
+            ta[q] = sSave[q][lane];
+            tb[q] = sSave[4 + q][lane];
+          }
+          tv = sSave[8][col];
+          unsigned used = 0;
+          GjPiv<4, 0>::run(ta, tb, tv, used, sPerm, col, rowbase, lane);
+          __syncthreads();
+          const int addr = (rowbase | sPerm[col]) << 2;  // unknown `col` sits in the column that was the pivot of step `col`
+#pragma unroll
+          for (int q = 0; q < 4; ++q) tb[q] = bperm(addr, tb[q]);
+          tv = bperm(addr, tv);
+          __syncthreads();
+        } else {
+          pivoted_lds(true);
+          const int src = sPerm[col];  // unknown `col` sits in the column that was the pivot of step `col`
+#pragma unroll
+          for (int q = 0; q < 4; ++q) tb[q] = sSave[4 + q][16 * kq + src];
+          tv = sSave[8][src];
+          __syncthreads();
+        }
       }
     }
     RTD_STAMP();  // 4 l + 2: elimination
