@@ -293,8 +293,10 @@ enum {
  *   RTD_BC_FORCE_HANDOVER tiled (64-stream) kernel: every third chain goes to the pivoted row-per-lane kernels
  *   RTD_BC_TILED          32 streams through the tiled kernel's T = 1 instance instead of rtd_bc_mfma_kernel
  *   RTD_BC_TILE_V1        64 streams through rtd_bc_tile_kernel<2> (one wavefront per SIMD, rounds 2-3) instead of the lean
- *                         rtd_bc_tile2_kernel (two per SIMD, round 4)
+ *                         two-wavefronts-per-SIMD kernel of rtd_bc_tile2.hip (round 4)
  *   RTD_EIG_MFMA          eigen stage with its assembly GEMMs on the matrix cores (measured slower; a tested variant)
+ *   RTD_EIG_SMALL_V1      2 ... 8 streams: eigen stage through the four-lanes-per-problem instance of the general eigen kernel
+ *                         instead of the one-lane-per-problem kernel of rtd_eig_small.hip
  *   RTD_SMALL_SPLIT       2 ... 16 streams through the separate interface / sweep / evaluation kernels instead of the fused
  *                         rtd_bc_small_kernel
  *   RTD_DEBUG             diagnostics on stderr

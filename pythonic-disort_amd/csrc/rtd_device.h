@@ -107,6 +107,7 @@ struct RtdRaw {
 // launchers (one per translation unit)
 void rtd_launch_prepare(const RtdDev& d, const RtdRaw& r, hipStream_t s);
 void rtd_launch_tables(const RtdDev& d, hipStream_t s, bool with_quad = true);  // with_quad: also the column-independent Y table
+void rtd_launch_eig_small(const RtdDev& d, hipStream_t s);  // rtd_eig_small.hip: the one-lane-per-problem eigen kernel (NP = 4, 8)
 void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part);  // the fused eigen kernel runs as part 1 (0, 2: empty timing slots)
 void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part);   // 0 iface, 1 sweep
 void rtd_launch_bc_small(const RtdDev& d, hipStream_t s);  // rtd_bc_small.hip: the fused kernel of the 2 ... 16-stream path

@@ -1104,6 +1104,12 @@ void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part) {
   case NPV:                                                                                      \
     hipLaunchKernelGGL((rtd_eigen_kernel<NPV, 2>), grid, dim3(64), 0, s, d);                     \
     break;
+  // 2 ... 8 streams: the one-lane-per-problem kernel (rtd_eig_small.hip) unless RTD_EIG_SMALL_V1 asks for rtd_eigen_kernel<4, 2>
+  static const bool small_v1 = getenv("RTD_EIG_SMALL_V1") != nullptr;
+  if (d.NP == 4 && !small_v1) {
+    rtd_launch_eig_small(d, s);
+    return;
+  }
   switch (d.NP) {
     RTD_EIG_CASE(4)
     RTD_EIG_CASE(8)
