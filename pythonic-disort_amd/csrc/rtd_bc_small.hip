@@ -52,9 +52,13 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_small_kernel(RtdDev d) {
 #endif
   RTD_BSTAMP(0);
   constexpr int GPW = 64 / NP, LD = NP + 1, Q = 2 * NP, NN = NP * NP;
-  __shared__ double sM[4][GPW][NP * LD];
-  __shared__ double sVec[GPW][10][NP];
-  enum { VK0, VK1, VE0, VE1, VS, VD, VRB, VRT, VP, VQ };
+  // LDS (17.9 KB at NP = 8: eight workgroups per CU, i.e. the 2 048 wavefronts of 1 024 cfg3 columns are resident at once; with a
+  // fourth matrix buffer and ten vectors -- 23.5 KB, six per CU -- the kernel ran in two rounds: 163 instead of ~100 us):
+  // two matrix buffers for the layer in use, which the interface operators then overwrite in place (see the loop), one for S at
+  // the bottom boundary; eight small vectors per chain, two of them doing double duty (VP, VQ).
+  __shared__ double sM[3][GPW][NP * LD];
+  __shared__ double sVec[GPW][8][NP];
+  enum { VK0, VK1, VE0, VE1, VS, VD, VRB, VRT, VP = VRT, VQ = VD };
   const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
   const long nprob = (long)d.C * d.M;
   long cm = (long)blockIdx.x * GPW + grp;
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_small_kernel(RtdDev d) {
   if (!valid) cm = nprob - 1;  // (a group without a chain redoes the last one and skips the stores)
   const int m = (int)(cm % d.M), c = (int)(cm / d.M);
   const int L = d.L, Lm1 = L - 1, NT = L + 1;
-  double *Yl = sM[0][grp], *Al = sM[1][grp], *Wq_ = sM[2][grp], *Wp_ = sM[3][grp];
+  double *Yl = sM[0][grp], *Al = sM[1][grp], *Sb = sM[2][grp];
   double(*vec)[NP] = sVec[grp];
   const double* Ym = d.Ym + cm * L * NN;
   const double* Am = d.Am + cm * L * NN;
@@ -149,12 +153,31 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_small_kernel(RtdDev d) {
     double* const vE1 = vec[(l & 1) ? VE0 : VE1];
     RTD_BSTAMP(1);
     const Lay nn = load(min(l + 2, Lm1));  // consumed by the NEXT iteration: a whole elimination to arrive
-    // independent of the carry, so ahead of the elimination in program order (the scheduler fills its bubbles with them):
-    // column j of Wp, Wq = (A_l^T Y' +- diag(k) Y_l^T A' diag(1/k'))/2 and the jump of the particular solution
+    // Independent of the carry, so ahead of the elimination in program order (the scheduler fills its bubbles with them): the
+    // jump of the particular solution and rho = G_l^-1 r_l, THEN the interface operators -- column j of Wp, Wq =
+    // (A_l^T Y' +- diag(k) Y_l^T A' diag(1/k'))/2 -- which overwrite A_l, Y_l in place: iteration r reads column r of both for the
+    // last time and stores row r of Wp, Wq there, transposed (Wp[r][j] at A_l[j][r], Wq[r][j] at Y_l[j][r]).
+    double rt = 0.0, rb = 0.0;
     if (l < Lm1) {
+      // r_l = p_(l+1)(tau_(l+1)) - p_l(tau_(l+1))  (:184-205, :242-245), lane = stream
+      const double ru = (nxt.bu - cur.bu) * nxt.at + (nxt.vtu - cur.vbu);
+      const double rd = (nxt.bd - cur.bd) * nxt.at + (nxt.vtd - cur.vbd);
+      __syncthreads();  // (VS, VD may still be read: the previous user is the bottom / a row sum -- not in this loop, but cheap)
+      vec[VS][j] = Tj * (ru + rd);
+      vec[VD][j] = Tj * (ru - rd);
+      __syncthreads();
+      // rho_t/b = 1/4 [V^-1 (r_up + r_dn) +- U^-1 (r_up - r_dn)],  V^-1[j][i] = T_i A[i][j],  U^-1[j][i] = -k_j T_i Y[i][j]
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const double a = Al[i * LD + j] * vec[VS][i], b = -cur.k * Yl[i * LD + j] * vec[VD][i];
+        rt += a + b;
+        rb += a - b;
+      }
+      rt *= 0.25;
+      rb *= 0.25;
       const double rk1 = fast_rcp(nxt.k);
 #pragma unroll
-      for (int r = 0; r < NP; ++r) {  // (Wq_, Wp_ are free: the previous iteration's carry update is over)
+      for (int r = 0; r < NP; ++r) {
         double vv = 0.0, uu = 0.0;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -162,15 +185,10 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_small_kernel(RtdDev d) {
           uu += Yl[i * LD + r] * nxt.a[i];
         }
         uu *= vk0[r] * rk1;
-        Wp_[r * LD + j] = 0.5 * (vv + uu);
-        Wq_[r * LD + j] = 0.5 * (vv - uu);
+        Al[j * LD + r] = 0.5 * (vv + uu);  // Wp[r][j]  (every lane has read column r: LDS operations of a wavefront are in order)
+        Yl[j * LD + r] = 0.5 * (vv - uu);  // Wq[r][j]
         if (NP > 4 || (r & 1)) RTD_FENCE();  // (keeps the scheduler from hoisting the LDS reads of every r at once: registers)
       }
-      // r_l = p_(l+1)(tau_(l+1)) - p_l(tau_(l+1))  (:184-205, :242-245), lane = stream
-      const double ru = (nxt.bu - cur.bu) * nxt.at + (nxt.vtu - cur.vbu);
-      const double rd = (nxt.bd - cur.bd) * nxt.at + (nxt.vtd - cur.vbd);
-      vec[VS][j] = Tj * (ru + rd);
-      vec[VD][j] = Tj * (ru - rd);
     }
     pc = -1;
     RTD_BSTAMP(2);
@@ -179,16 +197,6 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_small_kernel(RtdDev d) {
     if (pc < 0) pc = j;  // (a chain that has gone NaN finds no pivots: see rtd_sweep_kernel)
     if (l == Lm1) break;
     __syncthreads();
-    // rho = G_l^-1 r_l:  rho_t/b = 1/4 [V^-1 (r_up + r_dn) +- U^-1 (r_up - r_dn)],  V^-1[j][i] = T_i A[i][j],  U^-1[j][i] = -k_j T_i Y[i][j]
-    double rt = 0.0, rb = 0.0;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const double a = Al[i * LD + j] * vec[VS][i], b = -cur.k * Yl[i * LD + j] * vec[VD][i];
-      rt += a + b;
-      rb += a - b;
-    }
-    rt *= 0.25;
-    rb *= 0.25;
     vec[VRB][j] = rb;
     vec[VRT][j] = rt;
     vk1[j] = nxt.k;
@@ -219,18 +227,18 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_small_kernel(RtdDev d) {
       double swq = 0.0, swp = 0.0;
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
-        swq += tb[k] * Wq_[k * LD + cc];
-        swp += tb[k] * Wp_[k * LD + cc];
+        swq += tb[k] * Yl[cc * LD + k];  // Wq[k][cc]
+        swp += tb[k] * Al[cc * LD + k];  // Wp[k][cc]
       }
-      ta[cc] = -(Er * swq + Wp_[pc * LD + cc]);               // Ta' = -(E S Wq + Wp)
-      nbuf[cc] = -(Er * swp + Wq_[pc * LD + cc]) * vE1[cc];   // Tb' = -(E S Wp + Wq) E'
+      ta[cc] = -(Er * swq + Al[cc * LD + pc]);               // Ta' = -(E S Wq + Wp)
+      nbuf[cc] = -(Er * swp + Yl[cc * LD + pc]) * vE1[cc];   // Tb' = -(E S Wp + Wq) E'
       if (NP > 4 || (cc & 1)) RTD_FENCE();
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) tb[k] = nbuf[k];
     tt = tnew;
     RTD_BSTAMP(6);
-    __syncthreads();  // every lane is done with Y_l, A_l
+    __syncthreads();  // every lane is done with Wp, Wq
     park(nxt);
     cur = nxt;
     nxt = nn;
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_small_kernel(RtdDev d) {
   //      with C- = s - S C+  ->  (Bb - Ba S) C+ = br - Ba s.
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < NP; ++k) Wq_[pc * LD + k] = tb[k];  // S at its true row index
+  for (int k = 0; k < NP; ++k) Sb[pc * LD + k] = tb[k];  // S at its true row index
   vec[VS][pc] = tt;                                        // s
   vec[VD][j] = cur.bd;                                     // B-_L (the BDRF term reflects the downward beam solution)
   vec[VRT][j] = cur.vbd;                                   // ... and the downward thermal solution at tau_L
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_small_kernel(RtdDev d) {
       for (int cc = 0; cc < NP; ++cc) {  // am = Bb - Ba S,  bvec = br - Ba s
         double a = bb[cc];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) a -= ba[k] * Wq_[k * LD + cc];
+        for (int k = 0; k < NP; ++k) a -= ba[k] * Sb[k * LD + cc];
         am[cc] = a;
         RTD_FENCE();
       }
