@@ -360,7 +360,7 @@ def config_leg(name, golden, maker, kwargs, columns, window, device, passes, liv
     cw, nwin = plan.windows()
     fl = algorithmic_flops(nl, nq, nq, nl + 1)
     np_ = 4 if nq <= 8 else 8 if nq <= 16 else 16 if nq <= 32 else 32
-    names = {"eigen": f"rtd_eigen_kernel<{np_}, 2>",
+    names = {"eigen": "rtd_eigen_lane_kernel<4>" if np_ == 4 else f"rtd_eigen_kernel<{np_}, 2>",
              "bc": "rtd_bc_tile2_kernel" if np_ == 32 else "rtd_bc_mfma_kernel" if np_ == 16 else f"rtd_bc_small_kernel<{np_}>"}
     roof, ms = roofline_of(stage, fl, columns / nwin, names)
     roof["whole_path_tflops"] = fl["total"] * rate / 1e12
