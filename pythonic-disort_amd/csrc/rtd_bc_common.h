@@ -103,6 +103,24 @@ __device__ __forceinline__ double bcast_grp(double v) {
   else return bcast8<K>(v);
 }
 
+// v[c] -= f * (lane K of the caller's 8-lane group's v[c]) for c in [C0, C1), ONE half of a 16-lane DPP row per instruction: the DP
+// ALU's DPP form is the row broadcast, so lane K of the row serves the banks of its lower eight lanes (HI = false) and lane 8 + K
+// the upper eight (HI = true) -- two v_fmac_f64_dpp per register against four moves and an FMA.  The caller issues all first
+// halves, then all second halves: a DPP read needs two wait states after a VALU write of the same register, and the compiler's
+// hazard recogniser does not see writes made inside inline asm (build.py scans the generated ISA, tools/check_dpp_hazards.py).
+template <int K, bool HI, int C0, int C1, int N>
+struct FmacBank8 {
+  static __device__ __forceinline__ void run(double (&v)[N > 0 ? N : 1], const double f) {
+    if constexpr (C0 < C1) {
+      if constexpr (HI)
+        asm volatile("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xc" : "+v"(v[C0]) : "v"(f), "n"(8 + K));
+      else
+        asm volatile("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0x3" : "+v"(v[C0]) : "v"(f), "n"(K));
+      FmacBank8<K, HI, C0 + 1, C1, N>::run(v, f);
+    }
+  }
+};
+
 // Workspace layout per (c, m, l), l < L-1, inside d.Fws (4 NP^2 doubles per slot):
 //   [0, NP^2) Wp   [NP^2, 2NP^2) Wq   [2NP^2, 3NP^2) S   then rho_t, rho_b, s (NP each)
 template <int NP>
@@ -145,6 +163,15 @@ struct GjStep {
       const double piv = bcast_grp<NP, K>(am[K]);
       rp = fast_rcp(piv);
       f = isp ? 0.0 : am[K] * rp;
+      if constexpr (NP == 8) {
+        // (see FmacBank8: two bank-masked v_fmac_f64_dpp per register; all first halves, then all second halves)
+        FmacBank8<K, false, K + 1, NP, NP>::run(am, f);
+        FmacBank8<K, false, 0, NB, NB>::run(bm, f);
+        asm volatile("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0x3\n\ts_nop 1" : "+v"(bv) : "v"(f), "n"(K));
+        FmacBank8<K, true, K + 1, NP, NP>::run(am, f);
+        FmacBank8<K, true, 0, NB, NB>::run(bm, f);
+        asm volatile("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xc\n\ts_nop 1" : "+v"(bv) : "v"(f), "n"(8 + K));
+      } else {
       static_for<K + 1, NP>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         am[c] -= f * bcast_grp<NP, K>(am[c]);
@@ -154,6 +181,7 @@ struct GjStep {
         bm[c] -= f * bcast_grp<NP, K>(bm[c]);
       });
       bv -= f * bcast_grp<NP, K>(bv);
+      }
     } else {
       const unsigned long long bal = __ballot(key == kmax);
       const unsigned long long bits = NP == 64 ? bal : (bal >> (grp * NP)) & ((1ull << (NP & 63)) - 1);

@@ -204,10 +204,12 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
 // remain.  One thread per (point, stream): a workgroup takes FT_T consecutive points of one column, so that every mode's
 // slice is one contiguous read; no layer search, no LDS staging of the modes.  Same arithmetic, in the same order, as the
 // corresponding part of rtd_eval_kernel (which stays the kernel of every other evaluation).
-constexpr int FT_T = 8;
+// points of a column per workgroup: 8 at 32 / 64 streams (one / two (point, stream) pairs per thread); at 8 / 16 streams 32 / 16 of
+// them, so that the 9 interfaces of a cfg3 column are one workgroup, not a full one and a nearly empty one
+__host__ __device__ constexpr int ft_points(int np) { return np >= 16 ? 8 : 256 / (2 * np); }
 template <int NP>
 __global__ __launch_bounds__(EVAL_THREADS) void rtd_fourier_kernel(RtdDev d, RtdEval ev) {
-  constexpr int Q = 2 * NP;
+  constexpr int Q = 2 * NP, FT_T = ft_points(NP);
   static_assert(FT_T * Q <= 2 * EVAL_THREADS, "at most two (point, stream) pairs per thread");
   const int M = d.M, L = d.L, N = d.N, Qr = 2 * N;
   // a chain of this window went to the row-per-lane kernels, which leave no u^m: the evaluation kernel takes the window
@@ -321,7 +323,8 @@ __global__ void rtd_export_kernel(RtdDev d, int col, double* GC, double* K, doub
 
 void rtd_launch_eval(const RtdDev& d, const RtdEval& e, hipStream_t s) {
   if (e.um_in != nullptr && e.antider == 0 && rtd_bc_fuses_eval(d)) {  // u^m is there already: sums only
-    const dim3 g((unsigned)((long)d.C * ((e.ntau + FT_T - 1) / FT_T)));
+    const int ftt = ft_points(d.NP);
+    const dim3 g((unsigned)((long)d.C * ((e.ntau + ftt - 1) / ftt)));
     if (d.NP == 4) hipLaunchKernelGGL(rtd_fourier_kernel<4>, g, dim3(EVAL_THREADS), 0, s, d, e);
     else if (d.NP == 8) hipLaunchKernelGGL(rtd_fourier_kernel<8>, g, dim3(EVAL_THREADS), 0, s, d, e);
     else if (d.NP == 16) hipLaunchKernelGGL(rtd_fourier_kernel<16>, g, dim3(EVAL_THREADS), 0, s, d, e);
