@@ -121,15 +121,6 @@ struct FmacBank8 {
   }
 };
 
-// acc += (lane R of the caller's 8-lane group's src) * mult: the same two bank-masked instructions with a separate accumulator.
-// The DPP source is never written by inline asm (operands come from loads / compiler-visible arithmetic): no hazard to scan for,
-// and the statements are not volatile (the scheduler may interleave them).
-template <int R>
-__device__ __forceinline__ void fma_bcast8(double& acc, const double src, const double mult) {
-  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0x3" : "+v"(acc) : "v"(src), "v"(mult), "n"(R));
-  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xc" : "+v"(acc) : "v"(src), "v"(mult), "n"(8 + R));
-}
-
 // Workspace layout per (c, m, l), l < L-1, inside d.Fws (4 NP^2 doubles per slot):
 //   [0, NP^2) Wp   [NP^2, 2NP^2) Wq   [2NP^2, 3NP^2) S   then rho_t, rho_b, s (NP each)
 template <int NP>

@@ -168,49 +168,26 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_small_kernel(RtdDev d) {
       __syncthreads();
       // rho_t/b = 1/4 [V^-1 (r_up + r_dn) +- U^-1 (r_up - r_dn)],  V^-1[j][i] = T_i A[i][j],  U^-1[j][i] = -k_j T_i Y[i][j]
 #pragma unroll
-      for (int i = 0; i < NP; ++i) {  // (column j of A_l, Y_l: the lane's own registers)
-        const double a = cur.a[i] * vec[VS][i], b = -cur.k * cur.y[i] * vec[VD][i];
+      for (int i = 0; i < NP; ++i) {
+        const double a = Al[i * LD + j] * vec[VS][i], b = -cur.k * Yl[i * LD + j] * vec[VD][i];
         rt += a + b;
         rb += a - b;
       }
       rt *= 0.25;
       rb *= 0.25;
       const double rk1 = fast_rcp(nxt.k);
-      if constexpr (NP == 8) {
-        // A_l[i][r] is element i of the column that lane r holds: it reaches the FMA as a DPP row broadcast (fma_bcast8: two
-        // bank-masked v_fmac_f64_dpp) instead of an LDS read -- 256 vector instructions against 64 ds_read2_b64 + 128 FMAs, and
-        // nothing on the LDS pipe, which eight wavefronts per CU share (a stage's products were 4 200 of its 14 500 cycles)
-        double vv[NP], uu[NP];
 #pragma unroll
-        for (int r = 0; r < NP; ++r) vv[r] = uu[r] = 0.0;
-        static_for<0, NP>([&](auto rc) {
-          constexpr int r = decltype(rc)::value;
+      for (int r = 0; r < NP; ++r) {
+        double vv = 0.0, uu = 0.0;
 #pragma unroll
-          for (int i = 0; i < NP; ++i) {
-            fma_bcast8<r>(vv[r], cur.a[i], nxt.y[i]);
-            fma_bcast8<r>(uu[r], cur.y[i], nxt.a[i]);
-          }
-        });
-#pragma unroll
-        for (int r = 0; r < NP; ++r) {
-          const double us = uu[r] * (vk0[r] * rk1);
-          Al[j * LD + r] = 0.5 * (vv[r] + us);  // Wp[r][j], transposed in place (A_l, Y_l are not read from LDS in this loop any more)
-          Yl[j * LD + r] = 0.5 * (vv[r] - us);  // Wq[r][j]
+        for (int i = 0; i < NP; ++i) {
+          vv += Al[i * LD + r] * nxt.y[i];
+          uu += Yl[i * LD + r] * nxt.a[i];
         }
-      } else {
-#pragma unroll
-        for (int r = 0; r < NP; ++r) {
-          double vv = 0.0, uu = 0.0;
-#pragma unroll
-          for (int i = 0; i < NP; ++i) {
-            vv += Al[i * LD + r] * nxt.y[i];
-            uu += Yl[i * LD + r] * nxt.a[i];
-          }
-          uu *= vk0[r] * rk1;
-          Al[j * LD + r] = 0.5 * (vv + uu);  // Wp[r][j]  (every lane has read column r: LDS operations of a wavefront are in order)
-          Yl[j * LD + r] = 0.5 * (vv - uu);  // Wq[r][j]
-          if (r & 1) RTD_FENCE();  // (keeps the scheduler from hoisting the LDS reads of every r at once: registers)
-        }
+        uu *= vk0[r] * rk1;
+        Al[j * LD + r] = 0.5 * (vv + uu);  // Wp[r][j]  (every lane has read column r: LDS operations of a wavefront are in order)
+        Yl[j * LD + r] = 0.5 * (vv - uu);  // Wq[r][j]
+        if (NP > 4 || (r & 1)) RTD_FENCE();  // (keeps the scheduler from hoisting the LDS reads of every r at once: registers)
       }
     }
     pc = -1;
@@ -245,42 +222,17 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_small_kernel(RtdDev d) {
     for (int k = 0; k < NP; ++k) srb += tb[k] * vec[VRB][k];  // (S rho_b)[pc]
     const double tnew = vec[VRT][pc] - Er * (tt - srb);
     double nbuf[NP];
-    if constexpr (NP == 8) {
-      // (S Wq)[pc][cc] = sum_k S[pc][k] Wq[k][cc]: Wq[k][cc] is element k of the column that lane cc holds -- its own column back from
-      // LDS (one row of the transposed buffer), then DPP row broadcasts as above
-      double wq[NP], wp[NP], swq[NP], swp[NP];
+#pragma unroll
+    for (int cc = 0; cc < NP; ++cc) {
+      double swq = 0.0, swp = 0.0;
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
-        wq[k] = Yl[j * LD + k];
-        wp[k] = Al[j * LD + k];
-        swq[k] = swp[k] = 0.0;
+        swq += tb[k] * Yl[cc * LD + k];  // Wq[k][cc]
+        swp += tb[k] * Al[cc * LD + k];  // Wp[k][cc]
       }
-      static_for<0, NP>([&](auto cc_) {
-        constexpr int cc = decltype(cc_)::value;
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-          fma_bcast8<cc>(swq[cc], wq[k], tb[k]);
-          fma_bcast8<cc>(swp[cc], wp[k], tb[k]);
-        }
-      });
-#pragma unroll
-      for (int cc = 0; cc < NP; ++cc) {
-        ta[cc] = -(Er * swq[cc] + Al[cc * LD + pc]);               // Ta' = -(E S Wq + Wp)
-        nbuf[cc] = -(Er * swp[cc] + Yl[cc * LD + pc]) * vE1[cc];   // Tb' = -(E S Wp + Wq) E'
-      }
-    } else {
-#pragma unroll
-      for (int cc = 0; cc < NP; ++cc) {
-        double swq = 0.0, swp = 0.0;
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-          swq += tb[k] * Yl[cc * LD + k];  // Wq[k][cc]
-          swp += tb[k] * Al[cc * LD + k];  // Wp[k][cc]
-        }
-        ta[cc] = -(Er * swq + Al[cc * LD + pc]);               // Ta' = -(E S Wq + Wp)
-        nbuf[cc] = -(Er * swp + Yl[cc * LD + pc]) * vE1[cc];   // Tb' = -(E S Wp + Wq) E'
-        if (cc & 1) RTD_FENCE();
-      }
+      ta[cc] = -(Er * swq + Al[cc * LD + pc]);               // Ta' = -(E S Wq + Wp)
+      nbuf[cc] = -(Er * swp + Yl[cc * LD + pc]) * vE1[cc];   // Tb' = -(E S Wp + Wq) E'
+      if (NP > 4 || (cc & 1)) RTD_FENCE();
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) tb[k] = nbuf[k];
