@@ -747,14 +747,17 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
     const Col el = load_col(Ek + l * NP, col);
     Col cp;
     {
+      // (the three operand matrices of the step are requested together: one memory latency per step, not three; 96 of the 256
+      //  registers, and little else is live in this loop)
       const Mat al = load_d(Am + (long)l * NN, kq, col);
-      const Col t1 = col_dotT<T>(al, w1);
       const Mat yl = load_d(Ym + (long)l * NN, kq, col);
+      const Mat h = load_d(ws + Ws<NP>::S, kq, col);
+      __builtin_amdgcn_sched_barrier(0);
+      const Col t1 = col_dotT<T>(al, w1);
       const Col t2 = col_dotT<T>(yl, w2);
 #pragma unroll
       for (int J = 0; J < T; ++J) cp.c[J] = rbv.c[J] + 0.5 * (t1.c[J] + kl.c[J] * t2.c[J]);
       {
-        const Mat h = load_d(ws + Ws<NP>::S, kq, col);
         const Col hc = col_dotT<T>(h, col_to_rowT<T>(cp, rowbase, kq));
 #pragma unroll
         for (int J = 0; J < T; ++J) cminus.c[J] = sl.c[J] - hc.c[J];
