@@ -294,6 +294,8 @@ enum {
  *   RTD_BC_TILED          32 streams through the tiled kernel's T = 1 instance instead of rtd_bc_mfma_kernel
  *   RTD_BC_TILE_V1        64 streams through rtd_bc_tile_kernel<2> (one wavefront per SIMD, rounds 2-3) instead of the lean
  *                         two-wavefronts-per-SIMD kernel of rtd_bc_tile2.hip (round 4)
+ *   RTD_BC_WIDE_V1        66 ... 128 streams through the row-per-lane kernels (one wavefront per chain, rounds 1-3) instead of the
+ *                         four-wavefronts-per-chain kernels of rtd_bc_wide.hip (round 4)
  *   RTD_EIG_MFMA          eigen stage with its assembly GEMMs on the matrix cores (measured slower; a tested variant)
  *   RTD_EIG_SMALL_V1      2 ... 8 streams: eigen stage through the four-lanes-per-problem instance of the general eigen kernel
  *                         instead of the one-lane-per-problem kernel of rtd_eig_small.hip

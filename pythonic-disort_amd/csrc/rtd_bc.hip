@@ -2145,7 +2145,16 @@ void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part) {
   switch (d.NP) {
     RTD_BC_SMALL_CASE(4)
     RTD_BC_SMALL_CASE(8)
-    RTD_BC_CASE(64)  // 66 ... 128 streams: the row-per-lane kernels, one chain per wavefront
+    case 64: {  // 66 ... 128 streams: four wavefronts per chain (rtd_bc_wide.hip) unless RTD_BC_WIDE_V1 asks for the row-per-lane kernels
+      static const bool wide_v1 = getenv("RTD_BC_WIDE_V1") != nullptr;
+      if (!wide_v1) {
+        rtd_launch_bc_wide(d, s, part);
+        break;
+      }
+      if (part == 0 && nif > 0) hipLaunchKernelGGL(rtd_iface_kernel<64>, gi, dim3(64), 0, s, d, none);
+      if (part == 1) hipLaunchKernelGGL(rtd_sweep_kernel<64>, gs, dim3(64), 0, s, d, none);
+      break;
+    }
     case 16:
       if (tiled16) {
         RTD_BC_TILED_CASE(16, 1)

@@ -1,0 +1,454 @@
+// rtd_bc_wide.hip -- boundary-condition solve at 66 ... 128 streams (NP = 64 per hemisphere), round 4.
+//
+// The same structured block elimination as rtd_bc.hip (see its header: _solve_for_coeffs.py:8-390 of the reference), for
+// the stream counts whose 64 x 64 blocks fit no wavefront's registers.  Until round 4 these ran on the row-per-lane
+// kernels of the small stream counts instantiated at NP = 64: one wavefront per chain, its 64 x 129 carry rows in LDS
+// (two wavefronts per CU), every FMA of the elimination fed by two LDS reads -- 40 ms per 16 columns x 64 modes x 50 layers.
+//
+// Here a chain is a WORKGROUP of four wavefronts.  Lane = row of the carry system in all four; wavefront q keeps the
+// columns 4 i + q (i < 16) of the row's Ta and Tb parts in registers, so a pivot step costs every wavefront the same
+// work whatever the column.  What crosses wavefronts in the elimination is ONE column per pivot step (64 doubles through
+// LDS, double buffered: one barrier per step); the pivot row never moves between wavefronts -- each wavefront has its
+// own slice of it in the pivot lane's registers and broadcasts it with v_readlane (SGPR operands of the FMAs).  The
+// products with wave-uniform operands -- S Wq, S Wp of the carry, A^T Y' and Y^T A' of the interface operators -- are
+// plain FMAs whose uniform factor comes from scalar loads (constant address space: s_load), one FMA instruction per
+// 64 multiply-adds like an MFMA (FP64 vector and matrix instructions share the DP ALUs on this chip) with no operand
+// staging at all.  The interface operators are stored TRANSPOSED (lanes = rows contiguous): coalesced stores here,
+// contiguous scalar loads in the carry, coalesced loads in the backward sweep.
+//
+// Pivoting: partial pivoting on float keys exactly as the row-per-lane kernels (rtd_bc_common.h: GjStep); pivot rows are
+// left unscaled and scaled once at the end of an elimination (the scaling commutes with the later eliminations of that
+// row), which keeps the pivot lane on the same FMA as everyone else (f = 0) without the inexact 1 - 1/p form.
+#include <cstdlib>
+#include <type_traits>
+
+#include "rtd_device.h"
+
+namespace {
+
+#include "rtd_bc_common.h"
+
+constexpr int NP = 64, Q = 128, LDS_LD = 65;
+using W = Ws<NP>;
+
+// loads through the constant address space: a wave-uniform address becomes an s_load whatever the alias analysis thinks
+// (only for memory written by EARLIER kernels of the stream)
+typedef const double __attribute__((address_space(4))) kdouble;
+__device__ __forceinline__ kdouble* as_k(const double* p) { return (kdouble*)(p); }
+
+__device__ __forceinline__ double readlane_f64(const double v, const int lane) {  // lane: wave-uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Interface operators: per (c, m, l < L-1) the transposes of Wp, Wq = (A^T Y' +- k Y^T A' / k') / 2 and rho_t, rho_b.
+// Two wavefronts (blocks) per interface, 32 columns each; lane = row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64, 3) void rtd_iface_wide_kernel(RtdDev d) {
+  const int lane = threadIdx.x;
+  const int h = blockIdx.x & 1;
+  const long pid = blockIdx.x >> 1;
+  const int Lm1 = d.L - 1;
+  const int l = (int)(pid % Lm1);
+  const long cm = pid / Lm1;
+  const int m = (int)(cm % d.M), c = (int)(cm / d.M);
+  const long p0 = cm * d.L + l, p1 = p0 + 1;
+  const double* A0 = d.Am + p0 * NP * NP;
+  const double* Y0 = d.Ym + p0 * NP * NP;
+#ifdef RTD_WIDE_X_SAMEK
+  kdouble* Y1 = as_k(d.Ym + 32 * h);
+  kdouble* A1 = as_k(d.Am + 32 * h);
+#else
+  kdouble* Y1 = as_k(d.Ym + p1 * NP * NP + 32 * h);
+  kdouble* A1 = as_k(d.Am + p1 * NP * NP + 32 * h);
+#endif
+  double* ws = d.Fws + (cm * Lm1 + l) * W::SLOT;
+  // particular-solution jump r_l at the interface (:184-205, :242-245) and rho = G_l^-1 r_l:
+  //   rho_t/b = 1/4 [ V^-1 (r_up + r_dn) +- U^-1 (r_up - r_dn) ],  V^-1[j][i] = T_i A[i][j],  U^-1[j][i] = -k_j T_i Y[i][j]
+  // Lane i forms T_i (r_up +- r_dn)[i] once (coalesced loads); the sums over i ride along the main loop below, whose rows of
+  // A_l and Y_l they share (the row-per-lane kernel walked i with dependent loads: one memory latency per row).
+  double rsum = 0.0, rdif = 0.0;
+  if (h == 0) {
+    const double* ts0 = d.taus0 + (long)c * (d.L + 1);
+    const double tb = ts0[l + 1];
+    const int mg = d.m0 + d.mstep * m;
+    double ru = 0.0, rd = 0.0;
+    if (d.beam) {
+      const double att = exp(-tb / d.mu0[c]);
+      ru = (d.Bv[p1 * Q + lane] - d.Bv[p0 * Q + lane]) * att;
+      rd = (d.Bv[p1 * Q + NP + lane] - d.Bv[p0 * Q + NP + lane]) * att;
+    }
+    if (d.Ns > 0 && mg == 0) {
+      const double* dq0 = d.dq + ((long)c * d.L + l) * d.Ns * Q;
+      const double* dq1 = dq0 + (long)d.Ns * Q;
+      double tp = 1.0;
+      for (int q = 0; q < d.Ns; ++q) {
+        ru += (dq1[q * Q + lane] - dq0[q * Q + lane]) * tp;
+        rd += (dq1[q * Q + NP + lane] - dq0[q * Q + NP + lane]) * tp;
+        tp *= tb;
+      }
+    }
+    const double Ti = d.T[lane];
+    rsum = Ti * (ru + rd);
+    rdif = Ti * (ru - rd);
+  }
+  double vv[32], uu[32], ra = 0.0, ry = 0.0;
+#pragma unroll
+  for (int cc = 0; cc < 32; ++cc) vv[cc] = uu[cc] = 0.0;
+  // the lane's own column of A_l and Y_l four rows ahead (the loads of a chunk are in flight while the previous one is used; eight
+  // rows ahead cost 48 more registers and the third wavefront per SIMD: 7.9 against 5.1 ms per 51 200 interfaces)
+  constexpr int CH = 4;
+  double a[CH], y[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) {
+    a[e] = A0[e * NP + lane];
+    y[e] = Y0[e * NP + lane];
+  }
+#pragma unroll 1
+  for (int i0 = 0; i0 < NP; i0 += CH) {
+    double an[CH], yn[CH];
+    const int in = i0 + CH < NP ? i0 + CH : i0;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      an[e] = A0[(in + e) * NP + lane];
+      yn[e] = Y0[(in + e) * NP + lane];
+    }
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+#pragma unroll
+      for (int cc = 0; cc < 32; ++cc) vv[cc] = fma(a[e], Y1[(i0 + e) * NP + cc], vv[cc]);
+#pragma unroll
+      for (int cc = 0; cc < 32; ++cc) uu[cc] = fma(y[e], A1[(i0 + e) * NP + cc], uu[cc]);
+      ra = fma(a[e], readlane_f64(rsum, i0 + e), ra);
+      ry = fma(y[e], readlane_f64(rdif, i0 + e), ry);
+    }
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      a[e] = an[e];
+      y[e] = yn[e];
+    }
+  }
+  const double k0 = d.kk[p0 * NP + lane];
+  {
+    kdouble* k1 = as_k(d.kk + p1 * NP + 32 * h);
+#pragma unroll
+    for (int cc = 0; cc < 32; ++cc) {
+      const double u = uu[cc] * (k0 * fast_rcp(k1[cc]));
+      ws[W::WP + (32 * h + cc) * NP + lane] = 0.5 * (vv[cc] + u);
+      ws[W::WQ + (32 * h + cc) * NP + lane] = 0.5 * (vv[cc] - u);
+    }
+  }
+  if (h == 0) {
+    const double bb = -k0 * ry;
+    ws[W::RT + lane] = 0.25 * (ra + bb);
+    ws[W::RB + lane] = 0.25 * (ra - bb);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gauss-Jordan with partial pivoting on the rows [Ta | Tb | t] of a chain, four wavefronts (see the header).  On exit the
+// lane that owned pivot column `pc` holds its slice of row pc of Ta^-1 Tb in tb[] and (Ta^-1 t)[pc] in tt.
+// ------------------------------------------------------------------------------------------------
+template <bool WITH_TB>
+__device__ __forceinline__ void gj_wide(double (&ta)[16], double (&tb)[16], double& tt, int& pc, const int lane, const int q,
+                                        double (*sCol)[NP], int* sFound, const double* touch_at, double (&touched)[2]) {
+  pc = -1;
+  double myrp = 1.0;
+  static_for<0, 16>([&](auto kc) {
+    constexpr int kk = decltype(kc)::value;
+#pragma unroll 1
+    for (int qo = 0; qo < 4; ++qo) {  // pivot column K = 4 kk + qo: register kk of wavefront qo
+      const int buf = qo & 1;
+      if constexpr (kk == 12) {
+        // the carry that follows reads Wq, Wp of this interface with scalar loads: bring their 512 cache lines into the L2 now
+        // (two per thread, vector loads; see rtd_iface_wide_kernel)
+        if (touch_at != nullptr && qo == 0) {
+          touched[0] = touch_at[threadIdx.x * 16];
+          touched[1] = touch_at[(threadIdx.x + 256) * 16];
+        }
+      }
+      if (q == qo) {
+        const double mine = ta[kk];
+        const float key = (pc < 0) ? fabsf((float)mine) : -1.0f;
+        const float kmax = group_max_key<NP>(key);
+        const unsigned long long bal = __ballot(key == kmax);
+        sCol[buf][lane] = mine;
+        if (lane == 0) sFound[buf] = __ffsll((long long)bal) - 1;  // -1: a chain that has gone NaN
+      }
+      __syncthreads();
+      const double mine = sCol[buf][lane];
+      const int found = __builtin_amdgcn_readfirstlane(sFound[buf]);
+      const int src = found < 0 ? 0 : found;
+      const bool isp = lane == found;
+      const double rp = fast_rcp(sCol[buf][src]);
+      const double f = isp ? 0.0 : mine * rp;
+      if (isp) {
+        pc = 4 * kk + qo;
+        myrp = rp;
+      }
+#pragma unroll
+      for (int i = kk; i < 16; ++i) ta[i] = fma(-f, readlane_f64(ta[i], src), ta[i]);  // (columns up to K are dead)
+      if constexpr (WITH_TB) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tb[i] = fma(-f, readlane_f64(tb[i], src), tb[i]);
+      }
+      tt = fma(-f, readlane_f64(tt, src), tt);
+    }
+  });
+  if constexpr (WITH_TB) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tb[i] *= myrp;
+  }
+  tt *= myrp;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sweep kernel: per (c, m): forward carry recursion over the layers, bottom boundary, backward sweep.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void rtd_sweep_wide_kernel(RtdDev d) {
+  __shared__ double sS[NP * LDS_LD];   // S at its true row index
+  __shared__ double sT[NP * LDS_LD];   // bottom boundary: the rows of Ba
+  __shared__ double sCol[2][NP];
+  __shared__ int sFound[2];
+  __shared__ double sV[3][NP];
+  __shared__ double sRed[2][4][NP];
+  const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane;
+  const long cm = blockIdx.x;
+  const int m = (int)(cm % d.M), c = (int)(cm / d.M);
+  const int L = d.L, Lm1 = L - 1;
+  const double* Ym = d.Ym + cm * L * NP * NP;
+  const double* Am = d.Am + cm * L * NP * NP;
+  const double* kk = d.kk + cm * L * NP;
+  const double* Ek = d.Ek + cm * L * NP;
+  const double* Bv = d.Bv + cm * L * Q;
+  const double* ts0 = d.taus0 + (long)c * (L + 1);
+  const double* dq = d.dq + (long)c * L * d.Ns * Q;
+  double* wsb = d.Fws + cm * Lm1 * W::SLOT;
+  double* coef = d.coef + cm * L * Q;
+  const double rTj = 1.0 / d.T[j];
+  const int mg = d.m0 + d.mstep * m;
+  const bool iso = d.Ns > 0 && mg == 0;
+  const bool beam = d.beam != 0;
+  const double mu0 = beam ? d.mu0[c] : 1.0;
+  auto vpoly = [&](int l, double t, int idx) {
+    double a = 0.0, tp = 1.0;
+    for (int qq = 0; qq < d.Ns; ++qq) {
+      a += dq[((long)l * d.Ns + qq) * Q + idx] * tp;
+      tp *= t;
+    }
+    return a;
+  };
+
+  // carry rows Ta C- + Tb C+ = t, top boundary (:161-179, :284-285): Ta = Gm_0, Tb = Gp_0 E_0
+  double ta[16], tb[16], tt;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = 4 * i + q;
+    const double yv = Ym[j * NP + k], av = Am[j * NP + k] / kk[k];
+    ta[i] = (yv + av) * rTj;
+    tb[i] = (yv - av) * rTj * Ek[k];
+  }
+  tt = d.bneg[cm * NP + j];
+  if (beam) tt -= Bv[NP + j];
+  if (iso) tt -= dq[NP + j];
+
+  int pc = -1;
+  for (int l = 0; l < L; ++l) {
+#ifndef RTD_WIDE_X_NO_GJ
+    double touched[2] = {0.0, 0.0};
+    gj_wide<true>(ta, tb, tt, pc, lane, q, sCol, sFound, l < Lm1 ? wsb + (long)l * W::SLOT : nullptr, touched);
+#endif
+    if (pc < 0) pc = j;  // (a chain that has gone NaN finds no pivots: keep the stores inside the chain's own rows)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sS[pc * LDS_LD + 4 * i + q] = tb[i];
+    if (l == Lm1) break;
+    double* ws = wsb + (long)l * W::SLOT;
+    kdouble* wk = as_k(ws);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ws[W::S + (4 * i + q) * NP + pc] = tb[i];  // S^T for the backward sweep
+    if (q == 0) ws[W::SV + pc] = tt;
+    __syncthreads();
+    double srow[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) srow[k] = sS[pc * LDS_LD + k];
+    double srb = 0.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) srb = fma(srow[k], wk[W::RB + k], srb);  // (S rho_b)[pc]
+    const double Er = Ek[l * NP + pc];
+    const double tnew = ws[W::RT + pc] - Er * (tt - srb);
+    kdouble* e1 = as_k(Ek + (l + 1) * NP);
+#ifndef RTD_WIDE_X_NO_CARRY
+    // (S has left ta, tb for LDS: the row pc of Wp, Wq -- this lane's own loads -- waits there, all 32 loads in flight at once)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      ta[i] = ws[W::WP + (4 * i + q) * NP + pc];
+      tb[i] = ws[W::WQ + (4 * i + q) * NP + pc];
+    }
+#pragma unroll 2
+    for (int i = 0; i < 16; ++i) {
+      const int cc = 4 * i + q;
+      kdouble* wq = wk + W::WQ + cc * NP;  // column cc of Wq, Wp: rows of the stored transposes
+      kdouble* wp = wk + W::WP + cc * NP;
+      double swq0 = 0.0, swq1 = 0.0, swp0 = 0.0, swp1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NP; k += 2) {
+        swq0 = fma(srow[k], wq[k], swq0);
+        swq1 = fma(srow[k + 1], wq[k + 1], swq1);
+        swp0 = fma(srow[k], wp[k], swp0);
+        swp1 = fma(srow[k + 1], wp[k + 1], swp1);
+      }
+      ta[i] = -(Er * (swq0 + swq1) + ta[i]);           // Ta' = -(E S Wq + Wp)
+      tb[i] = -(Er * (swp0 + swp1) + tb[i]) * e1[cc];  // Tb' = -(E S Wp + Wq) E'
+    }
+#endif
+    tt = tnew;
+    if (touched[0] == 1.2345e-300 && touched[1] == 1.2345e-300) tt += touched[0];  // (never: keeps the touching loads alive)
+  }
+
+  // ---- bottom boundary (up-streams at tau_L) (:208-232, :248-254, :288-293):  Ba C- + Bb C+ = br,
+  //      with C- = s - S C+  ->  (Bb - Ba S) C+ = br - Ba s   (see rtd_sweep_kernel)
+  double* v0 = sV[0];
+  double* v1 = sV[1];
+  double* v2 = sV[2];
+  if (q == 0) v0[pc] = tt;  // s
+  const double s_pc = tt;
+  {
+    const int l = Lm1;
+    const double* ymL = Ym + (long)l * NP * NP;
+    const double* amL = Am + (long)l * NP * NP;
+    kdouble* ymk = as_k(ymL);
+    kdouble* amk = as_k(amL);
+    const double* kl = kk + (long)l * NP;
+    const double att = beam ? exp(-ts0[L] / mu0) : 0.0;
+    double pa[16], qa[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      pa[i] = ymL[j * NP + 4 * i + q] * rTj;
+      qa[i] = amL[j * NP + 4 * i + q] * rTj;
+    }
+    double br = d.bpos[cm * NP + j];
+    if (mg < d.NBDRF) {
+      const double delta = (mg == 0) ? 2.0 : 1.0;
+      const double* qt = d.bdrfq + (((long)c * d.NBDRF + mg) * NP + j) * NP;
+      double rbm = 0.0, rvm = 0.0;
+      for (int j2 = 0; j2 < NP; ++j2) {
+        const double Rij = delta * qt[j2] * d.mu[j2] * d.w[j2] / d.T[j2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          pa[i] -= Rij * ymk[j2 * NP + 4 * i + q];
+          qa[i] += Rij * amk[j2 * NP + 4 * i + q];
+        }
+        const double Rraw = Rij * d.T[j2];
+        if (beam) rbm += Rraw * Bv[l * Q + NP + j2];
+        if (iso) rvm += Rraw * vpoly(l, ts0[L], NP + j2);
+      }
+      if (beam) {
+        const double Xs = mu0 * d.I0[c] / M_PI * d.bdrfq0[((long)c * d.NBDRF + mg) * NP + j];
+        br += (Xs + rbm - Bv[l * Q + j]) * att;
+      }
+      if (iso) br += rvm - vpoly(l, ts0[L], j);
+    } else {
+      if (beam) br -= Bv[l * Q + j] * att;
+      if (iso) br -= vpoly(l, ts0[L], j);
+    }
+    double bb[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = 4 * i + q;
+      const double qk = qa[i] / kl[k];
+      sT[j * LDS_LD + k] = (pa[i] - qk) * Ek[l * NP + k];  // Ba (with the scaling of C-)
+      bb[i] = pa[i] + qk;
+    }
+    __syncthreads();  // S, s and Ba complete
+    double bvec = br;
+    {
+      double barow[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) barow[k] = sT[j * LDS_LD + k];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) bvec = fma(-barow[k], v0[k], bvec);
+      // am = Bb - Ba S into ta (this wavefront's columns)
+#pragma unroll 2
+      for (int i = 0; i < 16; ++i) {
+        const int cc = 4 * i + q;
+        double a0 = bb[i], a1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NP; k += 2) {
+          a0 = fma(-barow[k], sS[k * LDS_LD + cc], a0);
+          a1 = fma(-barow[k + 1], sS[(k + 1) * LDS_LD + cc], a1);
+        }
+        ta[i] = a0 + a1;
+      }
+    }
+    int pc2 = -1;
+    double touched[2] = {0.0, 0.0};
+    gj_wide<false>(ta, tb, bvec, pc2, lane, q, sCol, sFound, nullptr, touched);
+    if (pc2 < 0) pc2 = j;
+    if (q == 0) v1[pc2] = bvec;  // C+
+    __syncthreads();
+    if (q == 0) {
+      double cmin = s_pc;  // C-[pc] = s[pc] - S[pc][:] C+
+#pragma unroll 8
+      for (int k = 0; k < NP; ++k) cmin = fma(-sS[pc * LDS_LD + k], v1[k], cmin);
+      v2[pc] = cmin;
+    }
+    __syncthreads();
+    if (q == 0) {
+      coef[(long)l * Q + j] = v2[j];
+      coef[(long)l * Q + NP + j] = v1[j];
+      // singular system (the reference's solve_banded / solve raises LinAlgError, :326-333, :383)
+      if (!(fabs(v2[j]) + fabs(v1[j]) < 1e300)) rtd_raise(d, RTD_ST_BC, mg, c);
+    }
+  }
+  // ---- backward sweep: C+_l = Wq C-' + Wp E' C+' + rho_b ;  C-_l = s - S C+_l.  Every wavefront keeps both vectors
+  //      lane-wise; wavefront q sums over the columns [16 q, 16 q + 16) (readlane broadcasts), partial sums meet in LDS.
+  double cmj = v2[j], cpj = v1[j];
+  const int k0 = 16 * q;
+  for (int l = Lm1 - 1; l >= 0; --l) {
+    const double* ws = wsb + (long)l * W::SLOT;
+    double wq[16], wp[16], st[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      wq[i] = ws[W::WQ + (k0 + i) * NP + j];
+      wp[i] = ws[W::WP + (k0 + i) * NP + j];
+      st[i] = ws[W::S + (k0 + i) * NP + j];
+    }
+    const double rb = ws[W::RB + j], sv = ws[W::SV + j];
+    const double ecp = Ek[(l + 1) * NP + j] * cpj;  // E'_j C+'_j
+    double part = 0.0;
+    static_for<0, 16>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      // (k0 + i is wave-uniform but not a constant: v_readlane with an SGPR lane index)
+      part = fma(wq[i], readlane_f64(cmj, k0 + i), part);
+      part = fma(wp[i], readlane_f64(ecp, k0 + i), part);
+    });
+    // (one buffer per reduction is enough: a wavefront writes a buffer again only after a barrier that every reader of its
+    //  previous contents has reached)
+    sRed[0][q][j] = part;
+    __syncthreads();
+    const double cp = rb + ((sRed[0][0][j] + sRed[0][1][j]) + (sRed[0][2][j] + sRed[0][3][j]));
+    double part2 = 0.0;
+    static_for<0, 16>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      part2 = fma(st[i], readlane_f64(cp, k0 + i), part2);
+    });
+    sRed[1][q][j] = part2;
+    __syncthreads();
+    const double cmin = sv - ((sRed[1][0][j] + sRed[1][1][j]) + (sRed[1][2][j] + sRed[1][3][j]));
+    cmj = cmin;
+    cpj = cp;
+    if (q == 0) {
+      coef[(long)l * Q + j] = cmin;
+      coef[(long)l * Q + NP + j] = cp;
+    }
+  }
+}
+
+}  // namespace
+
+void rtd_launch_bc_wide(const RtdDev& d, hipStream_t s, int part) {
+  const long nif = (long)d.C * d.M * (d.L - 1);
+  if (part == 0 && nif > 0) hipLaunchKernelGGL(rtd_iface_wide_kernel, dim3((unsigned)(2 * nif)), dim3(64), 0, s, d);
+  if (part == 1) hipLaunchKernelGGL(rtd_sweep_wide_kernel, dim3((unsigned)((long)d.C * d.M)), dim3(256), 0, s, d);
+}

@@ -112,6 +112,7 @@ void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part);  // the fused eig
 void rtd_launch_bc(const RtdDev& d, hipStream_t s, int part);   // 0 iface, 1 sweep
 void rtd_launch_bc_small(const RtdDev& d, hipStream_t s);  // rtd_bc_small.hip: the fused kernel of the 2 ... 16-stream path
 void rtd_launch_bc_tile2(const RtdDev& d, hipStream_t s);  // rtd_bc_tile2.hip: the lean 64-stream kernel (two wavefronts per SIMD)
+void rtd_launch_bc_wide(const RtdDev& d, hipStream_t s, int part);  // rtd_bc_wide.hip: 66 ... 128 streams, four wavefronts per chain (0 iface, 1 sweep)
 bool rtd_small_split();  // RTD_SMALL_SPLIT is set: NP <= 8 takes the separate interface / sweep / evaluation kernels
 bool rtd_bc_fuses_eval(const RtdDev& d);  // the boundary-condition kernel chosen for d can fill d.um
 void rtd_launch_eval(const RtdDev& d, const RtdEval& e, hipStream_t s);

@@ -164,6 +164,10 @@ __device__ __forceinline__ double bcast_lane(double v) {
     lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xF, 0xF, true);  // row_newbcast:K; bound_ctrl + full masks: no `old` operand, no copy
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
+  } else if constexpr (NP == 64) {
+    // the group is the wavefront: lane K by v_readlane (an SGPR pair, used as such by the FMA that follows) -- no LDS crossbar.
+    // (ds_bpermute here made a 128-stream Cholesky factorisation 170 k cycles, 2 650 per pivot step: s_memtime stamps, round 4)
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), K), __builtin_amdgcn_readlane(__double2loint(v), K));
   } else {
     return __shfl(v, K, NP);
   }
@@ -231,6 +235,19 @@ struct RowFmacDpp {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc[I]) : "v"(y0), "v"(coef), "n"(I));
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc[16 + I]) : "v"(y1), "v"(coef), "n"(I));
     if constexpr (I + 1 < 16) RowFmacDpp<I + 1>::run(acc, y0, y1, coef);
+  }
+};
+
+// the same for 64 rows: acc[16 g + I] += bcast_I(y[g]) * coef, g < 4 (128 streams: lane jj of EVERY DPP row holds the table
+// elements jj, 16 + jj, 32 + jj, 48 + jj of the moment, so lane I of the caller's own row has the multiplier of row 16 g + I)
+template <int I>
+struct RowFmacDpp64 {
+  static __device__ __forceinline__ void run(double (&acc)[64], const double (&y)[4], const double coef) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc[I]) : "v"(y[0]), "v"(coef), "n"(I));
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc[16 + I]) : "v"(y[1]), "v"(coef), "n"(I));
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc[32 + I]) : "v"(y[2]), "v"(coef), "n"(I));
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc[48 + I]) : "v"(y[3]), "v"(coef), "n"(I));
+    if constexpr (I + 1 < 16) RowFmacDpp64<I + 1>::run(acc, y, coef);
   }
 };
 
@@ -724,6 +741,65 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
   for (int i = 0; i < NP; ++i) acc_e[i] = acc_o[i] = 0.0;
   double cmax = 0.0;
   const double* Y0b = d.Y0 + ((long)c * d.M + m) * P;  // Ybar_l^m(-mu0): wave-uniform (scalar loads); read only with a beam
+  if constexpr (NP == 64) {
+    // 66 ... 128 streams, one wavefront per SIMD: nothing hides a memory latency there, and the loop below pays one or two per
+    // moment (its 64 wave-uniform table elements arrive by scalar loads the FMAs wait for: 2 300 cycles per moment, s_memtime
+    // stamps).  Here lane jj of every DPP row loads the elements jj, 16 + jj, 32 + jj, 48 + jj of a moment's table row -- eight
+    // moments requested together, one chunk ahead of their use -- and the multiplier of acc[i] reaches its FMA as a DPP row
+    // broadcast of lane i % 16 (one v_fmac_f64_dpp per term, as at 64 streams).
+    typedef const double __attribute__((address_space(4))) kdouble;
+    kdouble* wk = (kdouble*)wl;    // wave-uniform: s_load
+    kdouble* Y0k = (kdouble*)Y0b;
+    const int jj = j & 15;
+    const bool jr1 = (j & 16) != 0, jr2 = (j & 32) != 0;  // the lane's own DPP row: which of its four elements is Yr[j]
+    const int Pn = P;
+    constexpr int CH = 8;
+    double yv[CH][4], yn[CH][4], wv[CH], wn[CH], y0v[CH], y0n[CH];  // (wv, y0v: wave-uniform, they live in SGPRs)
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      const int ell = id.mg + e < P ? id.mg + e : P - 1;  // (clamped, not predicated: no load waits behind a branch)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) yv[e][g] = Ym[(long)ell * NP + 16 * g + jj];
+      wv[e] = wk[ell];
+      y0v[e] = Y0k[ell];  // (allocated with or without a beam; the sums are read only with one)
+    }
+#pragma unroll 1
+    for (int base = id.mg; base < P; base += CH) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        const int ell = base + CH + e < P ? base + CH + e : P - 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) yn[e][g] = Ym[(long)ell * NP + 16 * g + jj];
+        wn[e] = wk[ell];
+        y0n[e] = Y0k[ell];
+      }
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        const int ell = base + e;
+        if (ell < P) {  // (wave-uniform)
+          const double cl = 0.5 * om * wv[e];
+          cmax = fmax(cmax, fabs(cl));
+          const double ylo = jr1 ? yv[e][1] : yv[e][0], yhi = jr1 ? yv[e][3] : yv[e][2];
+          const double ymine = jr2 ? yhi : ylo;  // Yr[j]
+          const double coef = 2.0 * cl * ymine;
+          if ((e & 1) == 0) {
+            xe_sum = fma(coef, y0v[e], xe_sum);
+            RowFmacDpp64<0>::run(acc_e, yv[e], coef);
+          } else {
+            xo_sum = fma(coef, y0v[e], xo_sum);
+            RowFmacDpp64<0>::run(acc_o, yv[e], coef);
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) yv[e][g] = yn[e][g];
+        wv[e] = wn[e];
+        y0v[e] = y0n[e];
+      }
+    }
+  } else {
   for (int ell = id.mg; ell < P; ell += 2) {
     {
       const double cl = 0.5 * om * wl[ell];
@@ -743,6 +819,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
 #pragma unroll
       for (int i = 0; i < NP; ++i) acc_o[i] += coef * Yr[i];
     }
+  }
   }
   // "shortcut" of the reference when multiple scattering is insignificant (:119, :162-168): the layer
   // is treated as non-scattering; the general path then gives G = [[0,D],[D,0]], k = 1/mu, B = 0.

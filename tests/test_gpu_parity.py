@@ -909,7 +909,7 @@ def test_fused_bc_kernel_pivoted_path_on_goldens(how):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["RTD_EIG_MFMA", "RTD_BC_TILED", "RTD_BC_FORCE_HANDOVER", "RTD_NO_PIPELINE", "RTD_SMALL_SPLIT", "RTD_BC_TILE_V1", "RTD_EIG_SMALL_V1"])
+@pytest.mark.parametrize("switch", ["RTD_EIG_MFMA", "RTD_BC_TILED", "RTD_BC_FORCE_HANDOVER", "RTD_NO_PIPELINE", "RTD_SMALL_SPLIT", "RTD_BC_TILE_V1", "RTD_EIG_SMALL_V1", "RTD_BC_WIDE_V1"])
 def test_alternative_kernel_paths_stay_correct(switch):
     """The runtime switches that select an alternative path -- RTD_EIG_MFMA=1: the assembly of Pm, Qm as rank-4 MFMA updates
     (32 streams); RTD_BC_TILED=1: the tiled fused kernel (the 64-stream kernel) with one tile, in place of the 32-stream
@@ -919,7 +919,8 @@ def test_alternative_kernel_paths_stay_correct(switch):
     of the two-stream pipeline; RTD_SMALL_SPLIT=1: 2 ... 16 streams through the separate interface / sweep / evaluation kernels
     of rounds 1-3 instead of the fused rtd_bc_small_kernel (round 4); RTD_BC_TILE_V1=1: 64 streams through rtd_bc_tile_kernel<2>
     (one wavefront per SIMD) instead of the lean rtd_bc_tile2_kernel; RTD_EIG_SMALL_V1=1: 2 ... 8 streams through
-    rtd_eigen_kernel<4, 2> instead of the one-lane-per-problem eigen kernel -- pass the golden replay (it has 40-, 48- and 64-stream cases), the synthetic configs incl.
+    rtd_eigen_kernel<4, 2> instead of the one-lane-per-problem eigen kernel; RTD_BC_WIDE_V1=1: 66 ... 128 streams through the
+    row-per-lane kernels (one wavefront per chain) instead of the four-wavefronts-per-chain kernels of rtd_bc_wide.hip -- pass the golden replay (it has 40-, 48- and 64-stream cases), the synthetic configs incl.
     cfg5, the random cases, the windowed plans and the fused-evaluation comparison.  (Round 3 removed the switches whose
     paths had lost every A/B: RTD_BC_SPLIT at 32 streams, RTD_EIG_V1, RTD_BCF_WAVES3.)"""
     import subprocess
@@ -930,7 +931,8 @@ def test_alternative_kernel_paths_stay_correct(switch):
                         os.path.join(os.path.dirname(__file__), "test_gpu_random_parity.py"),
                         "-k", "reference_golden or synthetic_config or random_many or edge_cases or fused_interface or windowed or layer_shards"
                               + (" or stamnes or cfg3 or random or mode_shards or failed_column or failure_in" if switch in ("RTD_SMALL_SPLIT", "RTD_EIG_SMALL_V1") else "")
-                              + (" or random_64 or cfg5 or high_precision_truth_56" if switch == "RTD_BC_TILE_V1" else "")],
+                              + (" or random_64 or cfg5 or high_precision_truth_56" if switch == "RTD_BC_TILE_V1" else "")
+                              + (" or beyond_64 or random_128 or random_many" if switch == "RTD_BC_WIDE_V1" else "")],
                        env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
