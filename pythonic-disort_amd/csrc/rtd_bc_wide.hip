@@ -145,13 +145,28 @@ __global__ __launch_bounds__(64, 3) void rtd_iface_wide_kernel(RtdDev d) {
   }
 }
 
+// max of a non-negative float key over the wavefront, in every lane's SGPR view (DPP only: quad permutes, row mirrors, then the
+// GFX9 row broadcasts 15 and 31, and a v_readlane of lane 63) -- the pivot search sits on the critical path of every step and
+// the LDS-crossbar forms (ds_swizzle, ds_bpermute) cost two LDS round trips there
+__device__ __forceinline__ float wave_max_key(float v) {
+  v = dpp_max_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_max_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_max_f32<0x141>(v);  // row_half_mirror
+  v = dpp_max_f32<0x140>(v);  // row_mirror: every lane has the max of its row of 16
+  int t = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1, 3
+  v = fmaxf(v, __int_as_float(t));
+  t = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x143, 0xC, 0xF, false);      // row_bcast:31 into rows 2, 3
+  v = fmaxf(v, __int_as_float(t));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // ------------------------------------------------------------------------------------------------
 // Gauss-Jordan with partial pivoting on the rows [Ta | Tb | t] of a chain, four wavefronts (see the header).  On exit the
 // lane that owned pivot column `pc` holds its slice of row pc of Ta^-1 Tb in tb[] and (Ta^-1 t)[pc] in tt.
 // ------------------------------------------------------------------------------------------------
 template <bool WITH_TB>
 __device__ __forceinline__ void gj_wide(double (&ta)[16], double (&tb)[16], double& tt, int& pc, const int lane, const int q,
-                                        double (*sCol)[NP], int* sFound, const double* touch_at, double (&touched)[2]) {
+                                        double (*sCol)[NP], int* sFound, double* sPiv, const double* touch_at, double (&touched)[2]) {
   pc = -1;
   double myrp = 1.0;
   static_for<0, 16>([&](auto kc) {
@@ -170,17 +185,21 @@ __device__ __forceinline__ void gj_wide(double (&ta)[16], double (&tb)[16], doub
       if (q == qo) {
         const double mine = ta[kk];
         const float key = (pc < 0) ? fabsf((float)mine) : -1.0f;
-        const float kmax = group_max_key<NP>(key);
+        const float kmax = wave_max_key(key);
         const unsigned long long bal = __ballot(key == kmax);
+        const int found_w = __ffsll((long long)bal) - 1;  // -1: a chain that has gone NaN
         sCol[buf][lane] = mine;
-        if (lane == 0) sFound[buf] = __ffsll((long long)bal) - 1;  // -1: a chain that has gone NaN
+        if (lane == 0) {
+          sFound[buf] = found_w;
+          sPiv[buf] = readlane_f64(mine, found_w < 0 ? 0 : found_w);
+        }
       }
       __syncthreads();
       const double mine = sCol[buf][lane];
       const int found = __builtin_amdgcn_readfirstlane(sFound[buf]);
       const int src = found < 0 ? 0 : found;
       const bool isp = lane == found;
-      const double rp = fast_rcp(sCol[buf][src]);
+      const double rp = fast_rcp(sPiv[buf]);
       const double f = isp ? 0.0 : mine * rp;
       if (isp) {
         pc = 4 * kk + qo;
@@ -210,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void rtd_sweep_wide_kernel(RtdDev d) {
   __shared__ double sT[NP * LDS_LD];   // bottom boundary: the rows of Ba
   __shared__ double sCol[2][NP];
   __shared__ int sFound[2];
+  __shared__ double sPiv[2];
   __shared__ double sV[3][NP];
   __shared__ double sRed[2][4][NP];
   const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -257,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void rtd_sweep_wide_kernel(RtdDev d) {
   for (int l = 0; l < L; ++l) {
 #ifndef RTD_WIDE_X_NO_GJ
     double touched[2] = {0.0, 0.0};
-    gj_wide<true>(ta, tb, tt, pc, lane, q, sCol, sFound, l < Lm1 ? wsb + (long)l * W::SLOT : nullptr, touched);
+    gj_wide<true>(ta, tb, tt, pc, lane, q, sCol, sFound, sPiv, l < Lm1 ? wsb + (long)l * W::SLOT : nullptr, touched);
 #endif
     if (pc < 0) pc = j;  // (a chain that has gone NaN finds no pivots: keep the stores inside the chain's own rows)
 #pragma unroll
@@ -383,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void rtd_sweep_wide_kernel(RtdDev d) {
     }
     int pc2 = -1;
     double touched[2] = {0.0, 0.0};
-    gj_wide<false>(ta, tb, bvec, pc2, lane, q, sCol, sFound, nullptr, touched);
+    gj_wide<false>(ta, tb, bvec, pc2, lane, q, sCol, sFound, sPiv, nullptr, touched);
     if (pc2 < 0) pc2 = j;
     if (q == 0) v1[pc2] = bvec;  // C+
     __syncthreads();

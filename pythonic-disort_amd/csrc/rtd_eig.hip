@@ -38,6 +38,8 @@ constexpr __host__ __device__ int dpp_xor_ctrl(int mask) {
 template <int MASK>
 __device__ __forceinline__ double xor_lane(double v) {
   // value of lane (lane ^ MASK)
+  // (lane ^ 16 and lane ^ 32 by v_permlane16_swap / v_permlane32_swap -- VALU, no LDS crossbar -- measured in round 4: the 64-stream
+  //  eigen kernel 9.3 -> 9.5 ms per 128 cfg5 columns, the 128-stream one unchanged; not kept)
   if constexpr (MASK >= 32) return __shfl_xor(v, MASK, 64);  // across the halves of the wavefront: ds_bpermute (NP = 64 only)
   int lo = __double2loint(v), hi = __double2hiint(v);
   constexpr int ctrl = dpp_xor_ctrl(MASK);

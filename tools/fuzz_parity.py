@@ -2,7 +2,7 @@
 """Wide random sweep on the GPU box: the HIP path against the oracle on seeds beyond the fixed ranges of
 tests/test_gpu_random_parity.py (660 cases, 14 s).  A near-conservative case (omega > 1 - 1e-5) further than 1e-6 from the oracle
 is to be arbitrated by its 40-digit solution (tools/hp_truth_case.py <family> <seed>) and pinned in EXTRA_ARBITRATED there.
-Usage: python tools/fuzz_parity.py"""
+Usage: [FUZZ_SCALE=10] [FUZZ_FAMS=random128] python tools/fuzz_parity.py"""
 import os, sys, time, warnings
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +14,8 @@ warnings.simplefilter("ignore")
 K = int(os.environ.get("FUZZ_SCALE", "1"))  # FUZZ_SCALE=10: ten times the seeds
 fams = [("random", T.make_case, range(100, 100 + 400 * K)), ("random32", T.make_case_many_streams, range(100, 100 + 160 * K)),
         ("random64", T.make_case_64_streams, range(100, 100 + 60 * K)), ("random128", T.make_case_128_streams, range(100, 100 + 40 * K))]
+if os.environ.get("FUZZ_FAMS"):  # FUZZ_FAMS=random128,random64: only these families
+    fams = [f for f in fams if f[0] in os.environ["FUZZ_FAMS"].split(",")]
 worst = {}
 t00 = time.time()
 for fam, mk, seeds in fams:
