@@ -224,9 +224,12 @@ __device__ __forceinline__ void gj_wide(double (&ta)[16], double (&tb)[16], doub
 // ------------------------------------------------------------------------------------------------
 // Sweep kernel: per (c, m): forward carry recursion over the layers, bottom boundary, backward sweep.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void rtd_sweep_wide_kernel(RtdDev d) {
+#ifndef RTD_WIDE_WG
+#define RTD_WIDE_WG 3  /* workgroups (chains) per CU the sweep kernel is built for: 3 = 168 registers, 49 KB of LDS */
+#endif
+__global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev d) {
   __shared__ double sS[NP * LDS_LD];   // S at its true row index
-  __shared__ double sT[NP * LDS_LD];   // bottom boundary: the rows of Ba
+  __shared__ double sQ[NP * 17];       // bottom boundary: a quarter of the rows of Ba at a time
   __shared__ double sCol[2][NP];
   __shared__ int sFound[2];
   __shared__ double sPiv[2];
@@ -289,39 +292,53 @@ __global__ __launch_bounds__(256, 2) void rtd_sweep_wide_kernel(RtdDev d) {
     for (int i = 0; i < 16; ++i) ws[W::S + (4 * i + q) * NP + pc] = tb[i];  // S^T for the backward sweep
     if (q == 0) ws[W::SV + pc] = tt;
     __syncthreads();
-    double srow[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) srow[k] = sS[pc * LDS_LD + k];
+    const double Er = Ek[l * NP + pc];
+    kdouble* e1 = as_k(Ek + (l + 1) * NP);
+    // S Wq and S Wp, the lane's row of S half at a time (32 registers instead of 64: three chains per CU), accumulated in ta, tb
     double srb = 0.0;
 #pragma unroll
-    for (int k = 0; k < NP; ++k) srb = fma(srow[k], wk[W::RB + k], srb);  // (S rho_b)[pc]
-    const double Er = Ek[l * NP + pc];
-    const double tnew = ws[W::RT + pc] - Er * (tt - srb);
-    kdouble* e1 = as_k(Ek + (l + 1) * NP);
+    for (int i = 0; i < 16; ++i) ta[i] = tb[i] = 0.0;
 #ifndef RTD_WIDE_X_NO_CARRY
-    // (S has left ta, tb for LDS: the row pc of Wp, Wq -- this lane's own loads -- waits there, all 32 loads in flight at once)
+#pragma unroll 1
+    for (int kh = 0; kh < NP; kh += 32) {
+      double srow[32];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      ta[i] = ws[W::WP + (4 * i + q) * NP + pc];
-      tb[i] = ws[W::WQ + (4 * i + q) * NP + pc];
-    }
+      for (int k = 0; k < 32; ++k) srow[k] = sS[pc * LDS_LD + kh + k];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) srb = fma(srow[k], wk[W::RB + kh + k], srb);  // (S rho_b)[pc]
 #pragma unroll 2
-    for (int i = 0; i < 16; ++i) {
-      const int cc = 4 * i + q;
-      kdouble* wq = wk + W::WQ + cc * NP;  // column cc of Wq, Wp: rows of the stored transposes
-      kdouble* wp = wk + W::WP + cc * NP;
-      double swq0 = 0.0, swq1 = 0.0, swp0 = 0.0, swp1 = 0.0;
+      for (int i = 0; i < 16; ++i) {
+        const int cc = 4 * i + q;
+        kdouble* wq = wk + W::WQ + cc * NP + kh;  // column cc of Wq, Wp: rows of the stored transposes
+        kdouble* wp = wk + W::WP + cc * NP + kh;
+        double swq0 = 0.0, swq1 = 0.0, swp0 = 0.0, swp1 = 0.0;
 #pragma unroll
-      for (int k = 0; k < NP; k += 2) {
-        swq0 = fma(srow[k], wq[k], swq0);
-        swq1 = fma(srow[k + 1], wq[k + 1], swq1);
-        swp0 = fma(srow[k], wp[k], swp0);
-        swp1 = fma(srow[k + 1], wp[k + 1], swp1);
+        for (int k = 0; k < 32; k += 2) {
+          swq0 = fma(srow[k], wq[k], swq0);
+          swq1 = fma(srow[k + 1], wq[k + 1], swq1);
+          swp0 = fma(srow[k], wp[k], swp0);
+          swp1 = fma(srow[k + 1], wp[k + 1], swp1);
+        }
+        ta[i] += swq0 + swq1;
+        tb[i] += swp0 + swp1;
       }
-      ta[i] = -(Er * (swq0 + swq1) + ta[i]);           // Ta' = -(E S Wq + Wp)
-      tb[i] = -(Er * (swp0 + swp1) + tb[i]) * e1[cc];  // Tb' = -(E S Wp + Wq) E'
+    }
+    {
+      // Ta' = -(E S Wq + Wp), Tb' = -(E S Wp + Wq) E': the row pc of Wp, Wq are this lane's own loads, all in flight at once
+      double wpr[16], wqr[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        wpr[i] = ws[W::WP + (4 * i + q) * NP + pc];
+        wqr[i] = ws[W::WQ + (4 * i + q) * NP + pc];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        ta[i] = -(Er * ta[i] + wpr[i]);
+        tb[i] = -(Er * tb[i] + wqr[i]) * e1[4 * i + q];
+      }
     }
 #endif
+    const double tnew = ws[W::RT + pc] - Er * (tt - srb);
     tt = tnew;
     if (touched[0] == 1.2345e-300 && touched[1] == 1.2345e-300) tt += touched[0];  // (never: keeps the touching loads alive)
   }
@@ -372,35 +389,41 @@ __global__ __launch_bounds__(256, 2) void rtd_sweep_wide_kernel(RtdDev d) {
       if (beam) br -= Bv[l * Q + j] * att;
       if (iso) br -= vpoly(l, ts0[L], j);
     }
-    double bb[16];
+    // am = Bb - Ba S (into ta: this wavefront's columns) and bvec = br - Ba s.  A lane needs its whole row of Ba, of which every
+    // wavefront made a quarter of the columns: the rows cross in LDS sixteen columns at a time (8.5 KB, not the 33 KB of a full
+    // copy: three chains fit a CU).
+    double ba[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int k = 4 * i + q;
       const double qk = qa[i] / kl[k];
-      sT[j * LDS_LD + k] = (pa[i] - qk) * Ek[l * NP + k];  // Ba (with the scaling of C-)
-      bb[i] = pa[i] + qk;
+      ba[i] = (pa[i] - qk) * Ek[l * NP + k];  // Ba (with the scaling of C-)
+      ta[i] = pa[i] + qk;                      // Bb
     }
-    __syncthreads();  // S, s and Ba complete
     double bvec = br;
-    {
-      double barow[NP];
+    static_for<0, 4>([&](auto kqc) {
+      constexpr int kq = decltype(kqc)::value;
+      __syncthreads();  // (first pass: S and s complete; later ones: the previous quarter has been read)
 #pragma unroll
-      for (int k = 0; k < NP; ++k) barow[k] = sT[j * LDS_LD + k];
+      for (int t = 0; t < 4; ++t) sQ[j * 17 + 4 * t + q] = ba[4 * kq + t];  // columns 16 kq + 4 t + q
+      __syncthreads();
+      double bq[16];
 #pragma unroll
-      for (int k = 0; k < NP; ++k) bvec = fma(-barow[k], v0[k], bvec);
-      // am = Bb - Ba S into ta (this wavefront's columns)
-#pragma unroll 2
+      for (int k = 0; k < 16; ++k) bq[k] = sQ[j * 17 + k];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) bvec = fma(-bq[k], v0[16 * kq + k], bvec);
+#pragma unroll 4
       for (int i = 0; i < 16; ++i) {
         const int cc = 4 * i + q;
-        double a0 = bb[i], a1 = 0.0;
+        double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-        for (int k = 0; k < NP; k += 2) {
-          a0 = fma(-barow[k], sS[k * LDS_LD + cc], a0);
-          a1 = fma(-barow[k + 1], sS[(k + 1) * LDS_LD + cc], a1);
+        for (int k = 0; k < 16; k += 2) {
+          a0 = fma(bq[k], sS[(16 * kq + k) * LDS_LD + cc], a0);
+          a1 = fma(bq[k + 1], sS[(16 * kq + k + 1) * LDS_LD + cc], a1);
         }
-        ta[i] = a0 + a1;
+        ta[i] -= a0 + a1;
       }
-    }
+    });
     int pc2 = -1;
     double touched[2] = {0.0, 0.0};
     gj_wide<false>(ta, tb, bvec, pc2, lane, q, sCol, sFound, sPiv, nullptr, touched);
