@@ -413,7 +413,8 @@ def single_column_leg(device, calls=30):
 
 def many_stream_leg(device, columns=32):
     """The other reading of BASELINE configs[4]: 128 streams, 50 layers, Fourier modes capped at 64
-    -- beyond that the reference's own Legendre tables overflow -- on the generic (untuned) kernel instances; parity against
+    -- beyond that the reference's own Legendre tables overflow -- on the NP = 64 instances (round 4: four-wavefronts-per-chain
+    boundary-condition kernels, csrc/rtd_bc_wide.hip; readlane Cholesky and DPP-broadcast assembly in the eigen kernel); parity against
     the reference's output for the 128-stream golden case (tests/golden/synth/q128.npz)."""
     import warnings
     import pydisort_amd
@@ -442,7 +443,7 @@ def many_stream_leg(device, columns=32):
     diff = np.abs(u - want)
     sig = np.abs(want) > 1e-8 * np.max(np.abs(want))
     return {"value": rate, "unit": "column-solves/sec", "columns": columns, "columns_per_window": cw, "windows": nwin,
-            "workload": "128 streams, 50 layers, 64 Fourier modes (Henyey-Greenstein, g up to 0.9, delta-M): generic kernel instances, not tuned",
+            "workload": "128 streams, 50 layers, 64 Fourier modes (Henyey-Greenstein, g up to 0.9, delta-M): rtd_eigen_kernel<64, 2> + rtd_iface_wide_kernel + rtd_sweep_wide_kernel (round 4; 253 col/s on the generic instances of round 3)",
             "parity": {"max_scale_rel": float(diff.max() / np.max(np.abs(want))), "max_rel_dI": float((diff[sig] / np.abs(want[sig])).max()),
                        "columns_checked": 1, "against": "reference-computed golden tests/golden/synth/q128.npz (128 streams, 2 layers, 64 modes)"}}
 
