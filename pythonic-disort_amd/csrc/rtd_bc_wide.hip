@@ -40,14 +40,52 @@ __device__ __forceinline__ double readlane_f64(const double v, const int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
+#ifndef RTD_WIDE_DPP_CARRY
+#define RTD_WIDE_DPP_CARRY 1  /* carry: wave-uniform factors as DPP row broadcasts of replicated vector loads instead of scalar loads (10.7 -> 9.9 ms per 24 columns) */
+#endif
+#ifndef RTD_WIDE_DPP_IFACE
+#define RTD_WIDE_DPP_IFACE 0  /* the same in the interface kernel: slower there (5.3 -> 6.0 ms: that kernel is bound by its HBM traffic, not by the scalar loads) */
+#endif
+// acc[T] += (lane T of the caller's 16-lane DPP row of u) * s for T = 0 .. 15: with u loaded so that lane t of EVERY row holds the
+// t-th of sixteen consecutive wave-uniform operands (address from lane & 15 only), one vector load feeds sixteen FMAs and each FMA
+// is ONE v_fmac_f64_dpp -- no SGPRs (eighty hold 160 cycles of operands: the scalar-load form was bound by the latency of the L2),
+// no v_readlane; vector loads take as many in flight as there are registers for them.
+template <int T, int N>
+struct FmacBcast16 {
+  static __device__ __forceinline__ void run(double (&acc)[N], const int base, const double u, const double s) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc[base + T]) : "v"(u), "v"(s), "n"(T));
+    if constexpr (T + 1 < 16) FmacBcast16<T + 1, N>::run(acc, base, u, s);
+  }
+};
+// four dot products of sixteen terms each, interleaved (four independent accumulation chains):
+//   q0 += sum_T bcast_T(uq0) s[T], p0 += sum_T bcast_T(up0) s[T], q1 += sum_T bcast_T(uq1) s[16 + T], p1 += sum_T bcast_T(up1) s[16 + T]
+template <int T>
+struct DotBcast16x4 {
+  static __device__ __forceinline__ void run(double& q0, double& p0, double& q1, double& p1, const double uq0, const double up0,
+                                             const double uq1, const double up1, const double (&s)[32]) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(q0) : "v"(uq0), "v"(s[T]), "n"(T));
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(p0) : "v"(up0), "v"(s[T]), "n"(T));
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(q1) : "v"(uq1), "v"(s[16 + T]), "n"(T));
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(p1) : "v"(up1), "v"(s[16 + T]), "n"(T));
+    if constexpr (T + 1 < 16) DotBcast16x4<T + 1>::run(q0, p0, q1, p1, uq0, up0, uq1, up1, s);
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // Interface operators: per (c, m, l < L-1) the transposes of Wp, Wq = (A^T Y' +- k Y^T A' / k') / 2 and rho_t, rho_b.
 // Two wavefronts (blocks) per interface, 32 columns each; lane = row.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64, 3) void rtd_iface_wide_kernel(RtdDev d) {
   const int lane = threadIdx.x;
-  const int h = blockIdx.x & 1;
-  const long pid = blockIdx.x >> 1;
+  // Workgroups go to the eight XCDs round robin, and every XCD has its own L2: the two halves of an interface (same A_l, Y_l) and
+  // the neighbouring interfaces of a chain (Y', A' of one are Y_l, A_l of the next) are made to meet in ONE L2 by giving XCD x the
+  // x-th contiguous eighth of the work items.
+  // (the grid is rounded up to a multiple of eight workgroups; work items beyond the last interface leave at once)
+  const unsigned nb = 2u * (unsigned)d.C * (unsigned)d.M * (unsigned)(d.L - 1), per = gridDim.x / 8;
+  const unsigned wi = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  if (wi >= nb) return;
+  const int h = wi & 1;
+  const long pid = wi >> 1;
   const int Lm1 = d.L - 1;
   const int l = (int)(pid % Lm1);
   const long cm = pid / Lm1;
@@ -104,6 +142,19 @@ __global__ __launch_bounds__(64, 3) void rtd_iface_wide_kernel(RtdDev d) {
     a[e] = A0[e * NP + lane];
     y[e] = Y0[e * NP + lane];
   }
+#if RTD_WIDE_DPP_IFACE
+  // rows of Y', A' (the wave-uniform factors): lane t of every DPP row loads the columns 32 h + t and 32 h + 16 + t (see FmacBcast16)
+  const double* Y1g = d.Ym + p1 * NP * NP + 32 * h + (lane & 15);
+  const double* A1g = d.Am + p1 * NP * NP + 32 * h + (lane & 15);
+  double yu[CH][2], au[CH][2];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) {
+    yu[e][0] = Y1g[e * NP];
+    yu[e][1] = Y1g[e * NP + 16];
+    au[e][0] = A1g[e * NP];
+    au[e][1] = A1g[e * NP + 16];
+  }
+#endif
 #pragma unroll 1
   for (int i0 = 0; i0 < NP; i0 += CH) {
     double an[CH], yn[CH];
@@ -113,12 +164,29 @@ __global__ __launch_bounds__(64, 3) void rtd_iface_wide_kernel(RtdDev d) {
       an[e] = A0[(in + e) * NP + lane];
       yn[e] = Y0[(in + e) * NP + lane];
     }
+#if RTD_WIDE_DPP_IFACE
+    double yun[CH][2], aun[CH][2];
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
+      yun[e][0] = Y1g[(in + e) * NP];
+      yun[e][1] = Y1g[(in + e) * NP + 16];
+      aun[e][0] = A1g[(in + e) * NP];
+      aun[e][1] = A1g[(in + e) * NP + 16];
+    }
+#endif
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+#if RTD_WIDE_DPP_IFACE
+      FmacBcast16<0, 32>::run(vv, 0, yu[e][0], a[e]);
+      FmacBcast16<0, 32>::run(uu, 0, au[e][0], y[e]);
+      FmacBcast16<0, 32>::run(vv, 16, yu[e][1], a[e]);
+      FmacBcast16<0, 32>::run(uu, 16, au[e][1], y[e]);
+#else
 #pragma unroll
       for (int cc = 0; cc < 32; ++cc) vv[cc] = fma(a[e], Y1[(i0 + e) * NP + cc], vv[cc]);
 #pragma unroll
       for (int cc = 0; cc < 32; ++cc) uu[cc] = fma(y[e], A1[(i0 + e) * NP + cc], uu[cc]);
+#endif
       ra = fma(a[e], readlane_f64(rsum, i0 + e), ra);
       ry = fma(y[e], readlane_f64(rdif, i0 + e), ry);
     }
@@ -126,6 +194,12 @@ __global__ __launch_bounds__(64, 3) void rtd_iface_wide_kernel(RtdDev d) {
     for (int e = 0; e < CH; ++e) {
       a[e] = an[e];
       y[e] = yn[e];
+#if RTD_WIDE_DPP_IFACE
+      yu[e][0] = yun[e][0];
+      yu[e][1] = yun[e][1];
+      au[e][0] = aun[e][0];
+      au[e][1] = aun[e][1];
+#endif
     }
   }
   const double k0 = d.kk[p0 * NP + lane];
@@ -306,6 +380,20 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
       for (int k = 0; k < 32; ++k) srow[k] = sS[pc * LDS_LD + kh + k];
 #pragma unroll
       for (int k = 0; k < 32; ++k) srb = fma(srow[k], wk[W::RB + kh + k], srb);  // (S rho_b)[pc]
+#if RTD_WIDE_DPP_CARRY
+      // (column cc of Wq, Wp = row cc of the stored transposes: sixteen consecutive elements per vector load, replicated over the
+      //  DPP rows; see FmacBcast16)
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const double* wqg = ws + W::WQ + (4 * i + q) * NP + kh + (lane & 15);
+        const double* wpg = ws + W::WP + (4 * i + q) * NP + kh + (lane & 15);
+        const double wq0 = wqg[0], wq1 = wqg[16], wp0 = wpg[0], wp1 = wpg[16];
+        double swq0 = 0.0, swq1 = 0.0, swp0 = 0.0, swp1 = 0.0;
+        DotBcast16x4<0>::run(swq0, swp0, swq1, swp1, wq0, wp0, wq1, wp1, srow);
+        ta[i] += swq0 + swq1;
+        tb[i] += swp0 + swp1;
+      }
+#else
 #pragma unroll 2
       for (int i = 0; i < 16; ++i) {
         const int cc = 4 * i + q;
@@ -322,6 +410,7 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
         ta[i] += swq0 + swq1;
         tb[i] += swp0 + swp1;
       }
+#endif
     }
     {
       // Ta' = -(E S Wq + Wp), Tb' = -(E S Wp + Wq) E': the row pc of Wp, Wq are this lane's own loads, all in flight at once
@@ -492,6 +581,6 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
 
 void rtd_launch_bc_wide(const RtdDev& d, hipStream_t s, int part) {
   const long nif = (long)d.C * d.M * (d.L - 1);
-  if (part == 0 && nif > 0) hipLaunchKernelGGL(rtd_iface_wide_kernel, dim3((unsigned)(2 * nif)), dim3(64), 0, s, d);
+  if (part == 0 && nif > 0) hipLaunchKernelGGL(rtd_iface_wide_kernel, dim3((unsigned)((2 * nif + 7) / 8 * 8)), dim3(64), 0, s, d);
   if (part == 1) hipLaunchKernelGGL(rtd_sweep_wide_kernel, dim3((unsigned)((long)d.C * d.M)), dim3(256), 0, s, d);
 }
