@@ -10,10 +10,10 @@
 // work whatever the column.  What crosses wavefronts in the elimination is ONE column per pivot step (64 doubles through
 // LDS, double buffered: one barrier per step); the pivot row never moves between wavefronts -- each wavefront has its
 // own slice of it in the pivot lane's registers and broadcasts it with v_readlane (SGPR operands of the FMAs).  The
-// products with wave-uniform operands -- S Wq, S Wp of the carry, A^T Y' and Y^T A' of the interface operators -- are
-// plain FMAs whose uniform factor comes from scalar loads (constant address space: s_load), one FMA instruction per
-// 64 multiply-adds like an MFMA (FP64 vector and matrix instructions share the DP ALUs on this chip) with no operand
-// staging at all.  The interface operators are stored TRANSPOSED (lanes = rows contiguous): coalesced stores here,
+// products with wave-uniform operands are plain FMAs, one instruction per 64 multiply-adds like an MFMA (FP64 vector and
+// matrix instructions share the DP ALUs on this chip) with no operand staging at all: A^T Y' and Y^T A' of the interface
+// operators take the uniform factor from scalar loads (constant address space: s_load), S Wq and S Wp of the carry as DPP
+// row broadcasts of replicated vector loads (DotBcast16x4 below).  The interface operators are stored TRANSPOSED (lanes = rows contiguous): coalesced stores here,
 // contiguous scalar loads in the carry, coalesced loads in the backward sweep.
 //
 // Pivoting: partial pivoting on float keys exactly as the row-per-lane kernels (rtd_bc_common.h: GjStep); pivot rows are
@@ -40,24 +40,12 @@ __device__ __forceinline__ double readlane_f64(const double v, const int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
-#ifndef RTD_WIDE_DPP_CARRY
-#define RTD_WIDE_DPP_CARRY 1  /* carry: wave-uniform factors as DPP row broadcasts of replicated vector loads instead of scalar loads (10.7 -> 9.9 ms per 24 columns) */
-#endif
-#ifndef RTD_WIDE_DPP_IFACE
-#define RTD_WIDE_DPP_IFACE 0  /* the same in the interface kernel: slower there (5.3 -> 6.0 ms: that kernel is bound by its HBM traffic, not by the scalar loads) */
-#endif
-// acc[T] += (lane T of the caller's 16-lane DPP row of u) * s for T = 0 .. 15: with u loaded so that lane t of EVERY row holds the
-// t-th of sixteen consecutive wave-uniform operands (address from lane & 15 only), one vector load feeds sixteen FMAs and each FMA
-// is ONE v_fmac_f64_dpp -- no SGPRs (eighty hold 160 cycles of operands: the scalar-load form was bound by the latency of the L2),
-// no v_readlane; vector loads take as many in flight as there are registers for them.
-template <int T, int N>
-struct FmacBcast16 {
-  static __device__ __forceinline__ void run(double (&acc)[N], const int base, const double u, const double s) {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc[base + T]) : "v"(u), "v"(s), "n"(T));
-    if constexpr (T + 1 < 16) FmacBcast16<T + 1, N>::run(acc, base, u, s);
-  }
-};
-// four dot products of sixteen terms each, interleaved (four independent accumulation chains):
+// Wave-uniform factors as DPP row broadcasts of replicated vector loads: u is loaded so that lane t of EVERY 16-lane DPP row holds
+// the t-th of sixteen consecutive wave-uniform operands (address from lane & 15 only); `v_fmac_f64_dpp acc, u, s row_newbcast:T`
+// then multiplies the lane's own s by the T-th operand.  One vector load feeds sixteen FMAs and each FMA is ONE instruction -- no
+// SGPRs (eighty of them hold 160 cycles of operands: the scalar-load form of the carry was bound by the latency of the L2), no
+// v_readlane; vector loads take as many in flight as there are registers for them.
+// Four dot products of sixteen terms each, interleaved (four independent accumulation chains):
 //   q0 += sum_T bcast_T(uq0) s[T], p0 += sum_T bcast_T(up0) s[T], q1 += sum_T bcast_T(uq1) s[16 + T], p1 += sum_T bcast_T(up1) s[16 + T]
 template <int T>
 struct DotBcast16x4 {
@@ -93,13 +81,8 @@ __global__ __launch_bounds__(64, 3) void rtd_iface_wide_kernel(RtdDev d) {
   const long p0 = cm * d.L + l, p1 = p0 + 1;
   const double* A0 = d.Am + p0 * NP * NP;
   const double* Y0 = d.Ym + p0 * NP * NP;
-#ifdef RTD_WIDE_X_SAMEK
-  kdouble* Y1 = as_k(d.Ym + 32 * h);
-  kdouble* A1 = as_k(d.Am + 32 * h);
-#else
   kdouble* Y1 = as_k(d.Ym + p1 * NP * NP + 32 * h);
   kdouble* A1 = as_k(d.Am + p1 * NP * NP + 32 * h);
-#endif
   double* ws = d.Fws + (cm * Lm1 + l) * W::SLOT;
   // particular-solution jump r_l at the interface (:184-205, :242-245) and rho = G_l^-1 r_l:
   //   rho_t/b = 1/4 [ V^-1 (r_up + r_dn) +- U^-1 (r_up - r_dn) ],  V^-1[j][i] = T_i A[i][j],  U^-1[j][i] = -k_j T_i Y[i][j]
@@ -142,19 +125,6 @@ __global__ __launch_bounds__(64, 3) void rtd_iface_wide_kernel(RtdDev d) {
     a[e] = A0[e * NP + lane];
     y[e] = Y0[e * NP + lane];
   }
-#if RTD_WIDE_DPP_IFACE
-  // rows of Y', A' (the wave-uniform factors): lane t of every DPP row loads the columns 32 h + t and 32 h + 16 + t (see FmacBcast16)
-  const double* Y1g = d.Ym + p1 * NP * NP + 32 * h + (lane & 15);
-  const double* A1g = d.Am + p1 * NP * NP + 32 * h + (lane & 15);
-  double yu[CH][2], au[CH][2];
-#pragma unroll
-  for (int e = 0; e < CH; ++e) {
-    yu[e][0] = Y1g[e * NP];
-    yu[e][1] = Y1g[e * NP + 16];
-    au[e][0] = A1g[e * NP];
-    au[e][1] = A1g[e * NP + 16];
-  }
-#endif
 #pragma unroll 1
   for (int i0 = 0; i0 < NP; i0 += CH) {
     double an[CH], yn[CH];
@@ -164,29 +134,12 @@ __global__ __launch_bounds__(64, 3) void rtd_iface_wide_kernel(RtdDev d) {
       an[e] = A0[(in + e) * NP + lane];
       yn[e] = Y0[(in + e) * NP + lane];
     }
-#if RTD_WIDE_DPP_IFACE
-    double yun[CH][2], aun[CH][2];
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
-      yun[e][0] = Y1g[(in + e) * NP];
-      yun[e][1] = Y1g[(in + e) * NP + 16];
-      aun[e][0] = A1g[(in + e) * NP];
-      aun[e][1] = A1g[(in + e) * NP + 16];
-    }
-#endif
-#pragma unroll
-    for (int e = 0; e < CH; ++e) {
-#if RTD_WIDE_DPP_IFACE
-      FmacBcast16<0, 32>::run(vv, 0, yu[e][0], a[e]);
-      FmacBcast16<0, 32>::run(uu, 0, au[e][0], y[e]);
-      FmacBcast16<0, 32>::run(vv, 16, yu[e][1], a[e]);
-      FmacBcast16<0, 32>::run(uu, 16, au[e][1], y[e]);
-#else
 #pragma unroll
       for (int cc = 0; cc < 32; ++cc) vv[cc] = fma(a[e], Y1[(i0 + e) * NP + cc], vv[cc]);
 #pragma unroll
       for (int cc = 0; cc < 32; ++cc) uu[cc] = fma(y[e], A1[(i0 + e) * NP + cc], uu[cc]);
-#endif
       ra = fma(a[e], readlane_f64(rsum, i0 + e), ra);
       ry = fma(y[e], readlane_f64(rdif, i0 + e), ry);
     }
@@ -194,12 +147,6 @@ __global__ __launch_bounds__(64, 3) void rtd_iface_wide_kernel(RtdDev d) {
     for (int e = 0; e < CH; ++e) {
       a[e] = an[e];
       y[e] = yn[e];
-#if RTD_WIDE_DPP_IFACE
-      yu[e][0] = yun[e][0];
-      yu[e][1] = yun[e][1];
-      au[e][0] = aun[e][0];
-      au[e][1] = aun[e][1];
-#endif
     }
   }
   const double k0 = d.kk[p0 * NP + lane];
@@ -352,10 +299,8 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
 
   int pc = -1;
   for (int l = 0; l < L; ++l) {
-#ifndef RTD_WIDE_X_NO_GJ
     double touched[2] = {0.0, 0.0};
     gj_wide<true>(ta, tb, tt, pc, lane, q, sCol, sFound, sPiv, l < Lm1 ? wsb + (long)l * W::SLOT : nullptr, touched);
-#endif
     if (pc < 0) pc = j;  // (a chain that has gone NaN finds no pivots: keep the stores inside the chain's own rows)
 #pragma unroll
     for (int i = 0; i < 16; ++i) sS[pc * LDS_LD + 4 * i + q] = tb[i];
@@ -372,7 +317,6 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
     double srb = 0.0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) ta[i] = tb[i] = 0.0;
-#ifndef RTD_WIDE_X_NO_CARRY
 #pragma unroll 1
     for (int kh = 0; kh < NP; kh += 32) {
       double srow[32];
@@ -380,7 +324,6 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
       for (int k = 0; k < 32; ++k) srow[k] = sS[pc * LDS_LD + kh + k];
 #pragma unroll
       for (int k = 0; k < 32; ++k) srb = fma(srow[k], wk[W::RB + kh + k], srb);  // (S rho_b)[pc]
-#if RTD_WIDE_DPP_CARRY
       // (column cc of Wq, Wp = row cc of the stored transposes: sixteen consecutive elements per vector load, replicated over the
       //  DPP rows; see FmacBcast16)
 #pragma unroll 4
@@ -393,24 +336,6 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
         ta[i] += swq0 + swq1;
         tb[i] += swp0 + swp1;
       }
-#else
-#pragma unroll 2
-      for (int i = 0; i < 16; ++i) {
-        const int cc = 4 * i + q;
-        kdouble* wq = wk + W::WQ + cc * NP + kh;  // column cc of Wq, Wp: rows of the stored transposes
-        kdouble* wp = wk + W::WP + cc * NP + kh;
-        double swq0 = 0.0, swq1 = 0.0, swp0 = 0.0, swp1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 32; k += 2) {
-          swq0 = fma(srow[k], wq[k], swq0);
-          swq1 = fma(srow[k + 1], wq[k + 1], swq1);
-          swp0 = fma(srow[k], wp[k], swp0);
-          swp1 = fma(srow[k + 1], wp[k + 1], swp1);
-        }
-        ta[i] += swq0 + swq1;
-        tb[i] += swp0 + swp1;
-      }
-#endif
     }
     {
       // Ta' = -(E S Wq + Wp), Tb' = -(E S Wp + Wq) E': the row pc of Wp, Wq are this lane's own loads, all in flight at once
@@ -426,7 +351,6 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
         tb[i] = -(Er * tb[i] + wqr[i]) * e1[4 * i + q];
       }
     }
-#endif
     const double tnew = ws[W::RT + pc] - Er * (tt - srb);
     tt = tnew;
     if (touched[0] == 1.2345e-300 && touched[1] == 1.2345e-300) tt += touched[0];  // (never: keeps the touching loads alive)

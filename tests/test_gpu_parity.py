@@ -646,8 +646,9 @@ def test_baseline_literal_configs(amd, name):
 
 @pytest.mark.parametrize("name", ["q72", "q96", "q128"])
 def test_beyond_64_streams_vs_reference(amd, name):
-    """72 / 96 / 128 streams -- the reference has no cap on NQuad (pydisort.py:258-264); these sizes run on the generic
-    kernel instances (one eigenproblem / one boundary-condition chain per wavefront) -- against the reference's own outputs
+    """72 / 96 / 128 streams -- the reference has no cap on NQuad (pydisort.py:258-264); these sizes run on the NP = 64 instances
+    (one eigenproblem per wavefront; a boundary-condition chain per workgroup of four wavefronts, csrc/rtd_bc_wide.hip; one chain per
+    wavefront on the row-per-lane kernels under RTD_BC_WIDE_V1) -- against the reference's own outputs
     (tests/golden/synth/q*.npz, make_synthetic_goldens.py).  Tolerances: the north star's 1e-6 pointwise; 1e-7 of the field
     scale (the reference's float64 algorithm and its restatement in oracle/ differ by 3e-10 from each other here)."""
     from conftest import record_parity
