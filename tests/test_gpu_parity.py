@@ -713,6 +713,42 @@ def test_beyond_64_streams_feature_paths(amd):
         assert np.max(np.abs(got[4](tau, phi) - ref[4](tau, phi))) / np.max(np.abs(ref[4](tau, phi))) < 1e-8
 
 
+def test_a_failed_column_at_72_streams_does_not_touch_the_rest_of_the_batch(amd):
+    """Beyond 64 streams a boundary-condition chain is a workgroup of four wavefronts (csrc/rtd_bc_wide.hip) whose pivot search
+    finds nothing in a chain that has gone NaN: a column whose 73-moment truncation of a g = 0.99 Henyey-Greenstein phase function
+    is not positive (no delta-M: the Cholesky factorisation of the eigen stage fails, as the reference's sqrt does,
+    _solve_for_gen_and_part_sols.py:186) sits between benign columns; they must equal their own one-column solves bit for bit,
+    `column_status` must name the failed ones, numeric_errors="nan" must return the batch with those columns NaN."""
+    NQ = 72
+    def column(g):
+        return dict(tau_arr=np.array([0.5, 1.0, 3.0]), omega_arr=np.array([0.8, 0.9, 0.7]), NQuad=NQ,
+                    Leg_coeffs_all=np.stack([0.6 ** np.arange(NQ + 1), g ** np.arange(NQ + 1), 0.5 ** np.arange(NQ + 1)]),
+                    mu0=0.6, I0=1.0, phi0=0.0, NFourier=6)
+    good, bad = column(0.9), column(0.99)
+    order = [good, bad, good, bad, good]
+    cfg = dict(tau_arr=np.stack([k["tau_arr"] for k in order]), omega_arr=np.stack([k["omega_arr"] for k in order]), NQuad=NQ,
+               Leg_coeffs_all=np.stack([k["Leg_coeffs_all"] for k in order]), mu0=np.full(5, 0.6), I0=np.full(5, 1.0),
+               phi0=np.full(5, 0.0), NFourier=6)
+    tau, phi = np.array([0.0, 0.7, 3.0]), np.array([0.0, 1.0])
+    taub = np.tile(tau, (5, 1))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        one = amd.pydisort(**good)
+        want = one[4](tau, phi)
+        with pytest.raises(np.linalg.LinAlgError):
+            amd.pydisort(**bad)[4](tau, phi)
+        _, sol = amd.pydisort_batch(**cfg)
+        with pytest.raises(np.linalg.LinAlgError, match=r"2 of 5 columns \(1, 3\)"):
+            sol.u(taub, phi)
+        st = sol.plan.column_status()
+        assert np.array_equal(st != 0, [False, True, False, True, False])
+        _, soln = amd.pydisort_batch(numeric_errors="nan", **cfg)
+        u = soln.u(taub, phi)
+    assert np.all(np.isnan(u[[1, 3]]))
+    for i in (0, 2, 4):
+        assert np.array_equal(u[i], want), i
+
+
 EDGE_CASES = {
     # two streams (N = 1, padded to 4 lanes), single layer
     "two_streams": dict(tau_arr=0.7, omega_arr=0.6, NQuad=2, Leg_coeffs_all=np.array([1.0, 0.3, 0.1]), mu0=0.4, I0=2.0, phi0=1.0),
