@@ -736,6 +736,102 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
       for (int r = i; r < NP; ++r) a += L_[lix(r, i)] * qcol[r];
       w[i] = a;
     }
+  } else if constexpr (NP == 64) {
+    // 66 ... 128 streams: one wavefront per SIMD (512 registers), nothing hides a latency, and only the 256 architectural registers
+    // can be VALU operands.  (a) One parity at a time, as at NP = 32: Pm is assembled, factorised and parked in LDS before Qm is
+    // touched -- with both accumulators and both Cholesky columns alive, half of them sat in AGPRs and every FMA on them paid
+    // two v_accvgpr_read and two v_accvgpr_write (970 cycles per moment, s_memtime stamps; 2 300 in the scalar-load form of round
+    // 3, one or two memory latencies per moment).  (b) Lane jj of every DPP row loads the elements jj, 16 + jj, 32 + jj, 48 + jj
+    // of a moment's table row -- eight moments of the parity requested together, one chunk ahead of their use -- and the
+    // multiplier of acc[i] reaches its FMA as a DPP row broadcast of lane i % 16 (one v_fmac_f64_dpp per term, as at 64 streams).
+    typedef const double __attribute__((address_space(4))) kdouble;
+    kdouble* wk = (kdouble*)wl;    // wave-uniform: s_load
+    kdouble* Y0k = (kdouble*)(d.Y0 + ((long)c * d.M + m) * P);  // Ybar_l^m(-mu0) (allocated with or without a beam)
+    const int jj = j & 15;
+    const bool jr1 = (j & 16) != 0, jr2 = (j & 32) != 0;  // the lane's own DPP row: which of its four elements is Yr[j]
+    // "shortcut" of the reference when multiple scattering is insignificant (:119, :162-168): max_l |omega w_l / 2| over all the
+    // layer's moments (lane j: the terms mg + j and mg + 64 + j; P <= 2 NP)
+    double cmax = 0.0;
+    {
+      const int l0 = id.mg + j, l1 = l0 + NP;
+      if (l0 < P) cmax = fabs(0.5 * om * wl[l0]);
+      if (l1 < P) cmax = fmax(cmax, fabs(0.5 * om * wl[l1]));
+      cmax = fmax(cmax, xor_lane<1>(cmax));
+      cmax = fmax(cmax, xor_lane<2>(cmax));
+      cmax = fmax(cmax, xor_lane<4>(cmax));
+      cmax = fmax(cmax, xor_lane<8>(cmax));
+      cmax = fmax(cmax, xor_lane<16>(cmax));
+      cmax = fmax(cmax, xor_lane<32>(cmax));
+    }
+    const double live = (cmax > 1e-8) ? 1.0 : 0.0;
+    auto assemble = [&](const int first, double (&col)[NP], double& beam_sum) {
+      // M^-1 - S (2 sum_{l = first, first + 2, ...} c_l Y_l Y_l^T) S
+      double acc[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) acc[i] = 0.0;
+      constexpr int CH = 8;
+      double yv[CH][4], yn[CH][4], wv[CH], wn[CH], y0v[CH], y0n[CH];  // (wv, y0v: wave-uniform, they live in SGPRs)
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        const int ell = first + 2 * e < P ? first + 2 * e : P - 1;  // (clamped, not predicated: no load waits behind a branch)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) yv[e][g] = Ym[(long)ell * NP + 16 * g + jj];
+        wv[e] = wk[ell];
+        y0v[e] = Y0k[ell];
+      }
+#pragma unroll 1
+      for (int base = first; base < P; base += 2 * CH) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          const int ell = base + 2 * (CH + e) < P ? base + 2 * (CH + e) : P - 1;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) yn[e][g] = Ym[(long)ell * NP + 16 * g + jj];
+          wn[e] = wk[ell];
+          y0n[e] = Y0k[ell];
+        }
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          if (base + 2 * e < P) {  // (wave-uniform)
+            const double ylo = jr1 ? yv[e][1] : yv[e][0], yhi = jr1 ? yv[e][3] : yv[e][2];
+            const double coef = om * wv[e] * (jr2 ? yhi : ylo);  // 2 c_l Yr[j], c_l = omega w_l / 2
+            beam_sum = fma(coef, y0v[e], beam_sum);
+            RowFmacDpp64<0>::run(acc, yv[e], coef);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) yv[e][g] = yn[e][g];
+          wv[e] = wn[e];
+          y0v[e] = y0n[e];
+        }
+      }
+      beam_sum *= live;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) col[i] = (i == j ? invmu_j : 0.0) - d.S[i] * (live * acc[i]) * S_j;
+    };
+    {
+      double pcol[NP];
+      assemble(id.mg, pcol, xe_sum);  // Pm = M^-1 - S Ae S  (D+/D- split by parity of l - m, :123-125)
+      RTD_ESTAMP(1);
+      dinv[j] = cholesky_columns<NP>(pcol, j);  // Pm = L L^T
+      RTD_ESTAMP(2);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) L_[lix(i, 0) + j] = pcol[i];
+    }
+    double qcol[NP];
+    assemble(id.mg + 1, qcol, xo_sum);  // Qm = M^-1 - S Ao S
+    RTD_ESTAMP(3);
+    cholesky_columns<NP>(qcol, j);  // Qm = R R^T
+    RTD_ESTAMP(4);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      double a = 0.0;
+#pragma unroll
+      for (int r = i; r < NP; ++r) a += L_[lix(r, i)] * qcol[r];
+      w[i] = a;
+    }
   } else {
   // D+/D- split by parity of (l - m): Ae = 2 sum_even c_l Y_l Y_l^T, Ao likewise (:123-125)
   double acc_e[NP], acc_o[NP];
@@ -743,65 +839,6 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
   for (int i = 0; i < NP; ++i) acc_e[i] = acc_o[i] = 0.0;
   double cmax = 0.0;
   const double* Y0b = d.Y0 + ((long)c * d.M + m) * P;  // Ybar_l^m(-mu0): wave-uniform (scalar loads); read only with a beam
-  if constexpr (NP == 64) {
-    // 66 ... 128 streams, one wavefront per SIMD: nothing hides a memory latency there, and the loop below pays one or two per
-    // moment (its 64 wave-uniform table elements arrive by scalar loads the FMAs wait for: 2 300 cycles per moment, s_memtime
-    // stamps).  Here lane jj of every DPP row loads the elements jj, 16 + jj, 32 + jj, 48 + jj of a moment's table row -- eight
-    // moments requested together, one chunk ahead of their use -- and the multiplier of acc[i] reaches its FMA as a DPP row
-    // broadcast of lane i % 16 (one v_fmac_f64_dpp per term, as at 64 streams).
-    typedef const double __attribute__((address_space(4))) kdouble;
-    kdouble* wk = (kdouble*)wl;    // wave-uniform: s_load
-    kdouble* Y0k = (kdouble*)Y0b;
-    const int jj = j & 15;
-    const bool jr1 = (j & 16) != 0, jr2 = (j & 32) != 0;  // the lane's own DPP row: which of its four elements is Yr[j]
-    const int Pn = P;
-    constexpr int CH = 8;
-    double yv[CH][4], yn[CH][4], wv[CH], wn[CH], y0v[CH], y0n[CH];  // (wv, y0v: wave-uniform, they live in SGPRs)
-#pragma unroll
-    for (int e = 0; e < CH; ++e) {
-      const int ell = id.mg + e < P ? id.mg + e : P - 1;  // (clamped, not predicated: no load waits behind a branch)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) yv[e][g] = Ym[(long)ell * NP + 16 * g + jj];
-      wv[e] = wk[ell];
-      y0v[e] = Y0k[ell];  // (allocated with or without a beam; the sums are read only with one)
-    }
-#pragma unroll 1
-    for (int base = id.mg; base < P; base += CH) {
-#pragma unroll
-      for (int e = 0; e < CH; ++e) {
-        const int ell = base + CH + e < P ? base + CH + e : P - 1;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) yn[e][g] = Ym[(long)ell * NP + 16 * g + jj];
-        wn[e] = wk[ell];
-        y0n[e] = Y0k[ell];
-      }
-#pragma unroll
-      for (int e = 0; e < CH; ++e) {
-        const int ell = base + e;
-        if (ell < P) {  // (wave-uniform)
-          const double cl = 0.5 * om * wv[e];
-          cmax = fmax(cmax, fabs(cl));
-          const double ylo = jr1 ? yv[e][1] : yv[e][0], yhi = jr1 ? yv[e][3] : yv[e][2];
-          const double ymine = jr2 ? yhi : ylo;  // Yr[j]
-          const double coef = 2.0 * cl * ymine;
-          if ((e & 1) == 0) {
-            xe_sum = fma(coef, y0v[e], xe_sum);
-            RowFmacDpp64<0>::run(acc_e, yv[e], coef);
-          } else {
-            xo_sum = fma(coef, y0v[e], xo_sum);
-            RowFmacDpp64<0>::run(acc_o, yv[e], coef);
-          }
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < CH; ++e) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) yv[e][g] = yn[e][g];
-        wv[e] = wn[e];
-        y0v[e] = y0n[e];
-      }
-    }
-  } else {
   for (int ell = id.mg; ell < P; ell += 2) {
     {
       const double cl = 0.5 * om * wl[ell];
@@ -821,7 +858,6 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
 #pragma unroll
       for (int i = 0; i < NP; ++i) acc_o[i] += coef * Yr[i];
     }
-  }
   }
   // "shortcut" of the reference when multiple scattering is insignificant (:119, :162-168): the layer
   // is treated as non-scattering; the general path then gives G = [[0,D],[D,0]], k = 1/mu, B = 0.
