@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
 #pragma unroll
     for (int r = 0; r <= i; ++r) a += L_[lix(i, r)] * zc[r];
     aa[i] = a;
-    RTD_FENCE();
+    if (NP != 64 || (i & 7) == 7) RTD_FENCE();  // (NP = 64, one wavefront per SIMD: eight rows between fences, so that their LDS reads overlap)
   }
   if (valid) {
     double* Am = d.Am + base * NP * NP;
