@@ -598,18 +598,17 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
     if ((rc = p->alloc(&p->att_all, C * (L + 1)))) return rc;
     p->tables_cached = true;
   }
-  HIP_TRY(hipMemsetAsync(d.status, 0, sizeof(int), p->stream));
+  // (d.sweeps, d.status, d.split_any and d.Bv, d.dq were carved next to each other: one fill each -- a fill costs ~8 us of host
+  //  time, which a one-column pydisort() call notices)
+  HIP_TRY(hipMemsetAsync(d.sweeps, 0, (size_t)(reinterpret_cast<char*>(d.split_any) - reinterpret_cast<char*>(d.sweeps)) + sizeof(int), p->stream));
   HIP_TRY(hipMemsetAsync(d.col_status, 0, sizeof(int) * (size_t)C, p->stream));
-  HIP_TRY(hipMemsetAsync(d.sweeps, 0, sizeof(int), p->stream));
   if (p->pipelined) {
     p->status2[0] = d.status; p->col_status2[0] = d.col_status; p->sweeps2[0] = d.sweeps;
     HIP_TRY(hipMemsetAsync(p->status2[1], 0, sizeof(int), p->stream));
     HIP_TRY(hipMemsetAsync(p->col_status2[1], 0, sizeof(int) * (size_t)C, p->stream));
     HIP_TRY(hipMemsetAsync(p->sweeps2[1], 0, sizeof(int), p->stream));
   }
-  HIP_TRY(hipMemsetAsync(d.split_any, 0, sizeof(int), p->stream));
-  HIP_TRY(hipMemsetAsync(d.Bv, 0, (size_t)(Cw * M * L * Q2) * 8, p->stream));
-  if (Ns > 0) HIP_TRY(hipMemsetAsync(d.dq, 0, (size_t)(Cw * L * Ns * Q2) * 8, p->stream));
+  HIP_TRY(hipMemsetAsync(d.Bv, 0, (size_t)(reinterpret_cast<char*>(d.dq) - reinterpret_cast<char*>(d.Bv)) + (Ns > 0 ? (size_t)(Cw * L * Ns * Q2) * 8 : 0), p->stream));
   if (p->pipelined) {
     HIP_TRY(hipMemsetAsync(h1.Bv, 0, (size_t)(Cw * M * L * Q2) * 8, p->stream));
     if (Ns > 0) HIP_TRY(hipMemsetAsync(h1.dq, 0, (size_t)(Cw * L * Ns * Q2) * 8, p->stream));
@@ -718,12 +717,18 @@ int rtd_plan_set_quadrature(rtd_plan* p, const double* mu_pos, const double* wei
     }
     im[i] = 1.0 / mu[i];
   }
+  // mu, w, 1/mu, S, T were carved one after the other (plan_build): ONE copy of a host image of that stretch instead of five
+  // (a small copy from pageable memory costs ~5 us of host time: it matters to a one-column pydisort() call)
   const size_t nb = (size_t)NP * 8;
-  HIP_TRY(hipMemcpyAsync((void*)p->d.mu, mu.data(), nb, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipMemcpyAsync((void*)p->d.w, w.data(), nb, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipMemcpyAsync((void*)p->d.invmu, im.data(), nb, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipMemcpyAsync((void*)p->d.S, S.data(), nb, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipMemcpyAsync((void*)p->d.T, T.data(), nb, hipMemcpyHostToDevice, p->stream));
+  const char* base = reinterpret_cast<const char*>(p->d.mu);
+  const size_t span = (size_t)(reinterpret_cast<const char*>(p->d.T) - base) + nb;
+  std::vector<char> img(span, 0);
+  std::memcpy(img.data(), mu.data(), nb);
+  std::memcpy(img.data() + (reinterpret_cast<const char*>(p->d.w) - base), w.data(), nb);
+  std::memcpy(img.data() + (reinterpret_cast<const char*>(p->d.invmu) - base), im.data(), nb);
+  std::memcpy(img.data() + (reinterpret_cast<const char*>(p->d.S) - base), S.data(), nb);
+  std::memcpy(img.data() + (reinterpret_cast<const char*>(p->d.T) - base), T.data(), nb);
+  HIP_TRY(hipMemcpyAsync((void*)p->d.mu, img.data(), span, hipMemcpyHostToDevice, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   p->have_quad = true;
   p->fork_needed = true;
@@ -748,7 +753,19 @@ int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* 
     for (int64_t c = 0; c < C; ++c)
       if (I0[c] > 0.0) return fail(RTD_ERR_ARG, "the plan was created with beam = 0 but a column has I0 > 0");
   hipStream_t s = p->stream;
-#define UP(dst, src, n) HIP_TRY(hipMemcpyAsync((void*)(dst), (src), (size_t)(n) * 8, hipMemcpyHostToDevice, s))
+  // The per-column inputs were carved one after the other, lperm first and the BDRF tables last (plan_build).  A small plan -- a
+  // one-column pydisort() call above all -- gets ONE copy of a host image of that stretch instead of fifteen small ones (~5 us of
+  // host time each from pageable memory); d.col_status lies inside the stretch and is cleared by every solve anyway.
+  const char* in_base = reinterpret_cast<const char*>(d.lperm);
+  const size_t in_span = (size_t)(reinterpret_cast<const char*>(d.bdrfq0) - in_base) + (size_t)std::max<int64_t>(C * NB * NP, 1) * 8;
+  std::vector<char> img;
+  if (in_span <= (size_t)(1u << 20)) img.assign(in_span, 0);
+  const bool one_copy = !img.empty();
+#define UP(dst, src, n)                                                                                              \
+  do {                                                                                                                \
+    if (one_copy) std::memcpy(img.data() + (reinterpret_cast<const char*>(dst) - in_base), (src), (size_t)(n) * 8);   \
+    else HIP_TRY(hipMemcpyAsync((void*)(dst), (src), (size_t)(n) * 8, hipMemcpyHostToDevice, s));                    \
+  } while (0)
   UP(d.omega, scaled_omega, C * L);
   // Layer order of the eigen stage: a wavefront iterates until the slowest of its 64/NP eigenproblems has converged,
   // and the Jacobi sweep count grows with omega* / (1 - g*) (g* = the first scaled moment).  Sorting each column's layers
@@ -766,7 +783,8 @@ int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* 
       for (int64_t l = 0; l < L; ++l) perm[(size_t)(c * L + l)] = key[(size_t)l].second;
     }
   }
-  HIP_TRY(hipMemcpyAsync((void*)d.lperm, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice, s));
+  if (one_copy) std::memcpy(img.data(), perm.data(), perm.size() * sizeof(int));
+  else HIP_TRY(hipMemcpyAsync((void*)d.lperm, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice, s));
   UP(d.tau, tau, C * L);
   UP(d.taus0, taus0, C * (L + 1));
   UP(d.scale, scale_tau, C * L);
@@ -780,9 +798,9 @@ int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* 
   std::vector<double> bp, bn;
   if (N == NP) {
     if (b_pos) UP(d.bpos, b_pos, C * M * NP);
-    else HIP_TRY(hipMemsetAsync((void*)d.bpos, 0, (size_t)(C * M * NP) * 8, s));
+    else if (!one_copy) HIP_TRY(hipMemsetAsync((void*)d.bpos, 0, (size_t)(C * M * NP) * 8, s));  // (the image is zero there)
     if (b_neg) UP(d.bneg, b_neg, C * M * NP);
-    else HIP_TRY(hipMemsetAsync((void*)d.bneg, 0, (size_t)(C * M * NP) * 8, s));
+    else if (!one_copy) HIP_TRY(hipMemsetAsync((void*)d.bneg, 0, (size_t)(C * M * NP) * 8, s));
   } else {
     bp.assign((size_t)(C * M * NP), 0.0);
     bn.assign((size_t)(C * M * NP), 0.0);
@@ -808,6 +826,7 @@ int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* 
     UP(d.bdrfq0, q0.data(), C * NB * NP);
   }
 #undef UP
+  if (one_copy) HIP_TRY(hipMemcpyAsync((void*)d.lperm, img.data(), in_span, hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));  // host staging vectors go out of scope
   p->h_tau.assign(tau, tau + C * L);
   p->ev_iface = false;  // stored evaluation points, if any, are no longer known to be this batch's interfaces
