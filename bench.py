@@ -443,7 +443,7 @@ def many_stream_leg(device, columns=32):
     diff = np.abs(u - want)
     sig = np.abs(want) > 1e-8 * np.max(np.abs(want))
     return {"value": rate, "unit": "column-solves/sec", "columns": columns, "columns_per_window": cw, "windows": nwin,
-            "workload": "128 streams, 50 layers, 64 Fourier modes (Henyey-Greenstein, g up to 0.9, delta-M): rtd_eigen_kernel<64, 2> + rtd_iface_wide_kernel + rtd_sweep_wide_kernel (round 4; 253 col/s on the generic instances of round 3)",
+            "workload": "128 streams, 50 layers, 64 Fourier modes (Henyey-Greenstein, g up to 0.9, delta-M): rtd_eigen_kernel<64, 2> + rtd_iface_mfma_kernel + rtd_sweep_wide_kernel (round 4; 253 col/s on the generic instances of round 3)",
             "parity": {"max_scale_rel": float(diff.max() / np.max(np.abs(want))), "max_rel_dI": float((diff[sig] / np.abs(want[sig])).max()),
                        "columns_checked": 1, "against": "reference-computed golden tests/golden/synth/q128.npz (128 streams, 2 layers, 64 modes)"}}
 

@@ -11,9 +11,9 @@
 // LDS, double buffered: one barrier per step); the pivot row never moves between wavefronts -- each wavefront has its
 // own slice of it in the pivot lane's registers and broadcasts it with v_readlane (SGPR operands of the FMAs).  The
 // products with wave-uniform operands are plain FMAs, one instruction per 64 multiply-adds like an MFMA (FP64 vector and
-// matrix instructions share the DP ALUs on this chip) with no operand staging at all: A^T Y' and Y^T A' of the interface
-// operators take the uniform factor from scalar loads (constant address space: s_load), S Wq and S Wp of the carry as DPP
-// row broadcasts of replicated vector loads (DotBcast16x4 below).  The interface operators are stored TRANSPOSED (lanes = rows contiguous): coalesced stores here,
+// matrix instructions share the DP ALUs on this chip) with no operand staging at all: S Wq and S Wp of the carry take the
+// uniform factor as DPP row broadcasts of replicated vector loads (DotBcast16x4 below).  The interface operators A^T Y' and
+// Y^T A' -- both factors in memory -- are MFMA chains fed by vector loads (rtd_iface_mfma_kernel).  The interface operators are stored TRANSPOSED (lanes = rows contiguous): coalesced stores here,
 // contiguous scalar loads in the carry, coalesced loads in the backward sweep.
 //
 // Pivoting: partial pivoting on float keys exactly as the row-per-lane kernels (rtd_bc_common.h: GjStep); pivot rows are
@@ -61,14 +61,21 @@ struct DotBcast16x4 {
 
 // ------------------------------------------------------------------------------------------------
 // Interface operators: per (c, m, l < L-1) the transposes of Wp, Wq = (A^T Y' +- k Y^T A' / k') / 2 and rho_t, rho_b.
-// Two wavefronts (blocks) per interface, 32 columns each; lane = row.
+// Two wavefronts (workgroups) per interface, 32 columns each, on the matrix cores: both products as v_mfma_f64_16x16x4_f64 chains
+// whose operands are plain vector loads straight from the row-major Y, A of the two layers -- the A operand of a lane (k, m)
+// is element [4 ks + k][16 mt + m] of A_l (or Y_l), the B operand of a lane (k, n) element [4 ks + k][32 h + 16 nt + n] of Y'
+// (or A'): four 128-byte segments per load, 512 distinct bytes per instruction, twelve loads per sixteen MFMAs, the next
+// k-step's operands in flight while this one's are used.  (The first version was a row-per-lane FMA loop whose uniform factors
+// came through scalar loads: the same 64 multiply-adds per instruction slot -- FP64 MFMA and FMA share the DP ALUs -- but eighty
+// SGPRs hold ONE row of operands, and the kernel waited for scalar loads five cycles in six: 4.9 against 2.65 ms per 76 800
+// interfaces, profiles/r04_pmc_many_streams.txt.)  Workgroups go to the eight XCDs round robin and every XCD has its own L2: the two
+// halves of an interface (same A_l, Y_l) and the neighbouring interfaces of a chain (Y', A' of one are Y_l, A_l of the next) are
+// made to meet in ONE L2 by giving XCD x the x-th contiguous eighth of the work items (the grid is rounded up to a multiple of
+// eight workgroups; work items beyond the last interface leave at once).  rho rides along in the first wavefront of an interface.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64, 3) void rtd_iface_wide_kernel(RtdDev d) {
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64, 2) void rtd_iface_mfma_kernel(RtdDev d) {
   const int lane = threadIdx.x;
-  // Workgroups go to the eight XCDs round robin, and every XCD has its own L2: the two halves of an interface (same A_l, Y_l) and
-  // the neighbouring interfaces of a chain (Y', A' of one are Y_l, A_l of the next) are made to meet in ONE L2 by giving XCD x the
-  // x-th contiguous eighth of the work items.
-  // (the grid is rounded up to a multiple of eight workgroups; work items beyond the last interface leave at once)
   const unsigned nb = 2u * (unsigned)d.C * (unsigned)d.M * (unsigned)(d.L - 1), per = gridDim.x / 8;
   const unsigned wi = (blockIdx.x % 8) * per + blockIdx.x / 8;
   if (wi >= nb) return;
@@ -81,15 +88,99 @@ __global__ __launch_bounds__(64, 3) void rtd_iface_wide_kernel(RtdDev d) {
   const long p0 = cm * d.L + l, p1 = p0 + 1;
   const double* A0 = d.Am + p0 * NP * NP;
   const double* Y0 = d.Ym + p0 * NP * NP;
-  kdouble* Y1 = as_k(d.Ym + p1 * NP * NP + 32 * h);
-  kdouble* A1 = as_k(d.Am + p1 * NP * NP + 32 * h);
   double* ws = d.Fws + (cm * Lm1 + l) * W::SLOT;
+  const int k4 = lane >> 4, n16 = lane & 15;
+  const double* a0p = A0 + k4 * NP + n16;                             // + 4 ks NP + 16 mt
+  const double* y0p = Y0 + k4 * NP + n16;
+  const double* y1p = d.Ym + p1 * NP * NP + k4 * NP + 32 * h + n16;   // + 4 ks NP + 16 nt
+  const double* a1p = d.Am + p1 * NP * NP + k4 * NP + 32 * h + n16;
+  v4d_t vv[4][2], uu[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) vv[mt][nt] = uu[mt][nt] = v4d_t{0.0, 0.0, 0.0, 0.0};
+  double ca[4], cy[4], cy1[2], ca1[2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    ca[mt] = a0p[16 * mt];
+    cy[mt] = y0p[16 * mt];
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    cy1[nt] = y1p[16 * nt];
+    ca1[nt] = a1p[16 * nt];
+  }
+#pragma unroll 2
+  for (int ks = 0; ks < 16; ++ks) {
+    const int kn = ks + 1 < 16 ? ks + 1 : ks;
+    double na[4], ny[4], ny1[2], na1[2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      na[mt] = a0p[kn * 4 * NP + 16 * mt];
+      ny[mt] = y0p[kn * 4 * NP + 16 * mt];
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      ny1[nt] = y1p[kn * 4 * NP + 16 * nt];
+      na1[nt] = a1p[kn * 4 * NP + 16 * nt];
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        vv[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[mt], cy1[nt], vv[mt][nt], 0, 0, 0);  // A_l^T Y'
+        uu[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(cy[mt], ca1[nt], uu[mt][nt], 0, 0, 0);  // Y_l^T A'
+      }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      ca[mt] = na[mt];
+      cy[mt] = ny[mt];
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      cy1[nt] = ny1[nt];
+      ca1[nt] = na1[nt];
+    }
+  }
+  // The accumulators: lane (kq, n), register q of tile (mt, nt) = element [16 mt + 4 q + kq][32 h + 16 nt + n].  They are stored
+  // transposed (rows of the stored matrix = columns of W); straight from the registers that is sixteen 32-byte pieces per store
+  // instruction (3.6 ms per 76 800 interfaces, 2.2 with the stores elided), so each matrix crosses LDS once and leaves as 32
+  // full 512-byte rows.
+  {
+    __shared__ double sW[32 * 66];
+    const double* k0p = d.kk + p0 * NP + k4;
+    const double* k1p = d.kk + p1 * NP + 32 * h + n16;
+    const double rk1[2] = {fast_rcp(k1p[0]), fast_rcp(k1p[16])};
+    double k0v[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) k0v[mt][q] = k0p[16 * mt + 4 * q];
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {  // Wp, then Wq
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const double u = uu[mt][nt][q] * (k0v[mt][q] * rk1[nt]);
+            sW[(16 * nt + n16) * 66 + 16 * mt + 4 * q + k4] = 0.5 * (which == 0 ? vv[mt][nt][q] + u : vv[mt][nt][q] - u);
+          }
+      __syncthreads();
+      double* dst = ws + (which == 0 ? W::WP : W::WQ) + (32 * h) * NP + lane;
+#pragma unroll 8
+      for (int cc = 0; cc < 32; ++cc) dst[cc * NP] = sW[cc * 66 + lane];
+      __syncthreads();
+    }
+  }
+  if (h != 0) return;
   // particular-solution jump r_l at the interface (:184-205, :242-245) and rho = G_l^-1 r_l:
   //   rho_t/b = 1/4 [ V^-1 (r_up + r_dn) +- U^-1 (r_up - r_dn) ],  V^-1[j][i] = T_i A[i][j],  U^-1[j][i] = -k_j T_i Y[i][j]
-  // Lane i forms T_i (r_up +- r_dn)[i] once (coalesced loads); the sums over i ride along the main loop below, whose rows of
-  // A_l and Y_l they share (the row-per-lane kernel walked i with dependent loads: one memory latency per row).
+  // lane i forms T_i (r_up +- r_dn)[i] (coalesced loads); lane j then sums over i with its own column of A_l, Y_l (just read above:
+  // cache hits; the row-per-lane kernel of rounds 1-3 walked i with dependent loads, one memory latency per row)
   double rsum = 0.0, rdif = 0.0;
-  if (h == 0) {
+  {
     const double* ts0 = d.taus0 + (long)c * (d.L + 1);
     const double tb = ts0[l + 1];
     const int mg = d.m0 + d.mstep * m;
@@ -113,57 +204,15 @@ __global__ __launch_bounds__(64, 3) void rtd_iface_wide_kernel(RtdDev d) {
     rsum = Ti * (ru + rd);
     rdif = Ti * (ru - rd);
   }
-  double vv[32], uu[32], ra = 0.0, ry = 0.0;
-#pragma unroll
-  for (int cc = 0; cc < 32; ++cc) vv[cc] = uu[cc] = 0.0;
-  // the lane's own column of A_l and Y_l four rows ahead (the loads of a chunk are in flight while the previous one is used; eight
-  // rows ahead cost 48 more registers and the third wavefront per SIMD: 7.9 against 5.1 ms per 51 200 interfaces)
-  constexpr int CH = 4;
-  double a[CH], y[CH];
-#pragma unroll
-  for (int e = 0; e < CH; ++e) {
-    a[e] = A0[e * NP + lane];
-    y[e] = Y0[e * NP + lane];
+  double ra = 0.0, ry = 0.0;
+#pragma unroll 16
+  for (int i = 0; i < NP; ++i) {
+    ra = fma(A0[i * NP + lane], readlane_f64(rsum, i), ra);
+    ry = fma(Y0[i * NP + lane], readlane_f64(rdif, i), ry);
   }
-#pragma unroll 1
-  for (int i0 = 0; i0 < NP; i0 += CH) {
-    double an[CH], yn[CH];
-    const int in = i0 + CH < NP ? i0 + CH : i0;
-#pragma unroll
-    for (int e = 0; e < CH; ++e) {
-      an[e] = A0[(in + e) * NP + lane];
-      yn[e] = Y0[(in + e) * NP + lane];
-    }
-#pragma unroll
-    for (int e = 0; e < CH; ++e) {
-#pragma unroll
-      for (int cc = 0; cc < 32; ++cc) vv[cc] = fma(a[e], Y1[(i0 + e) * NP + cc], vv[cc]);
-#pragma unroll
-      for (int cc = 0; cc < 32; ++cc) uu[cc] = fma(y[e], A1[(i0 + e) * NP + cc], uu[cc]);
-      ra = fma(a[e], readlane_f64(rsum, i0 + e), ra);
-      ry = fma(y[e], readlane_f64(rdif, i0 + e), ry);
-    }
-#pragma unroll
-    for (int e = 0; e < CH; ++e) {
-      a[e] = an[e];
-      y[e] = yn[e];
-    }
-  }
-  const double k0 = d.kk[p0 * NP + lane];
-  {
-    kdouble* k1 = as_k(d.kk + p1 * NP + 32 * h);
-#pragma unroll
-    for (int cc = 0; cc < 32; ++cc) {
-      const double u = uu[cc] * (k0 * fast_rcp(k1[cc]));
-      ws[W::WP + (32 * h + cc) * NP + lane] = 0.5 * (vv[cc] + u);
-      ws[W::WQ + (32 * h + cc) * NP + lane] = 0.5 * (vv[cc] - u);
-    }
-  }
-  if (h == 0) {
-    const double bb = -k0 * ry;
-    ws[W::RT + lane] = 0.25 * (ra + bb);
-    ws[W::RB + lane] = 0.25 * (ra - bb);
-  }
+  const double bb = -d.kk[p0 * NP + lane] * ry;
+  ws[W::RT + lane] = 0.25 * (ra + bb);
+  ws[W::RB + lane] = 0.25 * (ra - bb);
 }
 
 // max of a non-negative float key over the wavefront, in every lane's SGPR view (DPP only: quad permutes, row mirrors, then the
@@ -197,7 +246,7 @@ __device__ __forceinline__ void gj_wide(double (&ta)[16], double (&tb)[16], doub
       const int buf = qo & 1;
       if constexpr (kk == 12) {
         // the carry that follows reads Wq, Wp of this interface with scalar loads: bring their 512 cache lines into the L2 now
-        // (two per thread, vector loads; see rtd_iface_wide_kernel)
+        // (two per thread, vector loads)
         if (touch_at != nullptr && qo == 0) {
           touched[0] = touch_at[threadIdx.x * 16];
           touched[1] = touch_at[(threadIdx.x + 256) * 16];
@@ -505,6 +554,6 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
 
 void rtd_launch_bc_wide(const RtdDev& d, hipStream_t s, int part) {
   const long nif = (long)d.C * d.M * (d.L - 1);
-  if (part == 0 && nif > 0) hipLaunchKernelGGL(rtd_iface_wide_kernel, dim3((unsigned)((2 * nif + 7) / 8 * 8)), dim3(64), 0, s, d);
+  if (part == 0 && nif > 0) hipLaunchKernelGGL(rtd_iface_mfma_kernel, dim3((unsigned)((2 * nif + 7) / 8 * 8)), dim3(64), 0, s, d);
   if (part == 1) hipLaunchKernelGGL(rtd_sweep_wide_kernel, dim3((unsigned)((long)d.C * d.M)), dim3(256), 0, s, d);
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Stage times of the 66 ... 128-stream path (NP = 64 instances: rtd_eigen_kernel<64, 2>, rtd_iface_wide_kernel,
+"""Stage times of the 66 ... 128-stream path (NP = 64 instances: rtd_eigen_kernel<64, 2>, rtd_iface_mfma_kernel,
 rtd_sweep_wide_kernel, rtd_eval_kernel<64>) on synthetic Henyey-Greenstein columns -- diagnostic, not bench.py.
 Usage: python tools/many_stream_timing.py [columns]      (RTD_BC_WIDE_V1=1: the row-per-lane BC kernels of rounds 1-3)
 Prints, per configuration (NQuad, layers, Fourier modes, columns), the plan's per-stage HIP-event times in ms and columns/s."""
