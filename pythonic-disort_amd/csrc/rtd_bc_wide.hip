@@ -9,12 +9,17 @@
 // columns 4 i + q (i < 16) of the row's Ta and Tb parts in registers, so a pivot step costs every wavefront the same
 // work whatever the column.  What crosses wavefronts in the elimination is ONE column per pivot step (64 doubles through
 // LDS, double buffered: one barrier per step); the pivot row never moves between wavefronts -- each wavefront has its
-// own slice of it in the pivot lane's registers and broadcasts it with v_readlane (SGPR operands of the FMAs).  The
-// products with wave-uniform operands are plain FMAs, one instruction per 64 multiply-adds like an MFMA (FP64 vector and
-// matrix instructions share the DP ALUs on this chip) with no operand staging at all: S Wq and S Wp of the carry take the
-// uniform factor as DPP row broadcasts of replicated vector loads (DotBcast16x4 below).  The interface operators A^T Y' and
-// Y^T A' -- both factors in memory -- are MFMA chains fed by vector loads (rtd_iface_mfma_kernel).  The interface operators are stored TRANSPOSED (lanes = rows contiguous): coalesced stores here,
-// contiguous scalar loads in the carry, coalesced loads in the backward sweep.
+// own slice of it in the pivot lane's registers and broadcasts it with v_readlane (SGPR operands of the FMAs).
+//
+// The matrix products run on the matrix cores with their operands where they already are: the interface operators A^T Y'
+// and Y^T A' (both factors in memory, rtd_iface_mfma_kernel: vector loads straight from the row-major Y, A in the operand
+// layout) and S Wq, S Wp of the carry (S from LDS, the rows of the stored transposes by vector loads, all in flight before
+// the first MFMA; the products cross LDS back into the rows-on-lanes layout of the elimination).  Earlier forms, measured
+// and replaced in this order: plain FMAs with the uniform factor from scalar loads (eighty SGPRs hold one row of operands:
+// bound by the latency of the scalar loads), the same with the factor as a DPP row broadcast of replicated vector loads
+// (one load per sixteen FMAs; better, still latency-bound at three wavefronts per SIMD) -- DESIGN.md section 8.
+// The interface operators are stored TRANSPOSED (lanes = rows contiguous): coalesced row stores in the interface kernel,
+// coalesced loads in the carry's final step and in the backward sweep.
 //
 // Pivoting: partial pivoting on float keys exactly as the row-per-lane kernels (rtd_bc_common.h: GjStep); pivot rows are
 // left unscaled and scaled once at the end of an elimination (the scaling commutes with the later eliminations of that
@@ -39,25 +44,6 @@ __device__ __forceinline__ kdouble* as_k(const double* p) { return (kdouble*)(p)
 __device__ __forceinline__ double readlane_f64(const double v, const int lane) {  // lane: wave-uniform
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
-
-// Wave-uniform factors as DPP row broadcasts of replicated vector loads: u is loaded so that lane t of EVERY 16-lane DPP row holds
-// the t-th of sixteen consecutive wave-uniform operands (address from lane & 15 only); `v_fmac_f64_dpp acc, u, s row_newbcast:T`
-// then multiplies the lane's own s by the T-th operand.  One vector load feeds sixteen FMAs and each FMA is ONE instruction -- no
-// SGPRs (eighty of them hold 160 cycles of operands: the scalar-load form of the carry was bound by the latency of the L2), no
-// v_readlane; vector loads take as many in flight as there are registers for them.
-// Four dot products of sixteen terms each, interleaved (four independent accumulation chains):
-//   q0 += sum_T bcast_T(uq0) s[T], p0 += sum_T bcast_T(up0) s[T], q1 += sum_T bcast_T(uq1) s[16 + T], p1 += sum_T bcast_T(up1) s[16 + T]
-template <int T>
-struct DotBcast16x4 {
-  static __device__ __forceinline__ void run(double& q0, double& p0, double& q1, double& p1, const double uq0, const double up0,
-                                             const double uq1, const double up1, const double (&s)[32]) {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(q0) : "v"(uq0), "v"(s[T]), "n"(T));
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(p0) : "v"(up0), "v"(s[T]), "n"(T));
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(q1) : "v"(uq1), "v"(s[16 + T]), "n"(T));
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(p1) : "v"(up1), "v"(s[16 + T]), "n"(T));
-    if constexpr (T + 1 < 16) DotBcast16x4<T + 1>::run(q0, p0, q1, p1, uq0, up0, uq1, up1, s);
-  }
-};
 
 // ------------------------------------------------------------------------------------------------
 // Interface operators: per (c, m, l < L-1) the transposes of Wp, Wq = (A^T Y' +- k Y^T A' / k') / 2 and rho_t, rho_b.
@@ -359,48 +345,77 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
 #pragma unroll
     for (int i = 0; i < 16; ++i) ws[W::S + (4 * i + q) * NP + pc] = tb[i];  // S^T for the backward sweep
     if (q == 0) ws[W::SV + pc] = tt;
-    __syncthreads();
-    const double Er = Ek[l * NP + pc];
-    kdouble* e1 = as_k(Ek + (l + 1) * NP);
-    // S Wq and S Wp, the lane's row of S half at a time (32 registers instead of 64: three chains per CU), accumulated in ta, tb
-    double srb = 0.0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) ta[i] = tb[i] = 0.0;
-#pragma unroll 1
-    for (int kh = 0; kh < NP; kh += 32) {
-      double srow[32];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) srow[k] = sS[pc * LDS_LD + kh + k];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) srb = fma(srow[k], wk[W::RB + kh + k], srb);  // (S rho_b)[pc]
-      // (column cc of Wq, Wp = row cc of the stored transposes: sixteen consecutive elements per vector load, replicated over the
-      //  DPP rows; see FmacBcast16)
-#pragma unroll 4
-      for (int i = 0; i < 16; ++i) {
-        const double* wqg = ws + W::WQ + (4 * i + q) * NP + kh + (lane & 15);
-        const double* wpg = ws + W::WP + (4 * i + q) * NP + kh + (lane & 15);
-        const double wq0 = wqg[0], wq1 = wqg[16], wp0 = wpg[0], wp1 = wpg[16];
-        double swq0 = 0.0, swq1 = 0.0, swp0 = 0.0, swp1 = 0.0;
-        DotBcast16x4<0>::run(swq0, swp0, swq1, swp1, wq0, wp0, wq1, wp1, srow);
-        ta[i] += swq0 + swq1;
-        tb[i] += swp0 + swp1;
-      }
-    }
+    // ---- carry: P = S Wq, R = S Wp on the matrix cores.  Wavefront q forms the columns [16 q, 16 q + 16) of both: the A operand
+    // of a lane (k, m) is S[16 mt + m][4 ks + k] from LDS, the B operand of a lane (k, n) element [16 q + n][4 ks + k] of the stored
+    // transposes -- all 32 operand loads of the wavefront in flight before the first MFMA.  The products then cross LDS (the S
+    // area, free by then) into the rows-on-lanes layout of the elimination; from here on lane j holds row j.
+    // (the lane's indices go through an opaque copy per layer: with loop-invariant indices the 64-bit addresses of the 64 loads
+    //  below are hoisted out of the layer loop -- 64 registers' worth, spilled and reloaded every layer)
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int k4 = lane_o >> 4, n16 = lane_o & 15, jo = lane_o;
+    double bq[16], bp[16];
     {
-      // Ta' = -(E S Wq + Wp), Tb' = -(E S Wp + Wq) E': the row pc of Wp, Wq are this lane's own loads, all in flight at once
-      double wpr[16], wqr[16];
+      const double* wqg = ws + W::WQ + (16 * q + n16) * NP + k4;
+      const double* wpg = ws + W::WP + (16 * q + n16) * NP + k4;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        wpr[i] = ws[W::WP + (4 * i + q) * NP + pc];
-        wqr[i] = ws[W::WQ + (4 * i + q) * NP + pc];
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        ta[i] = -(Er * ta[i] + wpr[i]);
-        tb[i] = -(Er * tb[i] + wqr[i]) * e1[4 * i + q];
+      for (int ks = 0; ks < 16; ++ks) {
+        bq[ks] = wqg[4 * ks];
+        bp[ks] = wpg[4 * ks];
       }
     }
-    const double tnew = ws[W::RT + pc] - Er * (tt - srb);
+    {  // (S rho_b)[pc] over this wavefront's columns, and s, by true row index for the lanes that will hold those rows
+      double part = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) part = fma(tb[i], wk[W::RB + 4 * i + q], part);
+      sRed[0][q][pc] = part;
+      if (q == 0) sV[0][pc] = tt;
+    }
+    __syncthreads();  // S (and the partial sums) complete
+    v4d_t accP[4], accR[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) accP[mt] = accR[mt] = v4d_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      double a[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) a[mt] = sS[(16 * mt + n16) * LDS_LD + 4 * ks + k4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        accP[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], bq[ks], accP[mt], 0, 0, 0);
+        accR[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], bp[ks], accR[mt], 0, 0, 0);
+      }
+    }
+    const double Er = Ek[l * NP + j];
+    const double srb = (sRed[0][0][j] + sRed[0][1][j]) + (sRed[0][2][j] + sRed[0][3][j]);
+    const double tnew = ws[W::RT + j] - Er * (sV[0][j] - srb);
+    kdouble* e1 = as_k(Ek + (l + 1) * NP);
+    // the row j of Wp, Wq: this lane's own loads (coalesced), in flight across the exchange (the fence keeps the scheduler from
+    // hoisting them over the MFMA chain, where there are no registers for them: it spilled all 32)
+    RTD_FENCE();
+    double wpr[16], wqr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      wpr[i] = ws[W::WP + (4 * i + q) * NP + jo];
+      wqr[i] = ws[W::WQ + (4 * i + q) * NP + jo];
+    }
+    __syncthreads();  // every wavefront has read its A operands: the S area is free
+    // accumulator register r of tile mt, lane (kq, n): element [16 mt + 4 r + kq][16 q + n]
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sS[(16 * mt + 4 * r + k4) * LDS_LD + 16 * q + n16] = accP[mt][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ta[i] = -(Er * sS[j * LDS_LD + 4 * i + q] + wpr[i]);  // Ta' = -(E S Wq + Wp)
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sS[(16 * mt + 4 * r + k4) * LDS_LD + 16 * q + n16] = accR[mt][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tb[i] = -(Er * sS[j * LDS_LD + 4 * i + q] + wqr[i]) * e1[4 * i + q];  // Tb' = -(E S Wp + Wq) E'
     tt = tnew;
     if (touched[0] == 1.2345e-300 && touched[1] == 1.2345e-300) tt += touched[0];  // (never: keeps the touching loads alive)
   }
