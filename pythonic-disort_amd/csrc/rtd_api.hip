@@ -629,7 +629,7 @@ int rtd_plan_create_windowed(const rtd_dims* dims, int32_t device, int32_t work_
   if (dims->ncols < 1 || dims->nlayers < 1 || dims->nquad < 2 || (dims->nquad & 1) || dims->nleg < 1 ||
       dims->nfourier < 1 || dims->nfourier > dims->nleg || dims->nscoeffs < 0 || dims->nbdrf < 0)
     return fail(RTD_ERR_ARG, "invalid dimensions");
-  // 2 ... 64 streams: the tuned kernels; 66 ... 128 streams: the generic instances (one problem / one chain per wavefront)
+  // 2 ... 64 streams; 66 ... 128 streams: one eigenproblem per wavefront, one boundary-condition chain per workgroup (rtd_bc_wide.hip)
   if (N > 64) return fail(RTD_ERR_ARG, "NQuad > 128 is not supported by this build (N = NQuad/2 <= 64)");
   HIP_TRY(hipSetDevice(device));
   rtd_plan* p = new rtd_plan();

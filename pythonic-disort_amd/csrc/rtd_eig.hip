@@ -1233,7 +1233,7 @@ void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part) {
       else hipLaunchKernelGGL((rtd_eigen_kernel<16, 2>), grid, dim3(64), 0, s, d);
       break;
     RTD_EIG_CASE(32)
-    RTD_EIG_CASE(64)  // 66 ... 128 streams: the generic column-per-lane form, one problem per wavefront (correct, not tuned)
+    RTD_EIG_CASE(64)  // 66 ... 128 streams: one problem per wavefront (round 4: parity-at-a-time DPP assembly, readlane Cholesky)
     default: break;
   }
 #undef RTD_EIG_CASE

@@ -148,7 +148,7 @@ def pydisort(
         raise ValueError("The fractional scattering must be between 0 and 1.")
     if not use_banded_solver_NLayers >= 3:
         raise ValueError("The minimum threshold `use_banded_solver_NLayers` is 3, else the matrix will not be banded.")
-    if NQuad > 128:  # (66 ... 128 streams run on generic, untuned kernel instances)
+    if NQuad > 128:  # (66 ... 128 streams: the NP = 64 kernels, csrc/rtd_bc_wide.hip and rtd_eigen_kernel<64, 2>)
         raise ValueError("This build supports at most 128 streams (NQuad <= 128).")
 
     mu_pos, W = double_gauss(N)

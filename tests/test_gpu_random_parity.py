@@ -327,7 +327,7 @@ def test_thermal_polynomial_in_a_near_conservative_thin_layer_is_as_good_as_the_
 
 
 def make_case_128_streams(seed):
-    """Cases beyond 64 streams (66 <= NQuad <= 128, N = 33..64 padded to 64 lanes: the generic kernel instances, one
+    """Cases beyond 64 streams (66 <= NQuad <= 128, N = 33..64 padded to 64 lanes: the NP = 64 kernels, one
     eigenproblem / one chain per wavefront): 1-4 layers, omega <= 0.995 (no near-conservative layer: a 40-digit arbitration
     at these sizes takes hours), delta-M, beam / thermal / surface / Dirichlet sources mixed, few Fourier modes for most
     seeds and up to 40 for some (the reference's Legendre tables overflow beyond l + m ~ 170)."""
