@@ -495,6 +495,94 @@ struct PairStep<NP, NP - 1> {  // the last step of a sweep is step NP - 2
   static __device__ __forceinline__ void run(double (&)[NP / 2], double (&)[NP / 2], double&, double&, int&, int&, const int, int&) {}
 };
 
+#ifndef RTD_JAC_FAST
+#define RTD_JAC_FAST 1  /* NP >= 32: scaled ("fast") rotations in the pair-layout sweeps, see FastPairStep */
+#endif
+// The same step with SCALED rotations, for NP >= 32.  The lane keeps its halves of the two columns as x = sx xs, y = sy ys (xs, ys
+// stored, sx, sy per-column scalars) and applies (x, y) <- c (x - t y, y + t x) as
+//     xs <- xs - (t sy / sx) ys,   ys <- ys + (t sx / sy) xs,   sx <- c sx,   sy <- c sy :
+// TWO FMAs per element pair instead of mul + fma twice -- NP instructions less per step for ~14 of scale bookkeeping (1 / sx,
+// 1 / sy are carried along, multiplied by 1 / c = (1 + t^2) c; the scales of the column that moves on move with it).  At NP = 16
+// that is no gain (16 against 11 + moves, measured in round 3); at NP = 32 it is 18 of ~150 instructions per step, at NP = 64
+// 50 of ~267.  The scales are folded back into the columns after every sweep (2 multiplications per element), so they stay
+// within 2^-(NP/2) and sx (1 / sx) drifts by no more than NP - 1 roundings.  The steps that hand on X instead of Y (one per level
+// of the butterfly) keep the general two-coefficient form.
+template <int NP, int S>
+struct FastPairStep {
+  static constexpr int H = NP / 2;
+  static __device__ __forceinline__ void run(double (&xh)[H], double (&yh)[H], double& ax, double& ay, int& ix, int& iy,
+                                             const int p, int& notconv, double& sx, double& sy, double& rx, double& ry) {
+    constexpr JSched<NP> sched{};
+    constexpr int SW = sched.sw[S], MK = sched.mk[S];
+    double g0 = 0.0, g1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < H; i += 2) {
+      g0 = fma(xh[i], yh[i], g0);
+      g1 = fma(xh[i + 1], yh[i + 1], g1);
+    }
+    const double gp = g0 + g1;
+    const double gamma = (gp + xor_lane<H>(gp)) * (sx * sy);  // the inner product of the two columns themselves
+    const double delta = ay - ax;
+    const double g2 = 2.0 * gamma;
+    // (the angle from float arithmetic: see PairStep)
+    const float df = (float)delta, gf = (float)g2;
+    const float r2f = fmaf(df, df, fmaf(gf, gf, 1e-36f));
+    const float rhof = r2f * __builtin_amdgcn_rsqf(r2f);
+    const float denf = df + copysignf(rhof, df);
+    const double tt = (double)(gf * __builtin_amdgcn_rcpf(denf));
+    const double t2 = fma(tt, tt, 1.0);
+    // c to full precision here (two Newton steps): sx and 1 / sx are carried separately, and an error e of c makes their product
+    // drift by 2 e per rotation -- with the one-step c of PairStep (4e-15) the ratio sy / sx was 2e-13 off by the end of a sweep
+    // and the rotations that much off orthogonal (the fused / general evaluation paths then differed by 3e-11 instead of 1.4e-11)
+    const double c = fast_rsqrt(t2);
+    const double cinv = t2 * c;
+    notconv |= (gamma * gamma > RTD_JAC_TOL * ax * ay) ? 1 : 0;
+    const double nax = fma(-tt, gamma, ax), nay = fma(tt, gamma, ay);
+    const double a = -tt * (sy * rx), b = tt * (sx * ry);  // xs <- xs + a ys, ys <- ys + b xs
+    const double nsx = c * sx, nsy = c * sy, nrx = cinv * rx, nry = cinv * ry;
+    if constexpr (SW == 0) {
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
+        const double xi = xh[i], yi = yh[i];
+        xh[i] = fma(a, yi, xi);
+        yh[i] = xor_lane<MK>(fma(b, xi, yi));
+      }
+      ax = nax;
+      ay = xor_lane<MK>(nay);
+      sx = nsx;
+      rx = nrx;
+      sy = xor_lane<MK>(nsy);
+      ry = xor_lane<MK>(nry);
+    } else {
+      // the slots with (p & SW) write the rotated pair the other way round: (xs, ys) <- (ys + b xs, xs + a ys)
+      const bool swp = (p & SW) != 0;
+      const double pxx = swp ? b : 1.0, pxy = swp ? 1.0 : a, pyx = swp ? 1.0 : b, pyy = swp ? a : 1.0;
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
+        const double xi = xh[i], yi = yh[i];
+        xh[i] = fma(pxy, yi, pxx * xi);
+        yh[i] = xor_lane<MK>(fma(pyy, yi, pyx * xi));
+      }
+      ax = swp ? nay : nax;
+      ay = xor_lane<MK>(swp ? nax : nay);
+      sx = swp ? nsy : nsx;
+      rx = swp ? nry : nrx;
+      sy = xor_lane<MK>(swp ? nsx : nsy);
+      ry = xor_lane<MK>(swp ? nrx : nry);
+      const int t = swp ? iy : ix;
+      iy = swp ? ix : iy;
+      ix = t;
+    }
+    iy = xor_lane_i<MK>(iy);
+    FastPairStep<NP, S + 1>::run(xh, yh, ax, ay, ix, iy, p, notconv, sx, sy, rx, ry);
+  }
+};
+template <int NP>
+struct FastPairStep<NP, NP - 1> {
+  static __device__ __forceinline__ void run(double (&)[NP / 2], double (&)[NP / 2], double&, double&, int&, int&, const int, int&,
+                                             double&, double&, double&, double&) {}
+};
+
 // ------------------------------------------------------------------------------------------------
 // Fused eigen stage: assembly, Cholesky factors, one-sided Jacobi and the eigenvector /
 // particular-solution stage in ONE kernel per (c, m, l).  F, L, Qm and k Z never leave the CU (registers + LDS):
@@ -918,7 +1006,17 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
       }
       ax += xor_lane<H>(ax);
       ay += xor_lane<H>(ay);
-      PairStep<NP, 0>::run(xh, yh, ax, ay, ix, iy, p, notconv);
+      if constexpr (RTD_JAC_FAST && NP >= 32) {
+        double sx = 1.0, sy = 1.0, rx = 1.0, ry = 1.0;
+        FastPairStep<NP, 0>::run(xh, yh, ax, ay, ix, iy, p, notconv, sx, sy, rx, ry);
+#pragma unroll
+        for (int i = 0; i < H; ++i) {  // the scales back into the columns
+          xh[i] *= sx;
+          yh[i] *= sy;
+        }
+      } else {
+        PairStep<NP, 0>::run(xh, yh, ax, ay, ix, iy, p, notconv);
+      }
       ++nsweep;
       if (!__any(notconv)) {
         converged = true;
