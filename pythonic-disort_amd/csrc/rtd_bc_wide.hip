@@ -60,6 +60,7 @@ __device__ __forceinline__ double readlane_f64(const double v, const int lane) {
 // eight workgroups; work items beyond the last interface leave at once).  rho rides along in the first wavefront of an interface.
 // ------------------------------------------------------------------------------------------------
 typedef double v4d_t __attribute__((ext_vector_type(4)));
+template <int NCI>  // carried columns: 64, or 48 at 66 ... 96 streams (see below)
 __global__ __launch_bounds__(64, 2) void rtd_iface_mfma_kernel(RtdDev d) {
   const int lane = threadIdx.x;
   const unsigned nb = 2u * (unsigned)d.C * (unsigned)d.M * (unsigned)(d.L - 1), per = gridDim.x / 8;
@@ -75,6 +76,10 @@ __global__ __launch_bounds__(64, 2) void rtd_iface_mfma_kernel(RtdDev d) {
   const double* A0 = d.Am + p0 * NP * NP;
   const double* Y0 = d.Ym + p0 * NP * NP;
   double* ws = d.Fws + (cm * Lm1 + l) * W::SLOT;
+  // 66 ... 96 streams (N <= 48): the streams 48 ... 63 are padding that decouples exactly -- their rows of Y, A contribute nothing to
+  // the real columns of the products and their columns are never read (the sweep kernel's NI = 12 instance): twelve k-steps instead of
+  // sixteen, three column tiles instead of four
+  constexpr int nc = NCI;
   const int k4 = lane >> 4, n16 = lane & 15;
   const double* a0p = A0 + k4 * NP + n16;                             // + 4 ks NP + 16 mt
   const double* y0p = Y0 + k4 * NP + n16;
@@ -96,9 +101,11 @@ __global__ __launch_bounds__(64, 2) void rtd_iface_mfma_kernel(RtdDev d) {
     cy1[nt] = y1p[16 * nt];
     ca1[nt] = a1p[16 * nt];
   }
+  constexpr int nks = nc / 4;
+  const bool tile1 = nc == NP || 32 * h + 16 < nc;  // the second column tile of this half exists
 #pragma unroll 2
-  for (int ks = 0; ks < 16; ++ks) {
-    const int kn = ks + 1 < 16 ? ks + 1 : ks;
+  for (int ks = 0; ks < nks; ++ks) {
+    const int kn = ks + 1 < nks ? ks + 1 : ks;
     double na[4], ny[4], ny1[2], na1[2];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -111,12 +118,17 @@ __global__ __launch_bounds__(64, 2) void rtd_iface_mfma_kernel(RtdDev d) {
       na1[nt] = a1p[kn * 4 * NP + 16 * nt];
     }
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt) {
+      vv[mt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[mt], cy1[0], vv[mt][0], 0, 0, 0);  // A_l^T Y'
+      uu[mt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(cy[mt], ca1[0], uu[mt][0], 0, 0, 0);  // Y_l^T A'
+    }
+    if (tile1) {
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        vv[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[mt], cy1[nt], vv[mt][nt], 0, 0, 0);  // A_l^T Y'
-        uu[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(cy[mt], ca1[nt], uu[mt][nt], 0, 0, 0);  // Y_l^T A'
+      for (int mt = 0; mt < 4; ++mt) {
+        vv[mt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[mt], cy1[1], vv[mt][1], 0, 0, 0);
+        uu[mt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(cy[mt], ca1[1], uu[mt][1], 0, 0, 0);
       }
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       ca[mt] = na[mt];
@@ -155,8 +167,9 @@ __global__ __launch_bounds__(64, 2) void rtd_iface_mfma_kernel(RtdDev d) {
           }
       __syncthreads();
       double* dst = ws + (which == 0 ? W::WP : W::WQ) + (32 * h) * NP + lane;
+      const int ncc = nc - 32 * h < 32 ? nc - 32 * h : 32;
 #pragma unroll 8
-      for (int cc = 0; cc < 32; ++cc) dst[cc * NP] = sW[cc * 66 + lane];
+      for (int cc = 0; cc < ncc; ++cc) dst[cc * NP] = sW[cc * 66 + lane];
       __syncthreads();
     }
   }
@@ -220,17 +233,17 @@ __device__ __forceinline__ float wave_max_key(float v) {
 // Gauss-Jordan with partial pivoting on the rows [Ta | Tb | t] of a chain, four wavefronts (see the header).  On exit the
 // lane that owned pivot column `pc` holds its slice of row pc of Ta^-1 Tb in tb[] and (Ta^-1 t)[pc] in tt.
 // ------------------------------------------------------------------------------------------------
-template <bool WITH_TB>
-__device__ __forceinline__ void gj_wide(double (&ta)[16], double (&tb)[16], double& tt, int& pc, const int lane, const int q,
+template <bool WITH_TB, int NI>
+__device__ __forceinline__ void gj_wide(double (&ta)[NI], double (&tb)[NI], double& tt, int& pc, const int lane, const int q,
                                         double (*sCol)[NP], int* sFound, double* sPiv, const double* touch_at, double (&touched)[2]) {
   pc = -1;
   double myrp = 1.0;
-  static_for<0, 16>([&](auto kc) {
+  static_for<0, NI>([&](auto kc) {
     constexpr int kk = decltype(kc)::value;
 #pragma unroll 1
     for (int qo = 0; qo < 4; ++qo) {  // pivot column K = 4 kk + qo: register kk of wavefront qo
       const int buf = qo & 1;
-      if constexpr (kk == 12) {
+      if constexpr (kk == NI - 4) {
         // the carry that follows reads Wq, Wp of this interface with scalar loads: bring their 512 cache lines into the L2 now
         // (two per thread, vector loads)
         if (touch_at != nullptr && qo == 0) {
@@ -262,17 +275,17 @@ __device__ __forceinline__ void gj_wide(double (&ta)[16], double (&tb)[16], doub
         myrp = rp;
       }
 #pragma unroll
-      for (int i = kk; i < 16; ++i) ta[i] = fma(-f, readlane_f64(ta[i], src), ta[i]);  // (columns up to K are dead)
+      for (int i = kk; i < NI; ++i) ta[i] = fma(-f, readlane_f64(ta[i], src), ta[i]);  // (columns up to K are dead)
       if constexpr (WITH_TB) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) tb[i] = fma(-f, readlane_f64(tb[i], src), tb[i]);
+        for (int i = 0; i < NI; ++i) tb[i] = fma(-f, readlane_f64(tb[i], src), tb[i]);
       }
       tt = fma(-f, readlane_f64(tt, src), tt);
     }
   });
   if constexpr (WITH_TB) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tb[i] *= myrp;
+    for (int i = 0; i < NI; ++i) tb[i] *= myrp;
   }
   tt *= myrp;
 }
@@ -283,7 +296,13 @@ __device__ __forceinline__ void gj_wide(double (&ta)[16], double (&tb)[16], doub
 #ifndef RTD_WIDE_WG
 #define RTD_WIDE_WG 3  /* workgroups (chains) per CU the sweep kernel is built for: 3 = 168 registers, 49 KB of LDS */
 #endif
+// NI: registers per lane and wavefront for each of Ta, Tb = a quarter of the columns that are carried: 16 (98 ... 128 streams) or 12
+// (66 ... 96 streams, N <= 48: the padding streams 48 ... 63 decouple exactly; their rows are zero in every carried column, never
+// pivot and keep their lanes, their columns are left out: 48 pivot steps of 25 elements instead of 64 of 33, twelve k-steps and three
+// column tiles in the carry).
+template <int NI>
 __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev d) {
+  constexpr int NC = 4 * NI, NT = NC / 16;  // carried columns, 16-column tiles
   __shared__ double sS[NP * LDS_LD];   // S at its true row index
   __shared__ double sQ[NP * 17];       // bottom boundary: a quarter of the rows of Ba at a time
   __shared__ double sCol[2][NP];
@@ -320,9 +339,9 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
   };
 
   // carry rows Ta C- + Tb C+ = t, top boundary (:161-179, :284-285): Ta = Gm_0, Tb = Gp_0 E_0
-  double ta[16], tb[16], tt;
+  double ta[NI], tb[NI], tt;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int k = 4 * i + q;
     const double yv = Ym[j * NP + k], av = Am[j * NP + k] / kk[k];
     ta[i] = (yv + av) * rTj;
@@ -335,15 +354,15 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
   int pc = -1;
   for (int l = 0; l < L; ++l) {
     double touched[2] = {0.0, 0.0};
-    gj_wide<true>(ta, tb, tt, pc, lane, q, sCol, sFound, sPiv, l < Lm1 ? wsb + (long)l * W::SLOT : nullptr, touched);
+    gj_wide<true, NI>(ta, tb, tt, pc, lane, q, sCol, sFound, sPiv, l < Lm1 ? wsb + (long)l * W::SLOT : nullptr, touched);
     if (pc < 0) pc = j;  // (a chain that has gone NaN finds no pivots: keep the stores inside the chain's own rows)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sS[pc * LDS_LD + 4 * i + q] = tb[i];
+    for (int i = 0; i < NI; ++i) sS[pc * LDS_LD + 4 * i + q] = tb[i];
     if (l == Lm1) break;
     double* ws = wsb + (long)l * W::SLOT;
     kdouble* wk = as_k(ws);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ws[W::S + (4 * i + q) * NP + pc] = tb[i];  // S^T for the backward sweep
+    for (int i = 0; i < NI; ++i) ws[W::S + (4 * i + q) * NP + pc] = tb[i];  // S^T for the backward sweep
     if (q == 0) ws[W::SV + pc] = tt;
     // ---- carry: P = S Wq, R = S Wp on the matrix cores.  Wavefront q forms the columns [16 q, 16 q + 16) of both: the A operand
     // of a lane (k, m) is S[16 mt + m][4 ks + k] from LDS, the B operand of a lane (k, n) element [16 q + n][4 ks + k] of the stored
@@ -354,12 +373,13 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
     int lane_o = lane;
     asm volatile("" : "+v"(lane_o));
     const int k4 = lane_o >> 4, n16 = lane_o & 15, jo = lane_o;
-    double bq[16], bp[16];
-    {
+    const bool tile_on = NI == 16 || q < NT;  // (NI = 12: the fourth wavefront has no column tile; it keeps the barriers)
+    double bq[NI], bp[NI];
+    if (tile_on) {
       const double* wqg = ws + W::WQ + (16 * q + n16) * NP + k4;
       const double* wpg = ws + W::WP + (16 * q + n16) * NP + k4;
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
+      for (int ks = 0; ks < NI; ++ks) {
         bq[ks] = wqg[4 * ks];
         bp[ks] = wpg[4 * ks];
       }
@@ -367,7 +387,7 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
     {  // (S rho_b)[pc] over this wavefront's columns, and s, by true row index for the lanes that will hold those rows
       double part = 0.0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) part = fma(tb[i], wk[W::RB + 4 * i + q], part);
+      for (int i = 0; i < NI; ++i) part = fma(tb[i], wk[W::RB + 4 * i + q], part);
       sRed[0][q][pc] = part;
       if (q == 0) sV[0][pc] = tt;
     }
@@ -375,8 +395,9 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
     v4d_t accP[4], accR[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) accP[mt] = accR[mt] = v4d_t{0.0, 0.0, 0.0, 0.0};
+    if (tile_on) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
+    for (int ks = 0; ks < NI; ++ks) {
       double a[4];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) a[mt] = sS[(16 * mt + n16) * LDS_LD + 4 * ks + k4];
@@ -386,6 +407,7 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
         accR[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], bp[ks], accR[mt], 0, 0, 0);
       }
     }
+    }
     const double Er = Ek[l * NP + j];
     const double srb = (sRed[0][0][j] + sRed[0][1][j]) + (sRed[0][2][j] + sRed[0][3][j]);
     const double tnew = ws[W::RT + j] - Er * (sV[0][j] - srb);
@@ -393,29 +415,33 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
     // the row j of Wp, Wq: this lane's own loads (coalesced), in flight across the exchange (the fence keeps the scheduler from
     // hoisting them over the MFMA chain, where there are no registers for them: it spilled all 32)
     RTD_FENCE();
-    double wpr[16], wqr[16];
+    double wpr[NI], wqr[NI];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NI; ++i) {
       wpr[i] = ws[W::WP + (4 * i + q) * NP + jo];
       wqr[i] = ws[W::WQ + (4 * i + q) * NP + jo];
     }
     __syncthreads();  // every wavefront has read its A operands: the S area is free
     // accumulator register r of tile mt, lane (kq, n): element [16 mt + 4 r + kq][16 q + n]
+    if (tile_on) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+      for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sS[(16 * mt + 4 * r + k4) * LDS_LD + 16 * q + n16] = accP[mt][r];
+        for (int r = 0; r < 4; ++r) sS[(16 * mt + 4 * r + k4) * LDS_LD + 16 * q + n16] = accP[mt][r];
+    }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ta[i] = -(Er * sS[j * LDS_LD + 4 * i + q] + wpr[i]);  // Ta' = -(E S Wq + Wp)
+    for (int i = 0; i < NI; ++i) ta[i] = -(Er * sS[j * LDS_LD + 4 * i + q] + wpr[i]);  // Ta' = -(E S Wq + Wp)
+    __syncthreads();
+    if (tile_on) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sS[(16 * mt + 4 * r + k4) * LDS_LD + 16 * q + n16] = accR[mt][r];
+    }
     __syncthreads();
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sS[(16 * mt + 4 * r + k4) * LDS_LD + 16 * q + n16] = accR[mt][r];
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) tb[i] = -(Er * sS[j * LDS_LD + 4 * i + q] + wqr[i]) * e1[4 * i + q];  // Tb' = -(E S Wp + Wq) E'
+    for (int i = 0; i < NI; ++i) tb[i] = -(Er * sS[j * LDS_LD + 4 * i + q] + wqr[i]) * e1[4 * i + q];  // Tb' = -(E S Wp + Wq) E'
     tt = tnew;
     if (touched[0] == 1.2345e-300 && touched[1] == 1.2345e-300) tt += touched[0];  // (never: keeps the touching loads alive)
   }
@@ -435,9 +461,9 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
     kdouble* amk = as_k(amL);
     const double* kl = kk + (long)l * NP;
     const double att = beam ? exp(-ts0[L] / mu0) : 0.0;
-    double pa[16], qa[16];
+    double pa[NI], qa[NI];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NI; ++i) {
       pa[i] = ymL[j * NP + 4 * i + q] * rTj;
       qa[i] = amL[j * NP + 4 * i + q] * rTj;
     }
@@ -449,7 +475,7 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
       for (int j2 = 0; j2 < NP; ++j2) {
         const double Rij = delta * qt[j2] * d.mu[j2] * d.w[j2] / d.T[j2];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NI; ++i) {
           pa[i] -= Rij * ymk[j2 * NP + 4 * i + q];
           qa[i] += Rij * amk[j2 * NP + 4 * i + q];
         }
@@ -469,16 +495,16 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
     // am = Bb - Ba S (into ta: this wavefront's columns) and bvec = br - Ba s.  A lane needs its whole row of Ba, of which every
     // wavefront made a quarter of the columns: the rows cross in LDS sixteen columns at a time (8.5 KB, not the 33 KB of a full
     // copy: three chains fit a CU).
-    double ba[16];
+    double ba[NI];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int k = 4 * i + q;
       const double qk = qa[i] / kl[k];
       ba[i] = (pa[i] - qk) * Ek[l * NP + k];  // Ba (with the scaling of C-)
       ta[i] = pa[i] + qk;                      // Bb
     }
     double bvec = br;
-    static_for<0, 4>([&](auto kqc) {
+    static_for<0, NT>([&](auto kqc) {
       constexpr int kq = decltype(kqc)::value;
       __syncthreads();  // (first pass: S and s complete; later ones: the previous quarter has been read)
 #pragma unroll
@@ -490,7 +516,7 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
 #pragma unroll
       for (int k = 0; k < 16; ++k) bvec = fma(-bq[k], v0[16 * kq + k], bvec);
 #pragma unroll 4
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < NI; ++i) {
         const int cc = 4 * i + q;
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
@@ -503,14 +529,14 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
     });
     int pc2 = -1;
     double touched[2] = {0.0, 0.0};
-    gj_wide<false>(ta, tb, bvec, pc2, lane, q, sCol, sFound, sPiv, nullptr, touched);
+    gj_wide<false, NI>(ta, tb, bvec, pc2, lane, q, sCol, sFound, sPiv, nullptr, touched);
     if (pc2 < 0) pc2 = j;
     if (q == 0) v1[pc2] = bvec;  // C+
     __syncthreads();
     if (q == 0) {
       double cmin = s_pc;  // C-[pc] = s[pc] - S[pc][:] C+
 #pragma unroll 8
-      for (int k = 0; k < NP; ++k) cmin = fma(-sS[pc * LDS_LD + k], v1[k], cmin);
+      for (int k = 0; k < NC; ++k) cmin = fma(-sS[pc * LDS_LD + k], v1[k], cmin);  // (the columns that are carried)
       v2[pc] = cmin;
     }
     __syncthreads();
@@ -527,12 +553,13 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
   const int k0 = 16 * q;
   for (int l = Lm1 - 1; l >= 0; --l) {
     const double* ws = wsb + (long)l * W::SLOT;
+    const bool cols_on = NI == 16 || q < NT;  // (NI = 12: the columns 48 ... 63 are not carried -- nothing was stored for them)
     double wq[16], wp[16], st[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      wq[i] = ws[W::WQ + (k0 + i) * NP + j];
-      wp[i] = ws[W::WP + (k0 + i) * NP + j];
-      st[i] = ws[W::S + (k0 + i) * NP + j];
+      wq[i] = cols_on ? ws[W::WQ + (k0 + i) * NP + j] : 0.0;
+      wp[i] = cols_on ? ws[W::WP + (k0 + i) * NP + j] : 0.0;
+      st[i] = cols_on ? ws[W::S + (k0 + i) * NP + j] : 0.0;
     }
     const double rb = ws[W::RB + j], sv = ws[W::SV + j];
     const double ecp = Ek[(l + 1) * NP + j] * cpj;  // E'_j C+'_j
@@ -569,6 +596,13 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
 
 void rtd_launch_bc_wide(const RtdDev& d, hipStream_t s, int part) {
   const long nif = (long)d.C * d.M * (d.L - 1);
-  if (part == 0 && nif > 0) hipLaunchKernelGGL(rtd_iface_mfma_kernel, dim3((unsigned)((2 * nif + 7) / 8 * 8)), dim3(64), 0, s, d);
-  if (part == 1) hipLaunchKernelGGL(rtd_sweep_wide_kernel, dim3((unsigned)((long)d.C * d.M)), dim3(256), 0, s, d);
+  if (part == 0 && nif > 0) {
+    if (d.N <= 48) hipLaunchKernelGGL(rtd_iface_mfma_kernel<48>, dim3((unsigned)((2 * nif + 7) / 8 * 8)), dim3(64), 0, s, d);
+    else hipLaunchKernelGGL(rtd_iface_mfma_kernel<64>, dim3((unsigned)((2 * nif + 7) / 8 * 8)), dim3(64), 0, s, d);
+  }
+  if (part == 1) {
+    // 66 ... 96 streams: the instance that leaves the padding columns 48 ... 63 out (the interface kernel makes the same cut)
+    if (d.N <= 48) hipLaunchKernelGGL(rtd_sweep_wide_kernel<12>, dim3((unsigned)((long)d.C * d.M)), dim3(256), 0, s, d);
+    else hipLaunchKernelGGL(rtd_sweep_wide_kernel<16>, dim3((unsigned)((long)d.C * d.M)), dim3(256), 0, s, d);
+  }
 }
