@@ -377,3 +377,30 @@ def test_random_128_stream_case_matches_oracle(seed):
     record_parity("random128/%d" % seed, a, b, 1e-7, 1e-6)
     assert np.allclose(got[1](tau), ref[1](tau), rtol=1e-7, atol=1e-8 * scale)
     assert np.allclose(got[2](tau)[0], ref[2](tau)[0], rtol=1e-7, atol=1e-8 * scale)
+
+
+@pytest.mark.parametrize("nquad", [66, 94, 96, 98, 126])
+def test_stream_counts_either_side_of_the_48_stream_instances(nquad):
+    """66 ... 96 streams (N <= 48) run on boundary-condition kernels that leave the padding columns 48 ... 63 out
+    (rtd_sweep_wide_kernel<12>, rtd_iface_mfma_kernel<48>), 98 ... 128 on the full instances: the same three-layer atmosphere
+    with a thermal source, a beam and a Lambertian surface at stream counts on both sides of that switch, and at the ends of the
+    range, against the oracle (tolerances of the 128-stream cases)."""
+    import pydisort_amd
+    import goldens
+    from oracle import disort_oracle as O
+    kw = dict(tau_arr=np.array([0.3, 1.1, 2.5]), omega_arr=np.array([0.95, 0.6, 0.85]), NQuad=nquad,
+              Leg_coeffs_all=np.stack([0.75 ** np.arange(nquad + 1), 0.5 ** np.arange(nquad + 1), 0.8 ** np.arange(nquad + 1)]),
+              mu0=0.55, I0=1.3, phi0=0.4, NFourier=5, f_arr=np.array([0.75, 0.5, 0.8]) ** nquad,
+              s_poly_coeffs=np.array([[0.2, 0.05], [0.1, 0.0], [0.3, -0.02]]), b_neg=0.1,
+              BDRF_Fourier_modes=[0.3])
+    tau, phi = np.array([0.0, 0.2, 0.3, 1.0, 2.5]), np.array([0.0, 1.0, 2.5])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = O.pydisort(**kw)
+        got = pydisort_amd.pydisort(**kw)
+    want, gotu = ref[4](tau, phi), got[4](tau, phi)
+    scale = float(np.max(np.abs(want)))
+    a, b = goldens.max_rel_err(gotu, want)
+    assert a < 1e-7 and b < 1e-6, (nquad, a, b)
+    assert np.allclose(got[1](tau), ref[1](tau), rtol=1e-7, atol=1e-8 * scale)
+    assert np.allclose(got[2](tau)[0], ref[2](tau)[0], rtol=1e-7, atol=1e-8 * scale)
