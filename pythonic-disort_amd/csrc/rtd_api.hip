@@ -629,6 +629,9 @@ int rtd_plan_create_windowed(const rtd_dims* dims, int32_t device, int32_t work_
   if (dims->ncols < 1 || dims->nlayers < 1 || dims->nquad < 2 || (dims->nquad & 1) || dims->nleg < 1 ||
       dims->nfourier < 1 || dims->nfourier > dims->nleg || dims->nscoeffs < 0 || dims->nbdrf < 0)
     return fail(RTD_ERR_ARG, "invalid dimensions");
+  // include/rtd.h: nleg <= nquad (pydisort.py:232-234 of the reference).  The one-lane-per-problem eigen kernel of 2 ... 8 streams
+  // reads exactly 2 NP moments per parity: more would be dropped silently.
+  if (dims->nleg > dims->nquad) return fail(RTD_ERR_ARG, "invalid dimensions: nleg > nquad");
   // 2 ... 64 streams; 66 ... 128 streams: one eigenproblem per wavefront, one boundary-condition chain per workgroup (rtd_bc_wide.hip)
   if (N > 64) return fail(RTD_ERR_ARG, "NQuad > 128 is not supported by this build (N = NQuad/2 <= 64)");
   HIP_TRY(hipSetDevice(device));
@@ -1014,9 +1017,7 @@ int rtd_plan_run(rtd_plan* p) {
   return launch_solve(p, true, &e, p->have_nt);
 }
 
-int rtd_plan_fetch(rtd_plan* p, double* u, double* u0, double* flux_up, double* fdn, double* fdir) {
-  if (!p) return fail(RTD_ERR_ARG, "null plan");
-  if (p->ev_ntau < 1 || !p->solved) return fail(RTD_ERR_STATE, "nothing to fetch");
+static int fetch_queued(rtd_plan* p, double* u, double* u0, double* flux_up, double* fdn, double* fdir) {
   HIP_TRY(hipSetDevice(p->device));
   const int64_t C = p->d.C, Qr = 2 * p->d.N, nt = p->ev_ntau, np = p->ev_nphi;
   hipStream_t s = p->stream;
@@ -1026,6 +1027,23 @@ int rtd_plan_fetch(rtd_plan* p, double* u, double* u0, double* flux_up, double* 
   if (fdn) HIP_TRY(hipMemcpyAsync(fdn, p->ev_fl + C * nt, (size_t)(C * nt) * 8, hipMemcpyDeviceToHost, s));
   if (fdir) HIP_TRY(hipMemcpyAsync(fdir, p->ev_fl + 2 * C * nt, (size_t)(C * nt) * 8, hipMemcpyDeviceToHost, s));
   return check_status(p, u != nullptr);  // (u0 and the fluxes come from Fourier mode 0 alone)
+}
+
+// Whatever goes wrong, no copy into the caller's (pageable) arrays is left in flight behind the return: the caller may free or
+// reuse them at once.  check_status drains the stream on its own way out; the early returns before it do not.
+static int drained(rtd_plan* p, int rc) {
+  if (rc != 0 && p->stream) {
+    const std::string keep = g_err;
+    (void)hipStreamSynchronize(p->stream);
+    g_err = keep;
+  }
+  return rc;
+}
+
+int rtd_plan_fetch(rtd_plan* p, double* u, double* u0, double* flux_up, double* fdn, double* fdir) {
+  if (!p) return fail(RTD_ERR_ARG, "null plan");
+  if (p->ev_ntau < 1 || !p->solved) return fail(RTD_ERR_STATE, "nothing to fetch");
+  return drained(p, fetch_queued(p, u, u0, flux_up, fdn, fdir));
 }
 
 // solve + evaluate + copy out, window by window: the device-to-host copy of window w (copy stream, pinned staging)
@@ -1115,9 +1133,10 @@ int rtd_plan_evaluate(rtd_plan* p, int32_t ntau, const double* tau, int32_t nphi
   if (ulast) {  // queued before the fetch, whose status check drains the stream: a numerical failure of SOME columns must not
     //             leave the healthy columns' ulast unwritten (numeric_errors = "nan" keeps them)
     const int64_t C = p->d.C, Qr = 2 * p->d.N;
-    HIP_TRY(hipMemcpyAsync(ulast, p->ev_u0 + C * Qr * ntau, (size_t)(C * Qr * ntau) * 8, hipMemcpyDeviceToHost, p->stream));
+    hipError_t he = hipMemcpyAsync(ulast, p->ev_u0 + C * Qr * ntau, (size_t)(C * Qr * ntau) * 8, hipMemcpyDeviceToHost, p->stream);
+    if (he != hipSuccess) return drained(p, fail(RTD_ERR_HIP, std::string("hipMemcpyAsync(ulast): ") + hipGetErrorString(he)));
   }
-  return rtd_plan_fetch(p, u, u0, flux_up, fdn, fdir);
+  return drained(p, rtd_plan_fetch(p, u, u0, flux_up, fdn, fdir));  // (also behind fetch's own early returns: the ulast copy is pending)
 }
 
 int rtd_plan_set_nt(rtd_plan* p, int32_t nleg_all, const double* weighted_leg_all, const double* f_arr,
@@ -1558,6 +1577,7 @@ int rtd_comm_allgather_layers(rtd_plan* p, int32_t count) {
   // staging: this rank's packed layers, then everybody's (reuses the gathered-u buffer slot of the plan)
   double* mine = nullptr;
   HIP_TRY(hipMalloc(&mine, (size_t)per_rank * 8));
+  p->gathered_here = false;  // the gathered-u buffer is layer staging from here on: no results fetch may read it as gathered u
   if ((rc = grow(p, &p->gathered_u, &p->cap_gathered_u, per_rank * p->comm_size))) {
     (void)hipFree(mine);
     return rc;

@@ -7,6 +7,7 @@ import os
 import subprocess
 import sys
 import tempfile
+import time
 
 import pytest
 
@@ -25,17 +26,30 @@ def _run(mode, world, same_device=False):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     with tempfile.TemporaryDirectory(prefix="rtd_dist_") as d:
+        # every rank writes to files of its own: with pipes drained one process at a time, a chatty rank (NCCL_DEBUG=INFO,
+        # RTD_DEBUG) fills its 64 KB pipe while another is waited for, blocks in write() and hangs the collective
+        logs = [(open(os.path.join(d, f"rank_{r}.out"), "w+"), open(os.path.join(d, f"rank_{r}.err"), "w+")) for r in range(world)]
         procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "--mode", mode, "--rank", str(r),
                                    "--world", str(world), "--dir", d] + (["--device", "0"] if same_device else []),
-                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+                                  env=env, stdout=logs[r][0], stderr=logs[r][1], text=True) for r in range(world)]
         outs = []
         try:
+            deadline = time.monotonic() + 600
             for p in procs:
-                outs.append(p.communicate(timeout=600))
+                p.wait(timeout=max(1.0, deadline - time.monotonic()))
         finally:
             for p in procs:  # exact PIDs only
                 if p.poll() is None:
                     p.kill()
+                    p.wait()
+            for fo, fe in logs:
+                texts = []
+                for f in (fo, fe):
+                    f.flush()
+                    f.seek(0)
+                    texts.append(f.read())
+                    f.close()
+                outs.append(tuple(texts))
         res = []
         for r, p in enumerate(procs):
             path = os.path.join(d, f"result_{r}.json")

@@ -1,10 +1,13 @@
+#!/usr/bin/env bash
 # Round-4 evidence (run on the GPU box: bash tools/profile_round4.sh):
 #  a) cfg4 headline workload, windows one after the other (RTD_NO_PIPELINE=1): rocprofv3 --stats per-kernel averages (they must agree
 #     with the HIP-event pass bench.py reports in roofline.kernel_ms_per_launch) + PMC passes for traffic and SQ counters
 #  b) cfg5 (64 streams) with the lean two-wavefront boundary-condition kernel: stats + PMC passes of one 128-column window,
 #     and the same with RTD_BC_TILE_V1=1 (the one-wavefront kernel of rounds 2-3)
 #  c) the bench line itself
-cd $GRAFT_REPO_ROOT
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+mkdir -p gpurun_out
 export RTD_NO_PIPELINE=1
 bash tools/profile_pmc.sh prof_r4_cfg4_serial python3 bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 --total-columns 16384 > gpurun_out/prof_r4_cfg4_serial.txt 2>&1
 unset RTD_NO_PIPELINE
