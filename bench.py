@@ -656,20 +656,51 @@ def verify_gathered(plan, device, world, columns_per_gpu, total_columns, per_ran
     return ok, world, detail
 
 
-def reduce_max_seconds(dist, seconds):
-    """Max over ranks of a host-side duration through the (gloo) control plane."""
-    import torch
-    t = torch.tensor([seconds], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t[0])
+def reduce_max_seconds(ctl, seconds):
+    """Max over ranks of a host-side duration through the control plane (pydisort_amd/_control.py: sockets, no PyTorch)."""
+    return float(ctl.allreduce(float(seconds), "max"))
 
 
-def all_ranks_ok(dist, ok):
-    """True iff every rank reports ok (MIN over the gloo control plane)."""
-    import torch
-    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return int(t[0]) == 1
+def all_ranks_ok(ctl, ok):
+    """True iff every rank reports ok (MIN over the control plane)."""
+    return ctl.all_ok(bool(ok))
+
+
+# Where a rank is, for the message of a run that is stopped from outside (time-out) or by its own deadline: a hang is reported
+# with the phase and the Python stack of every rank, not as a silent kill.
+_PHASE = {"name": "start", "since": time.time(), "t0": time.time()}
+
+
+def phase(name):
+    _PHASE.update(name=name, since=time.time())
+    d = os.environ.get("RTD_BENCH_RUN_DIR")
+    if d:
+        try:
+            with open(os.path.join(d, f"phase_{os.environ.get('RANK', '0')}"), "w") as f:
+                f.write(f"{name} (entered {time.time() - _PHASE['t0']:.1f} s after the rank started)")
+        except OSError:
+            pass
+
+
+def arm_rank_deadline(rank, seconds):
+    """Every rank ends itself -- with its phase and the stack of every thread on stderr -- `seconds` after it started, whatever
+    launched it: the driver's own limit (1 800 s) must never be what stops a hung run.  SIGUSR1 dumps the stacks without
+    ending the rank (bench.py's launcher sends it before it stops the ranks)."""
+    import faulthandler
+    import signal
+    faulthandler.register(signal.SIGUSR1, file=sys.stderr, all_threads=True)
+
+    def expired():
+        print(f"[bench] rank {rank}: still in phase '{_PHASE['name']}' (for {time.time() - _PHASE['since']:.0f} s) when the run's "
+              f"deadline of {seconds:.0f} s expired; stacks follow", file=sys.stderr)
+        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        sys.stderr.flush()
+        os._exit(EXIT_TIMEOUT)
+
+    t = threading.Timer(seconds, expired)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def _free_port():
@@ -680,16 +711,24 @@ def _free_port():
     return p
 
 
+DEFAULT_TIMEOUT = 1500.0  # seconds; below the driver's 1 800 s, so that a hang ends HERE, with a diagnosis
+
+
 def spawn_ranks(n, argv, timeout=None):
     """Start n fresh rank processes of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, one GPU each), wait for
     all of them, relay rank 0's JSON line.  Any rank failing (or the timeout) ends the others and the run with a
-    non-zero exit code.  The parent never touches a GPU."""
-    timeout = float(os.environ.get("RTD_BENCH_TIMEOUT", "3000")) if timeout is None else timeout
+    non-zero exit code, after every rank's phase has been printed and every live rank has dumped its stacks.  The parent
+    never touches a GPU."""
+    import signal
+    import tempfile
+    timeout = float(os.environ.get("RTD_BENCH_TIMEOUT", str(DEFAULT_TIMEOUT))) if timeout is None else timeout
     port = _free_port()
+    run_dir = tempfile.mkdtemp(prefix="rtd_bench_run_")
     procs = []
     for r in range(n):
         env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   RTD_BENCH_RUN_DIR=run_dir, RTD_BENCH_TIMEOUT=str(timeout + 30.0))  # (the launcher's limit comes first)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
@@ -698,18 +737,38 @@ def spawn_ranks(n, argv, timeout=None):
     reader.start()
     t0 = time.time()
     code = 0
+
+    def report_state():
+        for r, p in enumerate(procs):
+            try:
+                with open(os.path.join(run_dir, f"phase_{r}")) as f:
+                    where = f.read()
+            except OSError:
+                where = "no phase recorded"
+            st = p.poll()
+            print(f"[bench]   rank {r}: {'running' if st is None else f'exited with status {st}'}; last phase: {where}", file=sys.stderr)
+        for p in procs:  # live ranks dump the stacks of all their threads (faulthandler, also from inside a C call)
+            if p.poll() is None:
+                try:
+                    p.send_signal(signal.SIGUSR1)
+                except OSError:
+                    pass
+        time.sleep(1.0)
+
     while True:
         states = [p.poll() for p in procs]
         bad = [s for s in states if s not in (None, 0)]
         if bad:
             code = bad[0] if bad[0] > 0 else 1
-            print(f"[bench] a rank exited with status {bad[0]}: stopping the run", file=sys.stderr)
+            print(f"[bench] a rank exited with status {bad[0]} after {time.time() - t0:.0f} s: stopping the run", file=sys.stderr)
+            report_state()
             break
         if all(s == 0 for s in states):
             break
         if time.time() - t0 > timeout:
             code = EXIT_TIMEOUT
             print(f"[bench] ranks still running after {timeout:.0f} s: stopping the run", file=sys.stderr)
+            report_state()
             break
         time.sleep(0.1)
     for p in procs:  # exact PIDs only
@@ -721,6 +780,8 @@ def spawn_ranks(n, argv, timeout=None):
         except subprocess.TimeoutExpired:
             p.kill()
     reader.join(timeout=5)
+    import shutil
+    shutil.rmtree(run_dir, ignore_errors=True)
     if code:
         return code
     text = (out0[0] if out0 else b"").decode()
@@ -749,6 +810,9 @@ def run_rank(a, rank, world, local):
     stub = os.environ.get("RTD_BENCH_STUB") == "1"  # CPU test of the launch / control plane: no GPU, no librtd
     if stub and os.environ.get("RTD_BENCH_STUB_FAIL_RANK") == str(rank):
         sys.exit(7)  # test hook: a rank that dies before it joins
+    if stub and os.environ.get("RTD_BENCH_STUB_HANG_RANK") == str(rank):
+        phase("stub hang")  # test hook: a rank that never joins
+        time.sleep(3600)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not stub:
         cpu = cpu_baseline_subprocess()
@@ -759,9 +823,12 @@ def run_rank(a, rank, world, local):
     first, C = shard_columns(rank, world, a.columns, a.total_columns)
     strong = a.total_columns > 0
     multi = world > 1 or a.force_dist
+    arm_rank_deadline(rank, float(os.environ.get("RTD_BENCH_TIMEOUT", str(DEFAULT_TIMEOUT))))
     plan = None
     cfg = None
+    mine = {"rank": rank, "local_rank": local, "pid": os.getpid(), "columns": C}  # this rank's own timings: where a poor curve comes from
     if not stub:
+        phase("generate inputs")
         from pydisort_amd import synthetic
         from pydisort_amd import _engine
         from pydisort_amd._engine import Plan
@@ -772,62 +839,91 @@ def run_rank(a, rank, world, local):
                   "contract (check ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES and --gpus)", file=sys.stderr)
             sys.stderr.flush()
             os._exit(EXIT_RANKS)
+        t0 = time.perf_counter()
         cfg, _, _ = shard_config(rank, world, a.columns, a.total_columns)
+        mine["input_generation_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
         prep = prepare_cfg4(cfg)
+        mine["host_preparation_s"] = time.perf_counter() - t0
         if multi:
-            Plan.comm_preload()  # bind RCCL to librtd's HIP runtime before torch (gloo control plane) is imported
+            Plan.comm_preload()  # RCCL from the ROCm install, bound to librtd's HIP runtime (the only one in this process)
+        phase("create plan, upload inputs")
+        t0 = time.perf_counter()
         plan = Plan(prep, device=local, work_columns=a.columns)  # uploads: inputs now resident in HBM
         tau = np.concatenate((np.zeros((C, 1)), cfg["tau_arr"]), axis=1)
         plan.set_eval_points(tau, np.array([0.0, np.pi / 2, np.pi]))
+        plan.synchronize()
+        mine["plan_creation_and_upload_s"] = time.perf_counter() - t0
 
-    dist = None
+    ctl = None
     gather = None
     gather_calls = {}
     chosen = "none"
     collective = "none (single rank)"
+    rccl_says = None
     watchdog = None
     if multi:
-        import torch.distributed as dist
-        # control plane: barriers, status and the max-over-ranks of the time
-        dist.init_process_group("gloo")
-        if dist.get_world_size() != world:
-            print(f"[bench] rank {rank}: process group has {dist.get_world_size()} ranks, expected {world}", file=sys.stderr)
+        # control plane: barriers, status and the max-over-ranks of the time -- sockets between the rank processes of this
+        # node (pydisort_amd/_control.py), no PyTorch: librtd's HIP runtime and RCCL are the only GPU libraries of a rank
+        phase("join the control plane")
+        from pydisort_amd import _control
+        t0 = time.perf_counter()
+        try:
+            ctl = _control.ControlPlane(rank, world)
+        except _control.ControlError as e:
+            print(f"[bench] rank {rank}: {e}", file=sys.stderr)
+            sys.stderr.flush()
             os._exit(EXIT_RANKS)
+        mine["control_plane_join_s"] = time.perf_counter() - t0
         if not stub:
             # data plane: RCCL all-gather of u + fluxes inside librtd.  A rank that cannot bootstrap or hangs ends the
             # whole run: the plan is never touched again after a failure, and a watchdog ends a rank stuck in RCCL.
             limit = float(os.environ.get("RTD_RCCL_TIMEOUT", "300"))
 
             def expired():
-                print(f"[bench] rank {rank}: RCCL bootstrap / first gather still pending after {limit:.0f} s", file=sys.stderr)
+                print(f"[bench] rank {rank}: RCCL bootstrap / first gather still pending after {limit:.0f} s (phase '{_PHASE['name']}')", file=sys.stderr)
+                import faulthandler
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
                 sys.stderr.flush()
                 os._exit(EXIT_RCCL)
 
             watchdog = threading.Timer(limit, expired)
             watchdog.daemon = True
             watchdog.start()
-            uid, err = [None], None
+            phase("RCCL unique id")
+            uid, err = None, None
             if rank == 0:
                 try:
-                    uid = [Plan.comm_unique_id()]
+                    uid = Plan.comm_unique_id()
                 except Exception as e:
                     err = e
-            dist.broadcast_object_list(uid, src=0)
-            ok = uid[0] is not None
+            uid = ctl.broadcast_bytes(uid, src=0)
+            ok = uid is not None
             gather_calls = {"all": plan.allgather_results, "root": lambda: plan.gather_results(0), "none": None}
             if ok:
                 try:
-                    plan.comm_init(uid[0], rank, world)
+                    phase("ncclCommInitRank")
+                    t0 = time.perf_counter()
+                    plan.comm_init(uid, rank, world)
+                    mine["rccl_comm_init_s"] = time.perf_counter() - t0
+                    rccl_says = plan.comm_size()  # ncclCommCount / ncclCommUserRank / ncclCommCuDevice: RCCL's own statement
+                    mine["rccl_nranks"], mine["rccl_rank"], mine["rccl_device"] = rccl_says
+                    if rccl_says[0] != world or rccl_says[1] != rank:
+                        raise RuntimeError(f"RCCL reports rank {rccl_says[1]} of {rccl_says[0]}, launched as rank {rank} of {world}")
+                    t0 = time.perf_counter()
                     for mode in (("all", "root") if a.gather == "auto" else (a.gather,)):  # every collective the run may use, once
+                        phase(f"first step + first collective ({mode})")
                         plan.run()
                         if gather_calls[mode]:
                             gather_calls[mode]()
                         plan.synchronize()
+                    mine["first_collectives_s"] = time.perf_counter() - t0
                 except Exception as e:
                     ok, err = False, e
             if not ok:
                 print(f"[bench] rank {rank}: RCCL data plane failed: {err!r}", file=sys.stderr)
-            everyone = all_ranks_ok(dist, ok)
+            phase("all ranks report their RCCL bootstrap")
+            everyone = all_ranks_ok(ctl, ok)
             watchdog.cancel()
             if not everyone:
                 sys.stderr.flush()
@@ -836,13 +932,17 @@ def run_rank(a, rank, world, local):
     def barrier():
         if plan is not None:
             plan.synchronize()
-        if dist is not None:
-            dist.barrier()
+        if ctl is not None:
+            ctl.barrier()
 
-    def timed(nsteps, gather_fn, fresh):
+    own = {}  # this rank's own seconds of the last timed region (the line reports the max over the ranks)
+
+    def timed(nsteps, gather_fn, fresh, label=None):
         """nsteps steps between barriers + device synchronisation on both sides -> seconds, max over the ranks.
         fresh: every step treats the resident inputs as new (the per-column Legendre tables at -mu0 and the beam attenuations
         are recomputed: what the reference does in every call, _solve_for_gen_and_part_sols.py:96-109)."""
+        if label:
+            phase(label)
         barrier()
         t0 = time.perf_counter()
         for _ in range(nsteps):
@@ -858,7 +958,8 @@ def run_rank(a, rank, world, local):
             plan.synchronize()
         el = time.perf_counter() - t0
         barrier()
-        return reduce_max_seconds(dist, el) if dist is not None else el
+        own["seconds"] = el
+        return reduce_max_seconds(ctl, el) if ctl is not None else el
 
     # which collective the timed region uses.  --gather auto (the default): ncclAllGather to every rank unless it costs the
     # step >= 3 % more than gathering on rank 0 alone (SURVEY 8(e) allows root-only "if only rank 0 needs results"); decided
@@ -881,18 +982,15 @@ def run_rank(a, rank, world, local):
         if a.gather == "auto":
             collective += " [--gather auto: chosen from trial regions, all-gather unless >= 3 % slower than root-only]"
 
-    timed(a.warmup, gather, True) if a.warmup > 0 else barrier()
-    elapsed = timed(a.steps, gather, True)          # THE timed region: exactly --steps steps, fresh inputs every step
-    elapsed_cached = timed(a.steps, gather, False)  # the same on repeated inputs (tables kept from run to run)
+    timed(a.warmup, gather, True, "warm-up steps") if a.warmup > 0 else barrier()
+    elapsed = timed(a.steps, gather, True, "timed region")          # THE timed region: exactly --steps steps, fresh inputs every step
+    mine["ms_per_step_own"] = 1e3 * own["seconds"] / a.steps
+    elapsed_cached = timed(a.steps, gather, False, "timed region (cached tables)")  # the same on repeated inputs (tables kept from run to run)
+    mine["ms_per_step_own_cached_tables"] = 1e3 * own["seconds"] / a.steps
     joined = world
-    if dist is not None:
-        import torch
-        cnt = torch.tensor([C], dtype=torch.int64)
-        dist.all_reduce(cnt)
-        total_cols = int(cnt[0])
-        one = torch.tensor([1], dtype=torch.int64)
-        dist.all_reduce(one)
-        joined = int(one[0])
+    if ctl is not None:
+        total_cols = int(ctl.allreduce(int(C), "sum"))
+        joined = int(ctl.allreduce(1, "sum"))
     else:
         total_cols = C
     if joined != world:
@@ -908,7 +1006,8 @@ def run_rank(a, rank, world, local):
         holds = chosen == "all" or (chosen == "root" and rank == 0)
         ok, detail = True, None
         if chosen != "none":
-            timed(1, gather, True)  # (a fresh gather of a known step; its results are what is checked)
+            timed(1, gather, True, "gather to be verified")  # (a fresh gather of a known step; its results are what is checked)
+            phase("verify the gathered arrays against local solves")
             if holds:
                 try:
                     ok, nver, detail = verify_gathered(plan, local, world, a.columns, a.total_columns)
@@ -916,7 +1015,7 @@ def run_rank(a, rank, world, local):
                     ok, detail = False, repr(e)
                 if not ok:
                     print(f"[bench] rank {rank}: gathered results differ from a local solve of the same columns: {detail}", file=sys.stderr)
-            if not all_ranks_ok(dist, ok):
+            if not all_ranks_ok(ctl, ok):
                 sys.stderr.flush()
                 os._exit(EXIT_VERIFY)
             verified = {"gather_verified": True, "ranks_verified": world, "columns_per_rank": 4,
@@ -926,12 +1025,15 @@ def run_rank(a, rank, world, local):
             if mode == chosen:
                 gather_rates[mode] = total_cols * a.steps / elapsed
             elif mode in gather_calls and (a.gather == "auto" or mode == "none"):
-                timed(1, gather_calls[mode], True)
+                timed(1, gather_calls[mode], True, f"rate with --gather {mode}")
                 gather_rates[mode] = total_cols * probe / timed(probe, gather_calls[mode], True)
+                mine[f"ms_per_step_own_gather_{mode}"] = 1e3 * own["seconds"] / probe
 
     # per-kernel HIP-event times from a separate short pass (events + a stream sync per window would otherwise sit
     # inside the timed region; the timed region above is the free-running pipeline)
     stage, sweeps = None, None
+    per_rank = ctl.gather(mine) if ctl is not None else [mine]
+    phase("HIP-event pass, extras")
     if plan is not None and rank == 0:
         plan.enable_timing(True)
         plan.timing(reset=True)
@@ -964,6 +1066,7 @@ def run_rank(a, rank, world, local):
                                    "delta-M on, beam source, u at 21 interfaces x 3 azimuths + fluxes",
                        "columns_per_gpu_per_step": C, "global_columns_per_step": total_cols,
                        "columns_per_window": a.columns, "ranks_joined": joined,
+                       "rccl_nranks": rccl_says[0] if rccl_says else None,
                        "total_columns": a.total_columns if strong else None,
                        "parallelism": f"column-sharded x{world}", "collective": collective,
                        "max_jacobi_sweeps": sweeps},
@@ -973,6 +1076,13 @@ def run_rank(a, rank, world, local):
             out["gather_verification"] = verified
         elif multi and not stub:
             out["config"].update(gather_verified=None, ranks_verified=0)  # --gather none: nothing is gathered
+        if multi:
+            out["control_plane"] = "sockets between the rank processes (pydisort_amd/_control.py); torch imported: " + str("torch" in sys.modules)
+            out["per_rank"] = per_rank  # every rank's own seconds: input generation, plan creation + upload, RCCL bootstrap, its own ms per step
+            if rccl_says:
+                out["rccl"] = {"nranks": rccl_says[0], "rank_of_this_line": rccl_says[1], "device": rccl_says[2],
+                               "source": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice on the plan's communicator (rtd_comm_size); "
+                                         "every rank's own answer is in per_rank"}
         if gather_rates:
             out["gather_rates"] = {"unit": "column-solves/sec, whole job", "chosen": chosen, "compute_only": gather_rates.get("none"),
                                    "allgather": gather_rates.get("all"), "root_only": gather_rates.get("root"),
@@ -1014,9 +1124,10 @@ def run_rank(a, rank, world, local):
         out.update(extras)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    phase("leave")
+    if ctl is not None:
+        ctl.barrier()
+        ctl.close()
     if plan is not None:
         plan.close()
 

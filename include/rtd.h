@@ -232,6 +232,9 @@ int rtd_plan_max_sweeps(rtd_plan* plan, int32_t* sweeps);
 int rtd_comm_preload(void);
 int rtd_comm_unique_id(char id[128]);
 int rtd_comm_init(rtd_plan* plan, const char id[128], int32_t rank, int32_t nranks);
+/* RCCL's own statement about the plan's communicator: ncclCommCount, ncclCommUserRank, ncclCommCuDevice (any pointer may be
+ * null).  RTD_ERR_STATE when they disagree with the arguments of rtd_comm_init. */
+int rtd_comm_size(rtd_plan* plan, int32_t* nranks, int32_t* rank, int32_t* device);
 int rtd_comm_allgather_fluxes(rtd_plan* plan);               /* asynchronous on the plan's stream */
 int rtd_comm_fetch_gathered(rtd_plan* plan, double* out);    /* host [nranks][3][C][ntau] */
 /* u AND fluxes of the last rtd_plan_run: the rank's results are snapshot into its own slot of the gathered arrays (device

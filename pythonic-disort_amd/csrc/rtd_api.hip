@@ -1315,6 +1315,9 @@ struct RcclApi {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi* rccl() {
@@ -1338,6 +1341,9 @@ RcclApi* rccl() {
       api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.h, "ncclGroupEnd");
       api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
       api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
+      api.CommCount = (decltype(api.CommCount))dlsym(api.h, "ncclCommCount");
+      api.CommUserRank = (decltype(api.CommUserRank))dlsym(api.h, "ncclCommUserRank");
+      api.CommCuDevice = (decltype(api.CommCuDevice))dlsym(api.h, "ncclCommCuDevice");
       if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy || !api.GetErrorString) api.h = nullptr;
     }
   });
@@ -1373,6 +1379,26 @@ int rtd_comm_init(rtd_plan* p, const char id[128], int32_t rank, int32_t nranks)
   }
   p->comm_rank = rank;
   p->comm_size = nranks;
+  return 0;
+}
+
+// What RCCL itself says about the plan's communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) -- not the
+// arguments rtd_comm_init was called with.  A caller that reports "N ranks" reports this.
+int rtd_comm_size(rtd_plan* p, int32_t* nranks, int32_t* rank, int32_t* device) {
+  if (!p || !p->comm) return fail(RTD_ERR_STATE, "communicator not initialised");
+  RcclApi* r = rccl();
+  if (!r || !r->CommCount || !r->CommUserRank) return fail(RTD_ERR_HIP, "librccl.so lacks ncclCommCount / ncclCommUserRank");
+  int n = -1, me = -1, dev = -1;
+  ncclResult_t rc = r->CommCount(p->comm, &n);
+  if (rc == ncclSuccess) rc = r->CommUserRank(p->comm, &me);
+  if (rc == ncclSuccess && r->CommCuDevice) rc = r->CommCuDevice(p->comm, &dev);
+  if (rc != ncclSuccess) return fail(RTD_ERR_HIP, std::string("ncclCommCount / ncclCommUserRank: ") + r->GetErrorString(rc));
+  if (n != p->comm_size || me != p->comm_rank)
+    return fail(RTD_ERR_STATE, "RCCL reports rank " + std::to_string(me) + " of " + std::to_string(n) + ", the plan was initialised as rank " +
+                                   std::to_string(p->comm_rank) + " of " + std::to_string(p->comm_size));
+  if (nranks) *nranks = n;
+  if (rank) *rank = me;
+  if (device) *device = dev;
   return 0;
 }
 

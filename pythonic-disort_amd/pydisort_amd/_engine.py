@@ -241,6 +241,13 @@ class Plan:
         _lib.check(self._lib.rtd_comm_init(self._h, uid, rank, nranks))
         self._nranks = nranks
 
+    def comm_size(self):
+        """(nranks, rank, device) as RCCL itself reports them for the plan's communicator (ncclCommCount,
+        ncclCommUserRank, ncclCommCuDevice; include/rtd.h: rtd_comm_size)."""
+        n, r, d = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+        _lib.check(self._lib.rtd_comm_size(self._h, C.byref(n), C.byref(r), C.byref(d)))
+        return int(n.value), int(r.value), int(d.value)
+
     def allgather_fluxes(self):
         _lib.check(self._lib.rtd_comm_allgather_fluxes(self._h))
 

@@ -72,6 +72,8 @@ def main():
             plan = sol.plan
             plan.set_eval_points(np.concatenate((np.zeros((per, 1)), mine["tau_arr"]), axis=1), phi)
             plan.comm_init(exchange_id(a, Plan, name), R, W)  # one communicator per plan (the library's model)
+            checks[name + "_rccl_says"] = list(plan.comm_size())  # ncclCommCount / ncclCommUserRank / ncclCommCuDevice
+            ok = ok and plan.comm_size() == (W, R, dev)
             for _ in range(2):  # the second step's gather overlaps nothing stale: its snapshot waits for the first gather
                 plan.run()
                 plan.allgather_results() if a.mode == "allgather" else plan.gather_results(0)

@@ -1,7 +1,7 @@
 """Hardware-facing readiness of the multi-GPU path on the one GPU a test box has: bench.py through the SAME code N ranks
-take -- gloo rendezvous, RCCL loaded before torch, communicator bootstrap under the watchdog, the data-path collective on
+take -- socket control plane (no PyTorch), RCCL from the ROCm install, communicator bootstrap under the watchdog, the data-path collective on
 its own stream overlapped with the next step -- with a communicator of one rank (`--force-dist`), as a fresh child process
-like the driver's.  (N > 1 itself: world-size-2 gloo tests in test_distributed_cpu.py; the driver's SCALE run.)"""
+like the driver's.  (N > 1 itself: world-size-2 control-plane tests in test_distributed_cpu.py; the driver's SCALE run.)"""
 import json
 import os
 import subprocess
@@ -34,6 +34,8 @@ def test_bench_force_dist_runs_the_rccl_path_with_one_rank(gather, prefix):
     assert out["scaling"] == "strong" and out["config"]["global_columns_per_step"] == 6000
     assert out["config"]["columns_per_window"] == 256 and out["roofline"]["launches_per_step"] == 24
     assert out["value"] > 1e4 and 0.05 < out["roofline"]["frac"] < 1.0
+    assert out["config"]["rccl_nranks"] == 1 and out["per_rank"][0]["rccl_comm_init_s"] > 0      # ncclCommCount's answer, not the caller's argument
+    assert out["control_plane"].endswith("torch imported: False")                               # north_star: no PyTorch
 
 
 def test_gathered_results_on_the_root_equal_the_ranks_own():

@@ -99,3 +99,9 @@ def test_bench_verifies_what_it_gathers_before_it_reports():
     g = out["gather_rates"]
     assert g["compute_only"] > 0 and g["allgather"] > 0 and g["root_only"] > 0 and g["chosen"] in ("all", "root")
     assert out["value_cached_tables"] > 0
+    # RCCL's own statement (ncclCommCount on every rank's communicator), the torch-free control plane, every rank's own timings
+    assert out["config"]["rccl_nranks"] == n and out["rccl"]["nranks"] == n
+    assert [p["rank"] for p in out["per_rank"]] == list(range(n))
+    assert all(p["rccl_nranks"] == n and p["rccl_rank"] == p["rank"] and p["rccl_device"] == p["local_rank"] for p in out["per_rank"])
+    assert all(p["ms_per_step_own"] > 0 and p["input_generation_s"] > 0 and p["plan_creation_and_upload_s"] > 0 for p in out["per_rank"])
+    assert out["control_plane"].endswith("torch imported: False")
