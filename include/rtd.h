@@ -60,6 +60,16 @@ int rtd_device_count(int32_t* count);
  * at the ABI: every call below is ordered on the plan's stream as before, rtd_plan_synchronize covers both. */
 int rtd_plan_create(const rtd_dims* dims, int32_t device, rtd_plan** plan);
 int rtd_plan_create_windowed(const rtd_dims* dims, int32_t device, int32_t work_columns, rtd_plan** plan);
+/* A plan whose evaluators can be called again after a solve WITHOUT solving again, whatever its window count -- the contract
+ * of the reference's closures, which keep GC_collect, K_collect, B_collect of the solve and evaluate any (tau, phi) from them
+ * (_assemble_intensity_and_fluxes.py:170-262).  Everything rtd_plan_evaluate / rtd_plan_get_tensors read of a solve (the
+ * eigenvector blocks Y, A, the eigenvalues, particular solutions and boundary-condition coefficients: 3.1 of the 8.4 MB of
+ * intermediates of a 20-layer 32-stream column) is then held for ALL columns; only the boundary-condition workspace stays
+ * windowed.  retain_bytes: budget for that state in bytes; < 0: three tenths of the device memory that is free at creation;
+ * 0: never (= rtd_plan_create_windowed).  A batch whose state does not fit is created as a plain windowed plan, whose
+ * rtd_plan_evaluate solves the windows again; rtd_plan_retained tells which it is (one-window plans: always 1). */
+int rtd_plan_create_retained(const rtd_dims* dims, int32_t device, int32_t work_columns, int64_t retain_bytes, rtd_plan** plan);
+int rtd_plan_retained(rtd_plan* plan, int32_t* retained);
 /* columns per window and number of windows of a plan */
 int rtd_plan_windows(rtd_plan* plan, int32_t* work_columns, int32_t* nwindows);
 int rtd_plan_destroy(rtd_plan* plan);

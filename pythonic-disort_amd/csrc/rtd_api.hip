@@ -131,6 +131,11 @@ struct rtd_plan {
   double *Y0_all = nullptr, *att_all = nullptr;
   bool tables_cached = false, tables_valid = false;
   bool pipelined = false;
+  // Retained plan (rtd_plan_create_retained): the eigen stage's hand-off arrays and the coefficients cover ALL columns instead
+  // of one window (two slots), so that the evaluators can be called again after a solve without solving again -- what the
+  // reference's closures do with GC_collect, K_collect, B_collect (_assemble_intensity_and_fluxes.py:170-262).  Only the
+  // boundary-condition workspace Fws (5 of a cfg4 column's 8.4 MB) stays windowed.
+  bool retained = false;
   bool fork_needed = true;               // inputs were (re)uploaded on `stream` since the last solve: the eigen stream must wait for them
   bool bc_recorded[2] = {false, false};  // ev_bc[slot] has been recorded by some earlier window (possibly of an earlier run)
   // Pipelined plans keep the device status words (status, col_status, sweeps) twice and alternate between them from solve to
@@ -252,6 +257,11 @@ RtdDev window_dev(const rtd_plan* p, int64_t c0, int cnt, int slot = 0) {
     w.att = p->att_all + c0 * ((int64_t)p->d.L + 1);
   }
   const int64_t L = w.L, M = w.M, P = w.P, NP = w.NP, Ns = w.Ns, NB = w.NBDRF;
+  if (p->retained) {  // every column has its own place in the hand-off arrays and the coefficients
+    w.Ym += c0 * M * L * NP * NP; w.Am += c0 * M * L * NP * NP; w.kk += c0 * M * L * NP; w.Ek += c0 * M * L * NP;
+    w.Bv += c0 * M * L * 2 * NP; w.coef += c0 * M * L * 2 * NP; w.dq += c0 * L * Ns * 2 * NP; w.zneg += c0 * L * NP;
+    if (Ns > 0) w.vb += c0 * L * 4 * NP;
+  }
   w.C = cnt;
   w.omega += c0 * L; w.tau += c0 * L; w.taus0 += c0 * (L + 1); w.scale += c0 * L; w.wleg += c0 * L * P;
   w.mu0 += c0; w.I0 += c0; w.phi0 += c0; w.rescale += c0;
@@ -337,8 +347,10 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
     const int64_t c0 = (int64_t)w * p->Cw;
     const int cnt = (int)std::min<int64_t>(p->Cw, p->d.C - c0);
     const int slot = w & 1;
-    RtdDev d = window_dev(p, c0, cnt, slot);
-    if (p->bc_recorded[slot]) (void)hipStreamWaitEvent(se, p->ev_bc[slot], 0);  // the slot's previous tenant has been consumed
+    RtdDev d = window_dev(p, c0, cnt, p->retained ? 0 : slot);
+    // the slot's previous tenant has been consumed (a retained plan has a place per column, not two slots: its window w is only
+    // rewritten by the NEXT run, which must not overtake this run's consumers of the same columns -- the same event says so)
+    if (p->bc_recorded[slot]) (void)hipStreamWaitEvent(se, p->ev_bc[slot], 0);
     if (w == 0) (void)clear_status(se);  // (a failure here shows up as the launch error checked below)
     if (w == 0 && all_tables) {
       rtd_launch_tables(*all_tables, se, true);
@@ -352,7 +364,7 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
   for (int w = 0; w < p->nwin; ++w) {
     const int64_t c0 = (int64_t)w * p->Cw;
     const int cnt = (int)std::min<int64_t>(p->Cw, p->d.C - c0);
-    RtdDev d = window_dev(p, c0, cnt, pipe ? (w & 1) : 0);
+    RtdDev d = window_dev(p, c0, cnt, pipe && !p->retained ? (w & 1) : 0);
     // run-path points at the layer interfaces: the boundary-condition kernel evaluates the Fourier modes there itself
     // (rtd_plan_evaluate -- the closures -- always takes the evaluation kernel, whatever the window count: a column's
     // closure values must not depend on the batch it was solved in)
@@ -480,7 +492,7 @@ int rtd_device_count(int32_t* count) {
   return 0;
 }
 
-static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t work_columns) {
+static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t work_columns, int64_t retain_bytes) {
   const int N = dims->nquad / 2;
   p->dims = *dims;
   p->device = device;
@@ -535,6 +547,20 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   p->Cw = (int)Cw;
   p->nwin = (int)((C + Cw - 1) / Cw);
   p->pipelined = p->nwin > 1 && may_pipeline;
+  // Retained evaluator state (rtd_plan_create_retained): everything but the boundary-condition workspace for ALL columns, when
+  // that fits the caller's budget (< 0: three tenths of the device memory that is free now)
+  const int64_t retain_col = handoff_col + 8 * (M * L * Q2);  // + coef
+  if (p->nwin > 1 && retain_bytes != 0) {
+    double cap = (double)retain_bytes;
+    if (retain_bytes < 0) {
+      size_t free_b = 0, total_b = 0;
+      HIP_TRY(hipSetDevice(device));
+      HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+      cap = 0.3 * (double)free_b;
+    }
+    p->retained = (double)C * (double)retain_col <= cap;
+  }
+  const int64_t Ch = p->retained ? C : Cw;  // columns the hand-off arrays and the coefficients cover
   rtd_plan::HandOff& h1 = p->slot1;
   double *mu = nullptr, *w = nullptr, *invmu = nullptr, *S = nullptr, *T = nullptr, *omega = nullptr, *tau = nullptr,
          *taus0 = nullptr, *scale = nullptr, *wleg = nullptr, *mu0 = nullptr, *I0 = nullptr, *phi0 = nullptr,
@@ -561,14 +587,16 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
     A(mu0, C) A(I0, C) A(phi0, C) A(rescale, C) A(d.col_status, C)
     A(bpos, C * M * NP) A(bneg, C * M * NP) A(spoly, C * L * Ns) A(bq, C * NB * NP * NP) A(bq0, C * NB * NP)
     // intermediates: one window of Cw columns
-    A(d.Y0, Cw * M * P) A(d.att, Cw * (L + 1))
-    A(d.Ym, Cw * M * L * NP * NP) A(d.Am, Cw * M * L * NP * NP) A(d.kk, Cw * M * L * NP) A(d.Bv, Cw * M * L * Q2)
-    A(d.dq, Cw * L * Ns * Q2) A(d.zneg, Cw * L * NP) A(d.vb, Ns > 0 ? Cw * L * 4 * NP : 1) A(d.coef, Cw * M * L * Q2)
-    A(d.Fws, Cw * M * (L - 1) * Q2 * Q2) A(d.Ek, Cw * M * L * NP) A(d.need_split, Cw * M)
+    A(d.Y0, Ch * M * P) A(d.att, Ch * (L + 1))
+    A(d.Ym, Ch * M * L * NP * NP) A(d.Am, Ch * M * L * NP * NP) A(d.kk, Ch * M * L * NP) A(d.Bv, Ch * M * L * Q2)
+    A(d.dq, Ch * L * Ns * Q2) A(d.zneg, Ch * L * NP) A(d.vb, Ns > 0 ? Ch * L * 4 * NP : 1) A(d.coef, Ch * M * L * Q2)
+    A(d.Fws, Cw * M * (L - 1) * Q2 * Q2) A(d.Ek, Ch * M * L * NP) A(d.need_split, Cw * M)
     A(d.sweeps, 1) A(d.status, 1) A(d.split_any, 1)
-    if (p->pipelined) {
+    if (p->pipelined && !p->retained) {
       A(h1.Y0, Cw * M * P) A(h1.att, Cw * (L + 1)) A(h1.Ym, Cw * M * L * NP * NP) A(h1.Am, Cw * M * L * NP * NP)
       A(h1.kk, Cw * M * L * NP) A(h1.Bv, Cw * M * L * Q2) A(h1.dq, Cw * L * Ns * Q2) A(h1.zneg, Cw * L * NP) A(h1.vb, Ns > 0 ? Cw * L * 4 * NP : 1) A(h1.Ek, Cw * M * L * NP)
+    }
+    if (p->pipelined) {
       A(p->status2[1], 1) A(p->col_status2[1], C) A(p->sweeps2[1], 1)
     }
 #undef A
@@ -588,7 +616,7 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   d.omega = omega; d.tau = tau; d.taus0 = taus0; d.scale = scale; d.wleg = wleg;
   d.mu0 = mu0; d.I0 = I0; d.phi0 = phi0; d.rescale = rescale; d.bpos = bpos; d.bneg = bneg;
   d.spoly = spoly; d.bdrfq = bq; d.bdrfq0 = bq0; d.lperm = lperm;
-  if (p->nwin == 1) {
+  if (p->nwin == 1 || p->retained) {
     p->Y0_all = d.Y0;
     p->att_all = d.att;
     p->tables_cached = true;
@@ -608,10 +636,12 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
     HIP_TRY(hipMemsetAsync(p->col_status2[1], 0, sizeof(int) * (size_t)C, p->stream));
     HIP_TRY(hipMemsetAsync(p->sweeps2[1], 0, sizeof(int), p->stream));
   }
-  HIP_TRY(hipMemsetAsync(d.Bv, 0, (size_t)(reinterpret_cast<char*>(d.dq) - reinterpret_cast<char*>(d.Bv)) + (Ns > 0 ? (size_t)(Cw * L * Ns * Q2) * 8 : 0), p->stream));
+  HIP_TRY(hipMemsetAsync(d.Bv, 0, (size_t)(reinterpret_cast<char*>(d.dq) - reinterpret_cast<char*>(d.Bv)) + (Ns > 0 ? (size_t)(Ch * L * Ns * Q2) * 8 : 0), p->stream));
   if (p->pipelined) {
-    HIP_TRY(hipMemsetAsync(h1.Bv, 0, (size_t)(Cw * M * L * Q2) * 8, p->stream));
-    if (Ns > 0) HIP_TRY(hipMemsetAsync(h1.dq, 0, (size_t)(Cw * L * Ns * Q2) * 8, p->stream));
+    if (!p->retained) {
+      HIP_TRY(hipMemsetAsync(h1.Bv, 0, (size_t)(Cw * M * L * Q2) * 8, p->stream));
+      if (Ns > 0) HIP_TRY(hipMemsetAsync(h1.dq, 0, (size_t)(Cw * L * Ns * Q2) * 8, p->stream));
+    }
     // (stream priorities either way changed nothing: profiles/r03_experiments.json)
     HIP_TRY(hipStreamCreateWithFlags(&p->eig_stream, hipStreamNonBlocking));
     for (hipEvent_t* e : {&p->ev_eig[0], &p->ev_eig[1], &p->ev_bc[0], &p->ev_bc[1], &p->ev_fork})
@@ -622,7 +652,7 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   return 0;
 }
 
-int rtd_plan_create_windowed(const rtd_dims* dims, int32_t device, int32_t work_columns, rtd_plan** out) {
+int rtd_plan_create_retained(const rtd_dims* dims, int32_t device, int32_t work_columns, int64_t retain_bytes, rtd_plan** out) {
   if (!dims || !out) return fail(RTD_ERR_ARG, "null argument");
   *out = nullptr;
   const int N = dims->nquad / 2;
@@ -636,7 +666,7 @@ int rtd_plan_create_windowed(const rtd_dims* dims, int32_t device, int32_t work_
   if (N > 64) return fail(RTD_ERR_ARG, "NQuad > 128 is not supported by this build (N = NQuad/2 <= 64)");
   HIP_TRY(hipSetDevice(device));
   rtd_plan* p = new rtd_plan();
-  const int rc = plan_build(p, dims, device, work_columns);
+  const int rc = plan_build(p, dims, device, work_columns, retain_bytes);
   if (rc) {
     const std::string keep = g_err;  // rtd_plan_destroy must not lose the message
     rtd_plan_destroy(p);
@@ -644,6 +674,16 @@ int rtd_plan_create_windowed(const rtd_dims* dims, int32_t device, int32_t work_
     return rc;
   }
   *out = p;
+  return 0;
+}
+
+int rtd_plan_create_windowed(const rtd_dims* dims, int32_t device, int32_t work_columns, rtd_plan** out) {
+  return rtd_plan_create_retained(dims, device, work_columns, 0, out);
+}
+
+int rtd_plan_retained(rtd_plan* p, int32_t* retained) {
+  if (!p || !retained) return fail(RTD_ERR_ARG, "null argument");
+  *retained = p->nwin == 1 || p->retained ? 1 : 0;
   return 0;
 }
 
@@ -1125,11 +1165,13 @@ int rtd_plan_evaluate(rtd_plan* p, int32_t ntau, const double* tau, int32_t nphi
   if (rc) return rc;
   const bool skip_nt = (antiderivative & 2) != 0;
   RtdEval e = make_eval(p, antiderivative & 1, u != nullptr);
-  // one window: the intermediates of the solve are resident, only the evaluation kernels run.  Several windows: they
-  // are solved again, window by window, with the evaluation behind each (the throughput form rtd_plan_run is the
-  // intended entry point for such batches).
-  rc = launch_windows(p, p->nwin > 1, &e, p->have_nt && !skip_nt, [](int, int64_t, int) { return 0; }, false);
+  // one window, or a retained plan (rtd_plan_create_retained): what the evaluators need of the solve is resident for every
+  // column, only the evaluation kernels run.  Several windows without retention: they are solved again, window by window,
+  // with the evaluation behind each (the throughput form rtd_plan_run is the intended entry point for such batches).
+  const bool solve_again = p->nwin > 1 && !p->retained;
+  rc = launch_windows(p, solve_again, &e, p->have_nt && !skip_nt, [](int, int64_t, int) { return 0; }, false);
   if (rc) return rc;
+  if (p->pipelined && !solve_again) p->fork_needed = true;  // the next solve's eigen stream must not overwrite what this pass still reads
   if (ulast) {  // queued before the fetch, whose status check drains the stream: a numerical failure of SOME columns must not
     //             leave the healthy columns' ulast unwritten (numeric_errors = "nan" keeps them)
     const int64_t C = p->d.C, Qr = 2 * p->d.N;
@@ -1183,7 +1225,10 @@ int rtd_plan_get_tensors(rtd_plan* p, int32_t column, double* GC, double* K, dou
   hipStream_t s = p->stream;
   RtdDev d = p->d;
   int local = column;
-  if (p->nwin > 1) {  // the column is solved again on its own (its window's intermediates may have been overwritten)
+  if (p->nwin > 1 && p->retained) {  // the column's own place in the retained arrays
+    d = window_dev(p, column, 1);
+    local = 0;
+  } else if (p->nwin > 1) {  // the column is solved again on its own (its window's intermediates may have been overwritten)
     d = window_dev(p, column, 1);
     local = 0;
     if (!p->tables_cached || !p->tables_valid) rtd_launch_tables(d, s, false);

@@ -12,9 +12,11 @@ def _f64(a):
 
 
 class Plan:
-    def __init__(self, prep, device=0, work_columns=0):
+    def __init__(self, prep, device=0, work_columns=0, retain_bytes=0):
         """prep: dict from _prepare.prepare_columns.  work_columns: columns whose intermediates are resident at a time
-        (0: sized by the library, include/rtd.h: rtd_plan_create_windowed)."""
+        (0: sized by the library, include/rtd.h: rtd_plan_create_windowed).  retain_bytes: budget for keeping what the
+        evaluators need of a solve for ALL columns of a plan of several windows, so that evaluate() does not solve again
+        (include/rtd.h: rtd_plan_create_retained; -1: automatic, 0: never -- the throughput form)."""
         lib = _lib.load()
         self._lib = lib
         self.prep = prep
@@ -23,7 +25,7 @@ class Plan:
         dims = _lib.rtd_dims(prep["C"], prep["L"], 2 * prep["N"], prep["P"], prep["M"], prep["Ns"],
                              prep["NBDRF"], int(prep["beam"]))
         h = C.c_void_p()
-        _lib.check(lib.rtd_plan_create_windowed(C.byref(dims), device, int(work_columns), C.byref(h)))
+        _lib.check(lib.rtd_plan_create_retained(C.byref(dims), device, int(work_columns), int(retain_bytes), C.byref(h)))
         self._h = h
         mu, w = _f64(prep["mu"]), _f64(prep["W"])
         _lib.check(lib.rtd_plan_set_quadrature(h, _lib.dptr(mu), _lib.dptr(w)))
@@ -181,6 +183,12 @@ class Plan:
         """Treat the resident inputs as new: the next solve recomputes the per-column Legendre tables at -mu0 and the beam
         attenuations it would otherwise keep from run to run (include/rtd.h: rtd_plan_invalidate_tables)."""
         _lib.check(self._lib.rtd_plan_invalidate_tables(self._h))
+
+    def retained(self):
+        """True when evaluate() after a solve only evaluates (one window, or the evaluator state of every column is resident)."""
+        r = C.c_int32()
+        _lib.check(self._lib.rtd_plan_retained(self._h, C.byref(r)))
+        return bool(r.value)
 
     def windows(self):
         """(columns per window, number of windows) of the plan's work arena."""

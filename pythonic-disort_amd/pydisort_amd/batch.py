@@ -43,7 +43,7 @@ class BatchSolution:
 def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLeg=None, NFourier=None,
                    b_pos=0, b_neg=0, only_flux=False, f_arr=0, NT_cor=False, bdrf_q=None, bdrf_q0=None,
                    s_poly_coeffs=None, device=0, bdrf_samples=None, NBDRF=None, mode_shard=None, work_columns=0,
-                   device_prepare=False, numeric_errors="raise", _defer_solve=False):
+                   device_prepare=False, numeric_errors="raise", retain="auto", _defer_solve=False):
     """Like ``pydisort`` with a leading column axis on every atmospheric input:
     tau_arr, omega_arr, f_arr [C, L]; Leg_coeffs_all [C, L, NLeg_all]; mu0, I0, phi0 [C];
     b_pos / b_neg: scalar, [C], [C, N] or [C, N, NFourier]; s_poly_coeffs [C, L, Ns];
@@ -63,6 +63,11 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
     columns are NaN in the returned arrays, every other column keeps its result: one bad column does not cost the batch).
     work_columns: columns whose intermediates are resident on the device at a time (0: sized by the library); batches
     larger than that are solved window by window (include/rtd.h: rtd_plan_create_windowed).
+    retain: the returned evaluators keep what they need of the solve for EVERY column -- as the reference's closures keep
+    GC_collect, K_collect, B_collect (_assemble_intensity_and_fluxes.py:170-262) -- so that calling them again costs an
+    evaluation, not a solve, also for a batch of several windows (include/rtd.h: rtd_plan_create_retained; 3.1 MB per
+    20-layer 32-stream column).  "auto" (default): while that fits three tenths of the free device memory; an int: that many
+    bytes; False: never (every call of an evaluator on a batch of several windows then solves them again).
     All columns share NQuad, NLeg, NFourier and the layer count.  Returns (mu_arr, BatchSolution)."""
     tau_arr = np.atleast_2d(np.asarray(tau_arr, float))
     C, L = tau_arr.shape
@@ -142,7 +147,15 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
         NT_cor = NT_cor and r == 0
     if numeric_errors not in ("raise", "nan"):
         raise ValueError('numeric_errors must be "raise" or "nan".')
-    plan = Plan(prep, device=device, work_columns=work_columns)
+    if retain == "auto":
+        retain_bytes = 0 if _defer_solve else -1  # (the throughput callers drive plan.run() themselves: nothing to keep)
+    elif retain is True:
+        retain_bytes = -1
+    elif retain is False or retain is None:
+        retain_bytes = 0
+    else:
+        retain_bytes = int(retain)
+    plan = Plan(prep, device=device, work_columns=work_columns, retain_bytes=retain_bytes)
     plan.numeric_errors = numeric_errors
     if bdrf_samples is not None:
         plan.set_bdrf_samples(bdrf_samples[0], bdrf_samples[1] if np.any(I0 > 0) else None)
