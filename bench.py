@@ -413,14 +413,15 @@ def single_column_leg(device, calls=30):
 
 def many_stream_leg(device, columns=32):
     """The other reading of BASELINE configs[4]: 128 streams, 50 layers, Fourier modes capped at 64
-    -- beyond that the reference's own Legendre tables overflow -- on the NP = 64 instances (round 4: four-wavefronts-per-chain
-    boundary-condition kernels, csrc/rtd_bc_wide.hip; readlane Cholesky and DPP-broadcast assembly in the eigen kernel); parity against
-    the reference's output for the 128-stream golden case (tests/golden/synth/q128.npz)."""
-    import warnings
+    -- beyond that the reference's own Legendre tables overflow -- on the NP = 64 instances (four-wavefronts-per-chain
+    boundary-condition kernels, csrc/rtd_bc_wide.hip; readlane Cholesky and DPP-broadcast assembly in the eigen kernel).  Parity:
+    the first two columns of the TIMED batch are the reference-computed golden columns (tests/golden/synth/q128_L50.npz: the same
+    128 x 50 x 64 workload at its full depth) and are compared at the interfaces in the timed pass's own results."""
     import pydisort_amd
     from pydisort_amd import synthetic
-    cfg = synthetic.cfg4_columns(columns, L=50, NQuad=128, g_hi=0.9)
-    cfg["NFourier"] = 64
+    maker_kw, nf, ncol = synthetic.many_stream_deep_cases()["q128_L50"]
+    cfg = synthetic.cfg4_columns(columns, **maker_kw)
+    cfg["NFourier"] = nf
     _, sol = pydisort_amd.pydisort_batch(device=device, _defer_solve=True, **cfg)
     plan = sol.plan
     tau = np.concatenate((np.zeros((columns, 1)), cfg["tau_arr"]), axis=1)
@@ -431,21 +432,24 @@ def many_stream_leg(device, columns=32):
     plan.run()
     plan.synchronize()
     rate = columns / (time.perf_counter() - t0)
+    got = plan.fetch()
     cw, nwin = plan.windows()
     plan.close()
-    kw, tau_pts = synthetic.many_stream_cases()["q128"]
-    z = np.load(os.path.join(ROOT, "tests", "golden", "synth", "q128.npz"))
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        res = pydisort_amd.pydisort(device=device, **kw)
-    u, want = res[4](tau_pts, z["phi"]), z["u"]
-    res[1].__self__.plan.close()
-    diff = np.abs(u - want)
-    sig = np.abs(want) > 1e-8 * np.max(np.abs(want))
+    z = np.load(os.path.join(ROOT, "tests", "golden", "synth", "q128_L50.npz"))
+    worst = worst_pw = 0.0
+    for i in range(ncol):
+        pts = np.searchsorted(z[f"c{i}.tau_pts"], tau[i])
+        assert np.array_equal(z[f"c{i}.tau_pts"][pts], tau[i])
+        want = z[f"c{i}.u"][:, pts, :3]
+        diff = np.abs(got["u"][i] - want)
+        sig = np.abs(want) > 1e-8 * np.max(np.abs(want))
+        worst = max(worst, float(diff.max() / np.max(np.abs(want))))
+        worst_pw = max(worst_pw, float((diff[sig] / np.abs(want[sig])).max()))
     return {"value": rate, "unit": "column-solves/sec", "columns": columns, "columns_per_window": cw, "windows": nwin,
-            "workload": "128 streams, 50 layers, 64 Fourier modes (Henyey-Greenstein, g up to 0.9, delta-M): rtd_eigen_kernel<64, 2> + rtd_iface_mfma_kernel + rtd_sweep_wide_kernel (round 4; 253 col/s on the generic instances of round 3)",
-            "parity": {"max_scale_rel": float(diff.max() / np.max(np.abs(want))), "max_rel_dI": float((diff[sig] / np.abs(want[sig])).max()),
-                       "columns_checked": 1, "against": "reference-computed golden tests/golden/synth/q128.npz (128 streams, 2 layers, 64 modes)"}}
+            "workload": "128 streams, 50 layers, 64 Fourier modes (Henyey-Greenstein, g up to 0.9, delta-M): rtd_eigen_kernel<64, 2> + rtd_iface_mfma_kernel + rtd_sweep_wide_kernel",
+            "parity_in_batch": {"max_scale_rel": worst, "max_rel_dI": worst_pw, "columns_checked": ncol,
+                                "against": "reference-computed goldens tests/golden/synth/q128_L50.npz (128 streams, 50 layers, 64 modes: this workload), "
+                                           "taken from the results of the timed pass at the 51 interfaces x 3 azimuths"}}
 
 
 def all_cloud_leg(device, columns=16384, window=256, passes=3):

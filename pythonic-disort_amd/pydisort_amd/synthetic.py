@@ -122,6 +122,16 @@ def literal_cases():
     return cases
 
 
+def many_stream_deep_cases():
+    """The 66 ... 128-stream workloads that bench.py and tools/many_stream_timing.py TIME, at their full depth (the reference is
+    finite there: 2 N_modes <= 170 - streams): name -> (keyword arguments of ``cfg4_columns``, NFourier,
+    number of golden columns).  The timed batches start with these very columns.
+    q128_L50 : 128 streams x 50 layers x 64 modes (BASELINE configs[4] in its 128-stream reading);
+    q96_L20  : 96 streams x 20 layers x 48 modes;   q72_L50 : 72 streams x 50 layers x 36 modes."""
+    return {"q128_L50": (dict(L=50, NQuad=128, g_hi=0.9), 64, 2), "q96_L20": (dict(L=20, NQuad=96, g_hi=0.9), 48, 2),
+            "q72_L50": (dict(L=50, NQuad=72, g_hi=0.9), 36, 1)}
+
+
 def many_stream_cases():
     """More than 64 streams (the reference has no cap on NQuad; its associated-Legendre tables overflow when l + m passes
     ~170, so NFourier stays where the reference itself is finite):

@@ -30,7 +30,7 @@ sys.dont_write_bytecode = True
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "ref")
-MAX_EVALS_PER_CLOSURE = 10
+MAX_EVALS_PER_CLOSURE = 100000  # every evaluation a test performs (round 5; rounds 1-4 kept the first ten per closure)
 
 sys.path.insert(0, os.path.join(REF, "src"))
 sys.path.insert(0, os.path.join(REF, "pydisotest"))

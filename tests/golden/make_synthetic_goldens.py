@@ -33,10 +33,11 @@ def lambertian_like(q, q0):
     return [mk(m) for m in range(q.shape[0])]
 
 
-def run(name, cfg, ncol):
+def run(name, cfg, ncol, **extra):
     out = {}
     for i in range(ncol):
         kw = synthetic.column_kwargs(cfg, i)
+        kw.update(extra)
         if "bdrf_q" in cfg:
             kw["BDRF_Fourier_modes"] = lambertian_like(cfg["bdrf_q"][i], cfg["bdrf_q0"][i])
         tau_arr = kw["tau_arr"]
@@ -102,6 +103,10 @@ if __name__ == "__main__":
     if "--cfg5-only" in sys.argv:  # after a change of synthetic.cfg5_columns
         run("cfg5", synthetic.cfg5_columns(8), 8)
         sys.exit(0)
+    if "--many-streams-deep-only" in sys.argv:  # round 5: the 66 ... 128-stream workloads that are TIMED, at their full depth
+        for name, (maker_kw, nf, ncol) in synthetic.many_stream_deep_cases().items():
+            run(name, synthetic.cfg4_columns(ncol, **maker_kw), ncol, NFourier=nf)
+        sys.exit(0)
     if "--many-streams-only" in sys.argv:  # 72 / 96 / 128 streams (round 3: the 64-stream cap went)
         for name, (kw, tau_pts) in synthetic.many_stream_cases().items():
             run_single(name, kw, tau_pts)
@@ -117,3 +122,5 @@ if __name__ == "__main__":
     run("cfg3_big", synthetic.cfg3_columns(4, big=True), 4)
     run("cfg3_small", synthetic.cfg3_columns(4, big=False), 4)
     run("cfg5", synthetic.cfg5_columns(8), 8)
+    for name, (maker_kw, nf, ncol) in synthetic.many_stream_deep_cases().items():
+        run(name, synthetic.cfg4_columns(ncol, **maker_kw), ncol, NFourier=nf)

@@ -670,6 +670,38 @@ def test_beyond_64_streams_vs_reference(amd, name):
     assert Fp.__self__.plan.max_sweeps() <= 14
 
 
+@pytest.mark.parametrize("name", ["q96_L20", "q72_L50", "q128_L50"])
+def test_timed_many_stream_workloads_at_full_depth_vs_reference(amd, name):
+    """The 66 ... 128-stream workloads that bench.py / tools/many_stream_timing.py time -- 96 x 20 x 48, 72 x 50 x 36 and
+    128 streams x 50 layers x 64 modes -- at their full depth against the reference's own outputs for the first columns of those
+    very batches (tests/golden/synth/q*_L*.npz; round-4 verdict: the only 128-stream golden was two layers deep): every
+    interface and mid-layer point, four azimuths, u0 and the fluxes; the golden columns sit in a batch with others behind them."""
+    from conftest import record_parity
+    from pydisort_amd import synthetic
+    maker_kw, nf, ncol = synthetic.many_stream_deep_cases()[name]
+    z = np.load(f"{goldens.HERE}/golden/synth/{name}.npz")
+    C = ncol + 3
+    cfg = synthetic.cfg4_columns(C, **maker_kw)
+    cfg["NFourier"] = nf
+    _, sol = amd.pydisort_batch(**cfg)
+    npts = len(z["c0.tau_pts"])
+    tau = np.stack([z[f"c{i}.tau_pts"] if i < ncol else np.linspace(0.0, cfg["tau_arr"][i, -1], npts) for i in range(C)])
+    u, u0, fu, (fdd, fdir) = sol.u(tau, z["phi"]), sol.u0(tau), sol.flux_up(tau), sol.flux_down(tau)
+    worst = worst_pw = 0.0
+    for i in range(ncol):
+        a, b = goldens.max_rel_err(u[i], z[f"c{i}.u"])
+        worst, worst_pw = max(worst, a), max(worst_pw, b)
+        scale = np.max(np.abs(z[f"c{i}.u"]))
+        assert np.max(np.abs(u0[i] - z[f"c{i}.u0"])) / scale < 1e-7
+        assert np.allclose(fu[i], z[f"c{i}.flux_up"], rtol=1e-8, atol=1e-10 * scale)
+        assert np.allclose(fdd[i], z[f"c{i}.flux_down_diffuse"], rtol=1e-8, atol=1e-10 * scale)
+        assert np.allclose(fdir[i], z[f"c{i}.flux_down_direct"], rtol=1e-12, atol=1e-300)
+    record_parity("synthetic/" + name, worst, worst_pw, 1e-7, PW_TOL, against="reference")
+    assert worst < 1e-7 and worst_pw < PW_TOL
+    assert sol.plan.max_sweeps() <= 14
+    sol.plan.close()
+
+
 def test_beyond_64_streams_feature_paths(amd):
     """The other entry points at more than 64 streams: Nakajima-Tanaka corrections, antiderivatives and the Fourier-error
     output at 80 streams against the oracle; a batch of 96-stream columns against per-column calls (bit-identical), as a

@@ -69,6 +69,26 @@ def test_oracle_beyond_64_streams(name):
     assert np.allclose(Fp(tau_pts), z["flux_up"], rtol=1e-9, atol=1e-11 * scale)
 
 
+@pytest.mark.parametrize("name", ["q96_L20", "q72_L50", "q128_L50"])
+def test_oracle_on_the_timed_many_stream_workloads_at_full_depth(name):
+    """The 66 ... 128-stream workloads that are timed (96 x 20 x 48, 72 x 50 x 36, 128 x 50 x 64: pydisort_amd.synthetic.
+    many_stream_deep_cases) at their full depth, first column, against the reference run here (round-4 verdict: the only
+    128-stream golden was 2 layers deep)."""
+    import os
+    import warnings
+    from pydisort_amd import synthetic
+    maker_kw, nf, ncol = synthetic.many_stream_deep_cases()[name]
+    cfg = synthetic.cfg4_columns(1, **maker_kw)
+    z = np.load(os.path.join(goldens.HERE, "golden", "synth", name + ".npz"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mu_arr, Fp, Fm, u0, u = O.pydisort(NFourier=nf, **synthetic.column_kwargs(cfg, 0))
+    tau_pts = z["c0.tau_pts"]
+    scale = np.max(np.abs(z["c0.u"]))
+    assert np.max(np.abs(u(tau_pts, z["phi"]) - z["c0.u"])) / scale < 1e-8
+    assert np.allclose(Fp(tau_pts), z["c0.flux_up"], rtol=1e-9, atol=1e-11 * scale)
+
+
 def test_oracle_against_high_precision_truth():
     """How far the reference's algorithm in float64 (this oracle) is from a 40-digit solution (tools/hp_truth_m0.py):
     rounding level on a benign atmosphere, ~6e-9 when omega = 1 - 1e-6 layers are present.  GPU parity tests against
