@@ -80,7 +80,8 @@ def test_oracle_on_the_timed_many_stream_workloads_at_full_depth(name):
     maker_kw, nf, ncol = synthetic.many_stream_deep_cases()[name]
     cfg = synthetic.cfg4_columns(1, **maker_kw)
     z = np.load(os.path.join(goldens.HERE, "golden", "synth", name + ".npz"))
-    with warnings.catch_warnings():
+    from threadpoolctl import threadpool_limits
+    with warnings.catch_warnings(), threadpool_limits(2):  # (many small LAPACK calls: more BLAS threads only contend)
         warnings.simplefilter("ignore")
         mu_arr, Fp, Fm, u0, u = O.pydisort(NFourier=nf, **synthetic.column_kwargs(cfg, 0))
     tau_pts = z["c0.tau_pts"]
