@@ -221,10 +221,51 @@ def pmc_child(columns):
         sol.plan.close()
 
 
+FP64_COUNTERS = ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64",
+                 "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE")
+LIVE_COUNTERS = {}  # {kernel instance: {counter: mean per launch, "seconds": mean duration under the profiler}} of the FP64 pass
+
+
+def executed_flops(c):
+    """FP64 operations a launch EXECUTED, from the SQ instruction counters (rocprofiler-sdk's own FLOP formula for gfx9:
+    counter_defs.yaml `TOTAL_64_OPS`): every FMA wave-instruction = 2 x 64, ADD / MUL / transcendental = 64, an MFMA 'MOP' = 512.
+    Wave-instructions count all 64 lanes whatever the EXEC mask and the padding streams: an upper bound on the useful ones."""
+    return 64.0 * (2.0 * c.get("SQ_INSTS_VALU_FMA_F64", 0.0) + c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0)
+                   + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)) + 512.0 * c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
+
+
+def executed_roofline(kernel, seconds_per_launch):
+    """What a kernel really executed against the FP64 peak -- beside `frac`, which prices LAPACK's operation count for the
+    reference's algorithm and is therefore a normalised throughput, not a utilisation.  From the live FP64 counter
+    pass of this bench.py invocation; None when no profiler ran.
+      executed_tflops / executed_frac : counted FP64 operations per launch / the kernel's HIP-event duration (/ 78.6 TFLOP/s)
+      valu_issue_frac                 : 4 cycles x wave-level VALU instructions / SIMD cycles while the kernel ran (FP64 issue-bound at 1)
+      sustained_clock_ghz             : GRBM_GUI_ACTIVE / 8 XCDs / the dispatch's duration in the profiled pass
+      peak_at_sustained_clock         : 78.6 TFLOP/s x sustained clock / 2.4 GHz -- the peak the chip offers at the clock it holds"""
+    c = LIVE_COUNTERS.get(kernel.replace(", ", ","))
+    if not c or not seconds_per_launch:
+        return None
+    fl = executed_flops(c)
+    out = {"executed_flop_per_launch": fl, "executed_tflops": fl / seconds_per_launch / 1e12,
+           "executed_frac": fl / seconds_per_launch / 1e12 / FP64_PEAK_TFLOPS,
+           "executed_what": "FP64 operations counted by SQ_INSTS_VALU_{FMA x 2, ADD, MUL, TRANS}_F64 x 64 lanes + SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 "
+                            "(rocprofv3 --pmc pass of this run) / the kernel's HIP-event duration: a UTILISATION of the FP64 units; "
+                            "`frac` is LAPACK's operation count for the reference's algorithm over the same time: a normalised throughput"}
+    if c.get("SQ_BUSY_CYCLES"):
+        out["valu_issue_frac"] = 4.0 * c.get("SQ_INSTS_VALU", 0.0) / (c["SQ_BUSY_CYCLES"] / 32.0 * 1024.0)
+    if c.get("GRBM_GUI_ACTIVE") and c.get("seconds"):
+        ghz = c["GRBM_GUI_ACTIVE"] / 8.0 / c["seconds"] / 1e9
+        out["sustained_clock_ghz"] = ghz
+        out["peak_at_sustained_clock"] = FP64_PEAK_TFLOPS * ghz / 2.4
+        out["executed_frac_of_peak_at_sustained_clock"] = out["executed_tflops"] / out["peak_at_sustained_clock"]
+    return out
+
+
 def live_traffic(columns, timeout=240):
     """HBM bytes per launch of every kernel of the headline config and of BASELINE's other configs, measured NOW: two rocprofv3
     passes (FETCH_SIZE and WRITE_SIZE cannot share one) of `bench.py --pmc-child`, corrected as MI355X_MICROARCH.md prescribes
-    (KiB units; FETCH_SIZE doubled on gfx950).  Returns {kernel name with its template arguments: bytes per launch} -- the
+    (KiB units; FETCH_SIZE doubled on gfx950), and a third pass with the FP64 instruction counters (FP64_COUNTERS -> LIVE_COUNTERS,
+    read by executed_roofline).  Returns {kernel name with its template arguments: bytes per launch} -- the
     plain name too where only one instance of a kernel ran -- or None when rocprofv3 is not usable here."""
     import csv
     import re
@@ -238,25 +279,46 @@ def live_traffic(columns, timeout=240):
     env = dict(os.environ, RTD_NO_PIPELINE="1", TMPDIR="/tmp")
     got = {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), FP64_COUNTERS):
             out = tempfile.mkdtemp(prefix="rtd_pmc_", dir="/tmp")
             try:
-                r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                r = subprocess.run([exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out, "--",
                                     sys.executable, os.path.abspath(__file__), "--pmc-child", "--columns", str(columns)],
                                    cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
                 files = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
                 if r.returncode != 0 or not files:
-                    print(f"[bench] live traffic pass {counter} failed (rc {r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
+                    print(f"[bench] live counter pass {counters[0]} ... failed (rc {r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
+                    if counters is FP64_COUNTERS:
+                        continue  # the traffic passes stand on their own
                     return None
-                acc = {}
+                acc, dur = {}, {}
                 with open(files[0]) as f:
                     for row in csv.DictReader(f):
                         m = re.search(r"rtd_\w+(<[^>]*>)?", row["Kernel_Name"])
-                        if m and row["Counter_Name"] == counter:
-                            acc.setdefault(m.group(0).replace(", ", ","), []).append(float(row["Counter_Value"]))
-                for k, v in acc.items():
+                        if m and row["Counter_Name"] in counters:
+                            k = m.group(0).replace(", ", ",")
+                            acc.setdefault((k, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+                            if row.get("Start_Timestamp") and row.get("End_Timestamp"):
+                                dur.setdefault(k, {})[row.get("Dispatch_Id")] = (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-9
+                if counters is FP64_COUNTERS and not dur:  # timestamps in the kernel trace of the same pass
+                    for path in [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("kernel_trace.csv")]:
+                        with open(path) as f:
+                            for row in csv.DictReader(f):
+                                m = re.search(r"rtd_\w+(<[^>]*>)?", row.get("Kernel_Name", ""))
+                                if m:
+                                    dur.setdefault(m.group(0).replace(", ", ","), {})[row.get("Dispatch_Id")] = \
+                                        (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-9
+                for (k, name), v in acc.items():
                     v = v[len(v) // 2:]  # the second (measured) pass
-                    got.setdefault(k, {})[counter] = sum(v) / len(v)
+                    if counters is FP64_COUNTERS:
+                        LIVE_COUNTERS.setdefault(k, {})[name] = sum(v) / len(v)
+                    else:
+                        got.setdefault(k, {})[name] = sum(v) / len(v)
+                for k, d in dur.items():
+                    v = list(d.values())
+                    v = v[len(v) // 2:]
+                    if counters is FP64_COUNTERS and k in LIVE_COUNTERS:
+                        LIVE_COUNTERS[k]["seconds"] = sum(v) / len(v)
             finally:
                 shutil.rmtree(out, ignore_errors=True)
     except Exception as e:  # profiler missing, timeout, unreadable output: the committed passes are used instead
@@ -286,9 +348,19 @@ def roofline_of(stage, fl, cols_per_launch, kernel_names):
     dom = "eigen" if ms["eigen"] >= ms["bc"] else "bc"
     dom_flops = fl["bc"] if dom == "bc" else fl["asm"] + fl["jacobi"] + fl["post"]
     achieved = dom_flops * cols_per_launch / (ms[dom] * 1e-3) / 1e12
-    return {"bound": "fp64-valu", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+    roof = {"bound": "fp64-valu", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / FP64_PEAK_TFLOPS, "kernel": kernel_names[dom], "kernel_ms_per_launch": ms,
-            "columns_per_launch": cols_per_launch}, ms
+            "columns_per_launch": cols_per_launch,
+            "frac_is": "a normalised throughput: LAPACK's operation count for the reference's algorithm (SURVEY 8(d)) over the kernel's "
+                       "time; the utilisation of the FP64 units is `executed_frac`"}
+    ex = executed_roofline(kernel_names[dom], ms[dom] * 1e-3)
+    if ex:
+        roof.update(ex)
+    other = "bc" if dom == "eigen" else "eigen"
+    ex2 = executed_roofline(kernel_names[other], ms[other] * 1e-3) if ms.get(other) else None
+    if ex2:
+        roof["other_kernel"] = dict(kernel=kernel_names[other], ms_per_launch=ms[other], **{k: v for k, v in ex2.items() if k != "executed_what"})
+    return roof, ms
 
 
 def golden_parity(name, maker, kwargs, device):

@@ -9,7 +9,7 @@ find $out/stats -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $out/kern
 rm -rf $out/stats
 head -8 $out/kernel_stats.csv
 i=0
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" ${RTD_EXTRA_PMC:+"$RTD_EXTRA_PMC"}; do
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU GRBM_GUI_ACTIVE" ${RTD_EXTRA_PMC:+"$RTD_EXTRA_PMC"}; do
   i=$((i+1))
   timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc$i -- "$@" > $out/pmc$i.log 2>&1
   f=$(find $out/pmc$i -name '*counter_collection.csv' | head -1)
