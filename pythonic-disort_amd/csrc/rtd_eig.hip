@@ -111,18 +111,41 @@ __device__ __forceinline__ double approx_rcp(double x) {
 #define RTD_JAC_TOL 1e-14
 #endif
 
+// One level of a transposed reduction across the lane bit O: the lanes with (lane & O) == 0 keep lo and take the partner's lo, the
+// others keep hi and take the partner's hi:  result = (lane & O ? hi : lo) + value of lane ^ O of (lane & O ? hi : lo)... which is
+// exactly what ONE row / half swap of the two registers gives, with no select and no LDS crossbar: v_permlane16_swap exchanges the
+// odd 16-lane rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the
+// lower half of the second -- afterwards first + second is the level's result in every lane.  (O = 16 and 32 were ds_swizzle /
+// ds_bpermute exchanges behind two selects; their latency-hiding schedule held both operand sets of every element at once: the beam
+// stage of the 64-stream kernel was where its 68-110 spilled registers came from.)
+template <int O, bool SWAP>
+__device__ __forceinline__ double level_add(const double lo, const double hi, const bool is_hi) {
+  if constexpr (SWAP && (O == 16 || O == 32)) {
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    u2 a, b;
+    if constexpr (O == 16) {
+      a = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(lo), (unsigned)__double2loint(hi), false, false);
+      b = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(lo), (unsigned)__double2hiint(hi), false, false);
+    } else {
+      a = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(lo), (unsigned)__double2loint(hi), false, false);
+      b = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(lo), (unsigned)__double2hiint(hi), false, false);
+    }
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+  } else {
+    const double keep = is_hi ? hi : lo, send = is_hi ? lo : hi;
+    return keep + xor_lane<O>(send);
+  }
+}
+
 // Transposed reduction: every lane enters with NP terms v[0..NP) (term i belongs to row i) and leaves with the sum of
-// row `j` over the NP lanes of its group -- NP-1 swizzle-adds in registers, no LDS memory.
+// row `j` over the NP lanes of its group -- NP-1 exchange-adds in registers, no LDS memory.
 template <int NP, int O>
 struct TransposeStep {
   static __device__ __forceinline__ void run(double (&v)[NP], const int j) {
     const bool hi = (j & O) != 0;
 #pragma unroll
-    for (int i = 0; i < O; ++i) {
-      const double keep = hi ? v[i + O] : v[i];
-      const double send = hi ? v[i] : v[i + O];
-      v[i] = keep + xor_lane<O>(send);
-    }
+    for (int i = 0; i < O; ++i) v[i] = level_add<O, NP == 32>(v[i], v[i + O], hi);  // (the 128-stream kernel keeps its ds_bpermute form:
+    //                                                                                 with the swaps it spilled 123 registers and ran 3.7 x slower)
     TransposeStep<NP, O / 2>::run(v, j);
   }
 };
@@ -252,6 +275,75 @@ struct RowFmacDpp64 {
     if constexpr (I + 1 < 16) RowFmacDpp64<I + 1>::run(acc, y, coef);
   }
 };
+
+// acc += (lane K of the caller's own 16-lane DPP row of `src`) * mul: one v_fmac_f64_dpp row_newbcast.  `src` comes from an LDS
+// load (no VALU write in front of the DPP read: no hazard for tools/check_dpp_hazards.py to find).
+template <int K>
+__device__ __forceinline__ void fmac_bcast(double& acc, const double src, const double mul) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(K));
+}
+
+// ---- NP = 32, round 5: the triangular products of the eigen stage with the rows of L SPREAD OVER THE LANES ----------------
+// F = L^T R, Y = L^-T Z and A = L Z were 528 FMAs per lane each, every one with its multiplier L[r][i] from a broadcast LDS read
+// (all 32 lanes of a problem read one address): 2 LDS cycles per read against 1 DP-ALU cycle per FMA with every CU's eight
+// wavefronts doing the same -- LDS-bandwidth-bound, 10-12 k cycles per product and wavefront at two wavefronts per SIMD (s_memtime
+// stamps, profiles/r05_eigen32_phases.txt).  Now lane t of every DPP row loads L[r][t] and L[r][16 + t] of row r ONCE (48 conflict-
+// free reads per product: the packed row is contiguous) and every FMA takes its multiplier as a DPP row broadcast of those two
+// registers.  Lanes t > r hold whatever follows row r in the packed triangle: they are never broadcast (i <= r at compile time).
+//   F (column j of R in the lane):  w[i]   += L[r][i] qcol[r]            for i <= r      (accumulators independent)
+//   Y (back substitution):          ya[r]  *= 1 / L[r][r];  ya[i] -= L[r][i] ya[r]      for i < r, r = 31 ... 0
+//   A (row r of L):                 aa[r]   = sum_{i <= r} L[r][i] zc[i]                 (two accumulation chains per row)
+struct LRow32 {
+  double lo, hi;  // lane t: L[r][t], L[r][16 + t]
+  template <int R>
+  static __device__ __forceinline__ LRow32 load(const double* L_, const int t) {
+    LRow32 x;
+    x.lo = L_[R * (R + 1) / 2 + t];
+    x.hi = R >= 16 ? L_[R * (R + 1) / 2 + 16 + t] : 0.0;
+    return x;
+  }
+};
+template <int R, int I, int IEND>
+struct AxpyRow32 {  // acc[i] += L[R][i] * mul for i = I .. IEND - 1
+  static __device__ __forceinline__ void run(double (&acc)[32], const LRow32& row, const double mul) {
+    if constexpr (I < IEND) {
+      fmac_bcast<I % 16>(acc[I], I < 16 ? row.lo : row.hi, mul);
+      AxpyRow32<R, I + 1, IEND>::run(acc, row, mul);
+    }
+  }
+};
+template <int R, int I, int IEND>
+struct DotRow32 {  // a0 += sum_{i < 16} L[R][i] v[i], a1 likewise over i >= 16
+  static __device__ __forceinline__ void run(double& a0, double& a1, const LRow32& row, const double (&v)[32]) {
+    if constexpr (I < IEND) {
+      if constexpr (I < 16) fmac_bcast<I>(a0, row.lo, v[I]);
+      else fmac_bcast<I - 16>(a1, row.hi, v[I]);
+      DotRow32<R, I + 1, IEND>::run(a0, a1, row, v);
+    }
+  }
+};
+
+// transposed reduction of x[i] = a[i] * s (and of a[i] * s + b[i] * t) with the products formed inside its first level: 16
+// temporaries instead of 32 -- stage 2 of the 64-stream kernel held zc, ya, aa and 32-element temporaries (256 + registers: 68
+// spilled, their reloads interleaved with the global stores of Y and A, each reload a wait for a store's acknowledgement)
+template <int NP>
+__device__ __forceinline__ double transpose_reduce_scaled(const double (&a)[NP], const double s, const int j) {
+  constexpr int O = NP / 2;
+  const bool hi = (j & O) != 0;
+  double v[O];
+#pragma unroll
+  for (int i = 0; i < O; ++i) v[i] = level_add<O, true>(a[i] * s, a[i + O] * s, hi);
+  return transpose_reduce<O>(v, j);
+}
+template <int NP>
+__device__ __forceinline__ double transpose_reduce_scaled2(const double (&a)[NP], const double s, const double (&b)[NP], const double t, const int j) {
+  constexpr int O = NP / 2;
+  const bool hi = (j & O) != 0;
+  double v[O];
+#pragma unroll
+  for (int i = 0; i < O; ++i) v[i] = level_add<O, true>(fma(b[i], t, a[i] * s), fma(b[i + O], t, a[i + O] * s), hi);
+  return transpose_reduce<O>(v, j);
+}
 
 // ---- NP = 32: blocked (2 x 2 blocks of 16) in the same one-column-per-lane layout.  A problem is two DPP rows of 16 lanes:
 // row 0 holds the columns 0..15, row 1 the columns 16..31, every lane all 32 rows of its column.  The pivot column of a
@@ -817,12 +909,16 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
     cholesky_columns32(qcol, j, sTab);  // Qm = R R^T
     RTD_ESTAMP(4);
     __syncthreads();
+    {  // F = L^T R with the rows of L spread over the lanes (LRow32)
+      const int t16 = j & 15;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      double a = 0.0;
-#pragma unroll
-      for (int r = i; r < NP; ++r) a += L_[lix(r, i)] * qcol[r];
-      w[i] = a;
+      for (int i = 0; i < NP; ++i) w[i] = 0.0;
+      static_for<0, NP>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const LRow32 row = LRow32::load<r>(L_, t16);
+        AxpyRow32<r, 0, r + 1>::run(w, row, qcol[r]);
+        if constexpr ((r & 3) == 3) RTD_FENCE();
+      });
     }
   } else if constexpr (NP == 64) {
     // 66 ... 128 streams: one wavefront per SIMD (512 registers), nothing hides a latency, and only the 256 architectural registers
@@ -1080,6 +1176,20 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
   // eigenvector blocks (:190-198): V = T^-1 L^-T Z, U = (alpha+beta) V / k = -T^-1 L Z / k; stored as
   // Y = L^-T Z and A = L Z, from which Gp = (Y - A/k)/T, Gm = (Y + A/k)/T, V^-1 = A^T T, U^-1 = -k Y^T T
   double ya[NP];
+  if constexpr (NP == 32) {  // the rows of L spread over the lanes (LRow32): ya[r] final, then its multiples leave the rows above
+    const int t16 = j & 15;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) ya[i] = zc[i];
+    static_for<0, NP>([&](auto kc) {
+      constexpr int r = NP - 1 - decltype(kc)::value;
+      ya[r] *= dinv[r];
+      if constexpr (r > 0) {
+        const LRow32 row = LRow32::load<r>(L_, t16);
+        AxpyRow32<r, 0, r>::run(ya, row, -ya[r]);
+      }
+      if constexpr ((r & 3) == 0) RTD_FENCE();
+    });
+  } else {
 #pragma unroll
   for (int i = NP - 1; i >= 0; --i) {
     double a = zc[i];
@@ -1088,19 +1198,44 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
     ya[i] = a * dinv[i];
     RTD_FENCE();
   }
-  RTD_ESTAMP(7);
-  if (valid) {
-    double* Ym = d.Ym + base * NP * NP;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) Ym[i * NP + j] = ya[i];
-    d.kk[base * NP + j] = kj;
-    const double* ts0 = d.taus0 + (long)c * (d.L + 1);
-    d.Ek[base * NP + j] = exp(-kj * (ts0[l + 1] - ts0[l]));
   }
+  RTD_ESTAMP(7);
+  // exp(-k dtau*): formed here, ahead of every store of the stage -- the load of the layer's boundaries behind them would wait for
+  // their acknowledgement (loads, stores and scratch accesses share one in-order counter)
+  double ekj = 0.0;
+  if constexpr (NP == 32) {
+    const double* ts0 = d.taus0 + (long)c * (d.L + 1);
+    ekj = exp(-kj * (ts0[l + 1] - ts0[l]));
+  }
+  auto store_Y = [&]() {
+    if constexpr (NP == 32) {  // every value in a register BEFORE the first store: a spilled one reloaded between two stores waits
+      //                         for the acknowledgement of the stores in front of it
+      asm volatile("" : "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]), "+v"(ya[3]), "+v"(ya[4]), "+v"(ya[5]), "+v"(ya[6]), "+v"(ya[7]), "+v"(ya[8]),
+                        "+v"(ya[9]), "+v"(ya[10]), "+v"(ya[11]), "+v"(ya[12]), "+v"(ya[13]), "+v"(ya[14]), "+v"(ya[15]));
+      asm volatile("" : "+v"(ya[16]), "+v"(ya[17]), "+v"(ya[18]), "+v"(ya[19]), "+v"(ya[20]), "+v"(ya[21]), "+v"(ya[22]), "+v"(ya[23]),
+                        "+v"(ya[24]), "+v"(ya[25]), "+v"(ya[26]), "+v"(ya[27]), "+v"(ya[28]), "+v"(ya[29]), "+v"(ya[30]), "+v"(ya[31]));
+    }
+    if (valid) {
+      double* Ym = d.Ym + base * NP * NP;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) Ym[i * NP + j] = ya[i];
+      d.kk[base * NP + j] = kj;
+      if constexpr (NP != 32) {
+        const double* ts0 = d.taus0 + (long)c * (d.L + 1);
+        ekj = exp(-kj * (ts0[l + 1] - ts0[l]));
+      }
+      d.Ek[base * NP + j] = ekj;
+    }
+  };
+  // NP = 32: Y leaves behind the beam stage, in one run of stores.  This kernel reloads spilled registers in the beam stage: stored
+  // here, every such reload waited for the acknowledgement of the 34 stores in front of it (the beam stage took 23 k of a
+  // wavefront's 178 k cycles: s_memtime stamps, profiles/r05_eigen32_phases.txt)
+  if constexpr (NP != 32) store_Y();
 
   // beam particular solution (:143-152, :226-231) through the spectral decomposition:
   //  s = B+ + B-, dd = B+ - B- ;  (I/mu0^2 - Qm Pm) T s = T(x+ + x-)/mu0 - Qm T (x+ - x-)
   //  T dd = mu0 [ T (x+ - x-) - Pm T s ],  Qm Pm = L^-T Z k^2 Z^T L^T
+  double bv_up = 0.0, bv_dn = 0.0;  // (NP = 32: stored with A at the end of the stage, no store in front of the stage's reloads)
   if (d.beam) {
     const double mu0 = d.mu0[c];
     // X^e_j, X^o_j of this lane's stream (:143-152): I0/(4 pi) (2 - delta_m0) omega sum_l w_l Ybar_l(-mu0) Y_l[j], from stage 1
@@ -1117,10 +1252,14 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
 #pragma unroll
       for (int i = 0; i < NP; ++i) tq += ya[i] * v0[i];
       tq *= k2;
-      double x[NP];
+      if constexpr (NP == 32) {
+        qv = transpose_reduce_scaled<NP>(ya, tq, j);
+      } else {
+        double x[NP];
 #pragma unroll
-      for (int i = 0; i < NP; ++i) x[i] = ya[i] * tq;
-      qv = transpose_reduce<NP>(x, j);
+        for (int i = 0; i < NP; ++i) x[i] = ya[i] * tq;
+        qv = transpose_reduce<NP>(x, j);
+      }
     }
     const double rmu0 = fast_rcp(mu0);
     const double rhat = 2.0 * T_j * xo * invmu_j * rmu0 - qv;
@@ -1137,7 +1276,10 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
     h *= fast_rcp(rmu0 * rmu0 - k2);
     // shat = L^-T Z h = Y h  and  t = L^T shat = Z h  (sums over the eigen-index = lanes): no triangular solve
     double sh, e;
-    {
+    if constexpr (NP == 32) {
+      sh = transpose_reduce_scaled<NP>(ya, h, j);
+      e = transpose_reduce_scaled<NP>(zc, h, j);
+    } else {
       double x[NP];
 #pragma unroll
       for (int i = 0; i < NP; ++i) x[i] = ya[i] * h;
@@ -1155,17 +1297,37 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
     const double rT = fast_rcp(T_j);
     const double s_j = sh * rT;
     const double d_j = mu0 * (txd - ps) * rT;
-    if (valid) {
-      d.Bv[base * 2 * NP + j] = 0.5 * (s_j + d_j);
-      d.Bv[base * 2 * NP + NP + j] = 0.5 * (s_j - d_j);
-      // 1/mu0 on an eigenvalue: the reference's solve (:226-231) meets a singular matrix
-      if (!(fabs(s_j) + fabs(d_j) < 1e300)) rtd_raise(d, RTD_ST_BEAM, id.mg, id.c);
+    bv_up = 0.5 * (s_j + d_j);
+    bv_dn = 0.5 * (s_j - d_j);
+    if constexpr (NP != 32) {
+      if (valid) {
+        d.Bv[base * 2 * NP + j] = bv_up;
+        d.Bv[base * 2 * NP + NP + j] = bv_dn;
+      }
     }
+    // 1/mu0 on an eigenvalue: the reference's solve (:226-231) meets a singular matrix
+    if (valid && !(fabs(s_j) + fabs(d_j) < 1e300)) rtd_raise(d, RTD_ST_BEAM, id.mg, id.c);
   }
   __syncthreads();
   RTD_ESTAMP(8);
   // A = L Z after the beam stage: its 2 NP registers are not live while that stage runs
   double aa[NP];
+  if constexpr (NP == 32) {  // the rows of L spread over the lanes (LRow32)
+    store_Y();
+    const int t16 = j & 15;
+    static_for<0, NP>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      const LRow32 row = LRow32::load<r>(L_, t16);
+      double a0 = 0.0, a1 = 0.0;
+      DotRow32<r, 0, r + 1>::run(a0, a1, row, zc);
+      aa[r] = r >= 16 ? a0 + a1 : a0;
+      if constexpr ((r & 3) == 3) RTD_FENCE();
+    });
+    asm volatile("" : "+v"(aa[0]), "+v"(aa[1]), "+v"(aa[2]), "+v"(aa[3]), "+v"(aa[4]), "+v"(aa[5]), "+v"(aa[6]), "+v"(aa[7]), "+v"(aa[8]),
+                      "+v"(aa[9]), "+v"(aa[10]), "+v"(aa[11]), "+v"(aa[12]), "+v"(aa[13]), "+v"(aa[14]), "+v"(aa[15]));
+    asm volatile("" : "+v"(aa[16]), "+v"(aa[17]), "+v"(aa[18]), "+v"(aa[19]), "+v"(aa[20]), "+v"(aa[21]), "+v"(aa[22]), "+v"(aa[23]),
+                      "+v"(aa[24]), "+v"(aa[25]), "+v"(aa[26]), "+v"(aa[27]), "+v"(aa[28]), "+v"(aa[29]), "+v"(aa[30]), "+v"(aa[31]));
+  } else {
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     double a = 0.0;
@@ -1174,20 +1336,43 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
     aa[i] = a;
     if (NP != 64 || (i & 7) == 7) RTD_FENCE();  // (NP = 64, one wavefront per SIMD: eight rows between fences, so that their LDS reads overlap)
   }
+  }
   if (valid) {
     double* Am = d.Am + base * NP * NP;
 #pragma unroll
     for (int i = 0; i < NP; ++i) Am[i * NP + j] = aa[i];
+    if constexpr (NP == 32) {
+      if (d.beam) {
+        d.Bv[base * 2 * NP + j] = bv_up;
+        d.Bv[base * 2 * NP + NP + j] = bv_dn;
+      }
+    }
   }
 
   // isotropic (thermal) source, Fourier mode 0 only (subroutines.py:746-862, _assemble.py:124).
   // A wave holds layers of ONE (c, m), so the branch is wave-uniform.
   if (d.Ns > 0 && id.mg == 0) {
     const bool act = true;
+    // NP = 32: this branch (Fourier mode 0 only: one wavefront in M) reads the lane's columns of Y and A back from the arrays it
+    // has just stored instead of keeping 128 registers alive across the beam stage for it -- with them the 64-stream kernel
+    // spilled 68-110 registers in stage 2, and every reload behind a global store is a wait for that store's acknowledgement
+    // (loads, stores and scratch accesses share one in-order counter).  A lane reads only what it wrote itself.
+    double yl[NP == 32 ? NP : 1], al[NP == 32 ? NP : 1];
+    if constexpr (NP == 32) {
+      const double* Yg = d.Ym + base * NP * NP;
+      const double* Ag = d.Am + base * NP * NP;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        yl[i] = Yg[i * NP + j];
+        al[i] = Ag[i * NP + j];
+      }
+    }
+    const auto& ya_t = [&]() -> const double(&)[NP] { if constexpr (NP == 32) return yl; else return ya; }();
+    const auto& aa_t = [&]() -> const double(&)[NP] { if constexpr (NP == 32) return al; else return aa; }();
     // zneg_j = -k_j/2 [Z^T L^-1 (T/mu)]_j = -k_j/2 sum_i Y[i][j] T_i/mu_i   (Y = L^-T Z: no triangular solve)
     double zn = 0.0;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) zn += ya[i] * (d.T[i] * d.invmu[i]);
+    for (int i = 0; i < NP; ++i) zn += ya_t[i] * (d.T[i] * d.invmu[i]);
     zn *= -0.5 * kj;
     if (valid && act) d.zneg[((long)c * d.L + l) * NP + j] = zn;
     const double* sp = d.spoly + ((long)c * d.L + l) * d.Ns;
@@ -1210,16 +1395,22 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
       // up-streams: Gp a + Gm b ; down-streams: Gm a + Gp b  (sum over eigen-index = lanes), with
       // Gp = (Y - A/k)/T, Gm = (Y + A/k)/T:  up = [Y (a+b) - A (a-b)/k]/T, down = [Y (a+b) + A (a-b)/k]/T
       const double sab = a + b, dab = (a - b) * rk;
-      double xu[NP], xd[NP];
-#pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        const double py = ya[i] * sab, pa = aa[i] * dab;
-        xu[i] = py - pa;
-        xd[i] = py + pa;
-      }
       const double rT = 1.0 / T_j;
-      const double up = transpose_reduce<NP>(xu, j) * rT;
-      const double dn = transpose_reduce<NP>(xd, j) * rT;
+      double up, dn;
+      if constexpr (NP == 32) {  // one after the other, the products formed inside the first level: 16 temporaries, not 2 x 32
+        up = transpose_reduce_scaled2<NP>(ya_t, sab, aa_t, -dab, j) * rT;
+        dn = transpose_reduce_scaled2<NP>(ya_t, sab, aa_t, dab, j) * rT;
+      } else {
+        double xu[NP], xd[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          const double py = ya_t[i] * sab, pa = aa_t[i] * dab;
+          xu[i] = py - pa;
+          xd[i] = py + pa;
+        }
+        up = transpose_reduce<NP>(xu, j) * rT;
+        dn = transpose_reduce<NP>(xd, j) * rT;
+      }
       if (valid && act) {
         double* dq = d.dq + (((long)c * d.L + l) * d.Ns + q) * 2 * NP;
         dq[j] = up;

@@ -14,7 +14,8 @@ for line in sys.stdin:
     sweeps = int(re.search(r"sweeps (\d+)", line).group(1))
     vals = {k: int(v) for k, v in re.findall(r"(\S+) (-?\d+)", line.split(":", 1)[1])}
     vals["sweeps"] = sweeps
-    rows[np_].append(vals)
+    if "total" in vals:  # (device printf output of concurrent wavefronts can interleave: incomplete lines are dropped)
+        rows[np_].append(vals)
 for np_, rs in sorted(rows.items()):
     keys = [k for k in rs[0] if k != "sweeps"]
     print(f"NP = {np_}: {len(rs)} wavefronts sampled, mean sweeps {statistics.mean(r['sweeps'] for r in rs):.2f}")
