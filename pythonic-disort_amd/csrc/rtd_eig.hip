@@ -728,6 +728,15 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
   int est_sweeps = 0;
 #endif
   RTD_ESTAMP(0);
+  // The column's beam direction and strength, read HERE: the wavefront's column is uniform and nothing has been stored yet, so these
+  // are scalar loads into SGPRs.  Read in stage 2 behind the stores of Y they were vector loads (the compiler cannot prove that the
+  // kernel's own stores leave them alone) that waited for those stores' acknowledgements: loads and stores share one in-order counter.
+  double mu0_c = 1.0, I0_c = 0.0;
+  if (d.beam) {
+    const int c0 = (int)(((long)blockIdx.x / ((d.ln + GPW - 1) / GPW)) / d.M);  // as locate()
+    mu0_c = d.mu0[c0];
+    I0_c = d.I0[c0];
+  }
   {  // ---- stage 1: assembly, Cholesky factors, F, Jacobi.  Only w, the two sums (and the LDS tile of L) leave this block.
   const int grp = threadIdx.x / NP, j = threadIdx.x % NP;
   const ProbId id = locate<NP>(d);
@@ -1159,7 +1168,12 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
   const double* wl = d.wleg + ((long)c * d.L + l) * P;
   const double om = d.omega[(long)c * d.L + l];
   const double* Ym = d.Y + (long)m * P * NP;
-  const double invmu_j = d.invmu[j], T_j = d.T[j];
+  double invmu_j = d.invmu[j], T_j = d.T[j];
+  double dts;  // the layer's scaled optical thickness (requested with the quadrature values, ahead of every store of the stage)
+  {
+    const double* ts0 = d.taus0 + (long)c * (d.L + 1);
+    dts = ts0[l + 1] - ts0[l];
+  }
   double k2 = 0.0;
 #pragma unroll
   for (int i = 0; i < NP; ++i) k2 += w[i] * w[i];
@@ -1203,10 +1217,10 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
   // exp(-k dtau*): formed here, ahead of every store of the stage -- the load of the layer's boundaries behind them would wait for
   // their acknowledgement (loads, stores and scratch accesses share one in-order counter)
   double ekj = 0.0;
-  if constexpr (NP == 32) {
-    const double* ts0 = d.taus0 + (long)c * (d.L + 1);
-    ekj = exp(-kj * (ts0[l + 1] - ts0[l]));
-  }
+  if constexpr (NP == 32) ekj = exp(-kj * dts);
+  // every load of the stage has landed before its first store: used for the first time behind the stores of Y, the quadrature
+  // values requested at the top of the stage made the wavefront wait for those stores (one in-order counter for loads and stores)
+  asm volatile("" : "+v"(invmu_j), "+v"(T_j), "+v"(dts));
   auto store_Y = [&]() {
     if constexpr (NP == 32) {  // every value in a register BEFORE the first store: a spilled one reloaded between two stores waits
       //                         for the acknowledgement of the stores in front of it
@@ -1220,10 +1234,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
 #pragma unroll
       for (int i = 0; i < NP; ++i) Ym[i * NP + j] = ya[i];
       d.kk[base * NP + j] = kj;
-      if constexpr (NP != 32) {
-        const double* ts0 = d.taus0 + (long)c * (d.L + 1);
-        ekj = exp(-kj * (ts0[l + 1] - ts0[l]));
-      }
+      if constexpr (NP != 32) ekj = exp(-kj * dts);
       d.Ek[base * NP + j] = ekj;
     }
   };
@@ -1237,9 +1248,9 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
   //  T dd = mu0 [ T (x+ - x-) - Pm T s ],  Qm Pm = L^-T Z k^2 Z^T L^T
   double bv_up = 0.0, bv_dn = 0.0;  // (NP = 32: stored with A at the end of the stage, no store in front of the stage's reloads)
   if (d.beam) {
-    const double mu0 = d.mu0[c];
+    const double mu0 = mu0_c;
     // X^e_j, X^o_j of this lane's stream (:143-152): I0/(4 pi) (2 - delta_m0) omega sum_l w_l Ybar_l(-mu0) Y_l[j], from stage 1
-    const double fac = d.I0[c] * (0.25 / M_PI) * (id.mg == 0 ? 1.0 : 2.0);
+    const double fac = I0_c * (0.25 / M_PI) * (id.mg == 0 ? 1.0 : 2.0);
     const double xe = fac * xe_sum, xo = fac * xo_sum;
     const double txd = 2.0 * T_j * xe * invmu_j;  // T (x+ - x-)
     v0[j] = txd;
