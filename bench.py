@@ -253,7 +253,8 @@ def executed_roofline(kernel, seconds_per_launch):
                             "`frac` is LAPACK's operation count for the reference's algorithm over the same time: a normalised throughput"}
     if c.get("SQ_BUSY_CYCLES"):
         out["valu_issue_frac"] = 4.0 * c.get("SQ_INSTS_VALU", 0.0) / (c["SQ_BUSY_CYCLES"] / 32.0 * 1024.0)
-    if c.get("GRBM_GUI_ACTIVE") and c.get("seconds"):
+    if c.get("GRBM_GUI_ACTIVE") and c.get("seconds") and c["seconds"] >= 3e-4:
+        # (MI355X_MICROARCH.md, DVFS: the quotient reads high on dispatches shorter than about 0.3 ms -- no clock is reported for those)
         ghz = c["GRBM_GUI_ACTIVE"] / 8.0 / c["seconds"] / 1e9
         out["sustained_clock_ghz"] = ghz
         out["peak_at_sustained_clock"] = FP64_PEAK_TFLOPS * ghz / 2.4
@@ -470,7 +471,7 @@ def single_column_leg(device, calls=30):
             res = pydisort_amd.pydisort(**kw)
             u = res[4](z["tau_pts"], z["phi"])
             times.append(time.perf_counter() - t0)
-            res[1].__self__.plan.close()
+            # (`res` is rebound by the next call: its closures go, and their plan serves that call -- pydisort.py: _plan_for)
     times = sorted(times[3:])
     want = z["u"]
     diff = np.abs(u - want)

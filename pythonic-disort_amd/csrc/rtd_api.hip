@@ -152,6 +152,13 @@ struct rtd_plan {
   bool have_quad = false, have_cols = false, solved = false;
   int numeric_status = 0;  // RTD_ST_* bits of the last solve other than the tau range: reported until the next solve
   std::vector<double> h_tau;  // host copy of tau_arr [C][L]: recognises evaluation points that are the layer interfaces
+  // Host images of the small uploads (quadrature, per-column inputs, evaluation points) live in the plan until the copy that reads
+  // them is known to have completed: no hipStreamSynchronize per upload (each costs a one-column pydisort() call 10-20 us; the
+  // call's only wait is now the one that brings its results back).  `*_pending`: an asynchronous copy from the image may still be
+  // in flight -- the next writer of the image waits for the stream first; every call that drains the stream clears them.
+  std::vector<char> quad_img, cols_img;
+  std::vector<double> ev_img;
+  bool quad_pending = false, cols_pending = false, ev_pending = false;
   // evaluation buffers (grown on demand)
   bool ev_iface = false;  // the stored evaluation points are [0, tau_arr] of every column (fused evaluation possible)
   double* um_buf = nullptr;  // [Cw][M][L+1][2 NP]: Fourier modes at the interfaces, written by the boundary-condition kernel
@@ -439,6 +446,7 @@ int check_status(rtd_plan* p, const bool all_modes = true) {
   int st = 0;
   HIP_TRY(hipMemcpyAsync(&st, p->d.status, sizeof(int), hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
+  p->quad_pending = p->cols_pending = p->ev_pending = false;
   if (st != 0) {
     HIP_TRY(hipMemsetAsync(p->d.status, 0, sizeof(int), p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -726,6 +734,7 @@ int rtd_plan_destroy(rtd_plan* p) {
 int rtd_plan_synchronize(rtd_plan* p) {
   if (!p) return fail(RTD_ERR_ARG, "null plan");
   HIP_TRY(hipStreamSynchronize(p->stream));
+  p->quad_pending = p->cols_pending = p->ev_pending = false;
   if (p->eig_stream) HIP_TRY(hipStreamSynchronize(p->eig_stream));  // (every eigen stage is consumed on `stream`: a formality)
   if (p->comm_stream) HIP_TRY(hipStreamSynchronize(p->comm_stream));
   return 0;
@@ -766,14 +775,16 @@ int rtd_plan_set_quadrature(rtd_plan* p, const double* mu_pos, const double* wei
   const size_t nb = (size_t)NP * 8;
   const char* base = reinterpret_cast<const char*>(p->d.mu);
   const size_t span = (size_t)(reinterpret_cast<const char*>(p->d.T) - base) + nb;
-  std::vector<char> img(span, 0);
+  if (p->quad_pending) HIP_TRY(hipStreamSynchronize(p->stream));  // (an earlier upload may still read the image)
+  std::vector<char>& img = p->quad_img;
+  img.assign(span, 0);
   std::memcpy(img.data(), mu.data(), nb);
   std::memcpy(img.data() + (reinterpret_cast<const char*>(p->d.w) - base), w.data(), nb);
   std::memcpy(img.data() + (reinterpret_cast<const char*>(p->d.invmu) - base), im.data(), nb);
   std::memcpy(img.data() + (reinterpret_cast<const char*>(p->d.S) - base), S.data(), nb);
   std::memcpy(img.data() + (reinterpret_cast<const char*>(p->d.T) - base), T.data(), nb);
   HIP_TRY(hipMemcpyAsync((void*)p->d.mu, img.data(), span, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->quad_pending = true;  // (no wait: the image stays with the plan)
   p->have_quad = true;
   p->fork_needed = true;
   p->tables_valid = false;
@@ -802,9 +813,10 @@ int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* 
   // host time each from pageable memory); d.col_status lies inside the stretch and is cleared by every solve anyway.
   const char* in_base = reinterpret_cast<const char*>(d.lperm);
   const size_t in_span = (size_t)(reinterpret_cast<const char*>(d.bdrfq0) - in_base) + (size_t)std::max<int64_t>(C * NB * NP, 1) * 8;
-  std::vector<char> img;
-  if (in_span <= (size_t)(1u << 20)) img.assign(in_span, 0);
-  const bool one_copy = !img.empty();
+  const bool one_copy = in_span <= (size_t)(1u << 20);
+  if (one_copy && p->cols_pending) HIP_TRY(hipStreamSynchronize(s));  // (an earlier upload may still read the image)
+  std::vector<char>& img = p->cols_img;
+  if (one_copy) img.assign(in_span, 0);
 #define UP(dst, src, n)                                                                                              \
   do {                                                                                                                \
     if (one_copy) std::memcpy(img.data() + (reinterpret_cast<const char*>(dst) - in_base), (src), (size_t)(n) * 8);   \
@@ -870,8 +882,12 @@ int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* 
     UP(d.bdrfq0, q0.data(), C * NB * NP);
   }
 #undef UP
-  if (one_copy) HIP_TRY(hipMemcpyAsync((void*)d.lperm, img.data(), in_span, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipStreamSynchronize(s));  // host staging vectors go out of scope
+  if (one_copy) {
+    HIP_TRY(hipMemcpyAsync((void*)d.lperm, img.data(), in_span, hipMemcpyHostToDevice, s));
+    p->cols_pending = true;  // (no wait: the image stays with the plan; the caller's arrays have been copied into it)
+  } else {
+    HIP_TRY(hipStreamSynchronize(s));  // the caller's arrays and the host staging vectors must outlive their copies
+  }
   p->h_tau.assign(tau, tau + C * L);
   p->ev_iface = false;  // stored evaluation points, if any, are no longer known to be this batch's interfaces
   p->have_cols = true;
@@ -1013,9 +1029,18 @@ int rtd_plan_set_eval_points(rtd_plan* p, int32_t ntau, const double* tau, int32
   if ((rc = grow(p, &p->ev_u, &p->cap_u, C * Qr * ntau * (nphi > 0 ? nphi : 1)))) return rc;
   if ((rc = grow(p, &p->ev_u0, &p->cap_u0, 2 * C * Qr * ntau))) return rc;  // u0 and ulast
   if ((rc = grow(p, &p->ev_fl, &p->cap_fl, 3 * C * ntau))) return rc;
-  HIP_TRY(hipMemcpyAsync(p->ev_tau, tau, (size_t)(C * ntau) * 8, hipMemcpyHostToDevice, p->stream));
-  if (nphi > 0) HIP_TRY(hipMemcpyAsync(p->ev_phi, phi, (size_t)nphi * 8, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  if ((C * ntau + nphi) * 8 <= (int64_t)(1 << 20)) {  // small: through an image that stays with the plan, no wait
+    if (p->ev_pending) HIP_TRY(hipStreamSynchronize(p->stream));
+    p->ev_img.assign(tau, tau + C * ntau);
+    if (nphi > 0) p->ev_img.insert(p->ev_img.end(), phi, phi + nphi);
+    HIP_TRY(hipMemcpyAsync(p->ev_tau, p->ev_img.data(), (size_t)(C * ntau) * 8, hipMemcpyHostToDevice, p->stream));
+    if (nphi > 0) HIP_TRY(hipMemcpyAsync(p->ev_phi, p->ev_img.data() + C * ntau, (size_t)nphi * 8, hipMemcpyHostToDevice, p->stream));
+    p->ev_pending = true;
+  } else {
+    HIP_TRY(hipMemcpyAsync(p->ev_tau, tau, (size_t)(C * ntau) * 8, hipMemcpyHostToDevice, p->stream));
+    if (nphi > 0) HIP_TRY(hipMemcpyAsync(p->ev_phi, phi, (size_t)nphi * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+  }
   p->ev_ntau = ntau;
   p->ev_nphi = nphi;
   // points = the layer interfaces [0, tau_arr] of every column?  Then rtd_plan_run takes the fused evaluation.

@@ -7,6 +7,7 @@ checks (pydisort.py:222-291), preparation (_prepare.py) and thin closures that c
 evaluators.  The eigen stage, the boundary-condition solve and every evaluation of u, u0 and the
 fluxes are HIP kernels reached through the C ABI in include/rtd.h; there is no CPU fallback.
 """
+import threading
 import warnings
 from math import pi
 
@@ -15,6 +16,47 @@ import numpy as np
 from . import _nt
 from ._engine import Plan
 from ._prepare import double_gauss, prepare_columns
+
+
+# One-column plans whose closures are gone, kept for the next call with the same dimensions: plan creation (device arena, fills,
+# stream) and the quadrature upload are a third of a one-column call's latency.  A plan is never shared: it is handed out
+# when no closure of an earlier call refers to it any more (CPython frees the closures of `res = pydisort(...)` as soon as `res` is
+# rebound), holds at most _IDLE_MAX plans, and a plan that was closed by hand is dropped.
+_IDLE, _IDLE_LOCK, _IDLE_MAX = {}, threading.Lock(), 8
+
+
+def _plan_for(prep, device):
+    key = (device, prep["L"], prep["N"], prep["P"], prep["M"], prep["Ns"], prep["NBDRF"], bool(prep["beam"]))
+    while True:
+        with _IDLE_LOCK:
+            lst = _IDLE.get(key)
+            plan = lst.pop() if lst else None
+        if plan is None:
+            break
+        if getattr(plan, "_h", None):
+            try:
+                if getattr(plan, "_nt_on", False):
+                    plan.clear_nt()
+                    plan._nt_on = False
+                plan.set_columns(prep)  # (same dimensions, same quadrature: only the column changes)
+                return plan
+            except Exception:
+                plan.close()
+    plan = Plan(prep, device=device)
+    plan._idle_key = key
+    return plan
+
+
+def _release(plan):
+    """Called when the closures of a call are gone: the plan waits for the next call of its shape, or is closed."""
+    if not getattr(plan, "_h", None):
+        return
+    key = getattr(plan, "_idle_key", None)
+    with _IDLE_LOCK:
+        if key is not None and sum(len(v) for v in _IDLE.values()) < _IDLE_MAX:
+            _IDLE.setdefault(key, []).append(plan)
+            return
+    plan.close()
 
 
 def _tabulate_bdrf(modes, mu, mu0, beam):
@@ -168,7 +210,7 @@ def pydisort(
         warnings.warn("Some delta-scaled phase function Legendre coefficients have a magnitude that is very close to 1"
                       " (this excludes the zeroth index coefficient which must be 1) which may cause numerical instability.")
 
-    plan = Plan(prep, device=device)
+    plan = _plan_for(prep, device)
     plan.solve()
     sol = _Closures(plan, prep, tau_arr, NFourier, beam, mu0, I0)
 
@@ -177,6 +219,7 @@ def pydisort(
     nt_on = (NT_cor and beam and np.any(f_arr > 0) and NLeg < NLeg_all and np.any(omega_arr > 0))
     if nt_on:  # the device adds TMS + IMS to u from now on (the reference returns u_corrected as `u`, :696-698)
         plan.set_nt(*_nt.nt_inputs(prep, omega_arr[None], f_full[None], Leg_coeffs_all[None], NLeg, [mu0]))
+        plan._nt_on = True
     return mu_arr, sol.flux_up, sol.flux_down, sol.u0, sol.u
 
 
@@ -186,6 +229,12 @@ class _Closures:
     def __init__(self, plan, prep, tau_arr, M, beam, mu0, I0_user):
         self.plan, self.prep, self.tau_arr, self.M, self.beam = plan, prep, tau_arr, M, beam
         self.mu0, self.I0_user = mu0, I0_user
+
+    def __del__(self):  # the last of the returned callables is gone: the plan may serve the next call of this shape
+        try:
+            _release(self.plan)
+        except Exception:
+            pass
 
     def _tau(self, tau):
         tau = np.atleast_1d(np.asarray(tau, dtype=float))
