@@ -289,36 +289,37 @@ __device__ __forceinline__ void fmac_bcast(double& acc, const double src, const 
 // wavefronts doing the same -- LDS-bandwidth-bound, 10-12 k cycles per product and wavefront at two wavefronts per SIMD (s_memtime
 // stamps, profiles/r05_eigen32_phases.txt).  Now lane t of every DPP row loads L[r][t] and L[r][16 + t] of row r ONCE (48 conflict-
 // free reads per product: the packed row is contiguous) and every FMA takes its multiplier as a DPP row broadcast of those two
-// registers.  Lanes t > r hold whatever follows row r in the packed triangle: they are never broadcast (i <= r at compile time).
+// registers (NP = 64: four registers per row, the padded square of L in LDS; same three products).  Lanes t > r hold whatever follows row r in the packed triangle: they are never broadcast (i <= r at compile time).
 //   F (column j of R in the lane):  w[i]   += L[r][i] qcol[r]            for i <= r      (accumulators independent)
 //   Y (back substitution):          ya[r]  *= 1 / L[r][r];  ya[i] -= L[r][i] ya[r]      for i < r, r = 31 ... 0
 //   A (row r of L):                 aa[r]   = sum_{i <= r} L[r][i] zc[i]                 (two accumulation chains per row)
-struct LRow32 {
-  double lo, hi;  // lane t: L[r][t], L[r][16 + t]
-  template <int R>
-  static __device__ __forceinline__ LRow32 load(const double* L_, const int t) {
-    LRow32 x;
-    x.lo = L_[R * (R + 1) / 2 + t];
-    x.hi = R >= 16 ? L_[R * (R + 1) / 2 + 16 + t] : 0.0;
+template <int NP>
+struct LRowN {  // row r of L: lane t of every DPP row holds L[r][16 g + t] in g[g] (NP = 64: four registers per row)
+  double g[NP / 16];
+  template <int R, bool PACKED>
+  static __device__ __forceinline__ LRowN load(const double* L_, const int t) {
+    constexpr int off = PACKED ? R * (R + 1) / 2 : R * (NP + 1);  // (the packed triangle at NP = 32, the padded square at NP = 64)
+    LRowN x;
+#pragma unroll
+    for (int gi = 0; gi < NP / 16; ++gi) x.g[gi] = 16 * gi <= R ? L_[off + 16 * gi + t] : 0.0;
     return x;
   }
 };
-template <int R, int I, int IEND>
-struct AxpyRow32 {  // acc[i] += L[R][i] * mul for i = I .. IEND - 1
-  static __device__ __forceinline__ void run(double (&acc)[32], const LRow32& row, const double mul) {
+template <int NP, int I, int IEND>
+struct AxpyRowN {  // acc[i] += L[r][i] * mul for i = I .. IEND - 1
+  static __device__ __forceinline__ void run(double (&acc)[NP], const LRowN<NP>& row, const double mul) {
     if constexpr (I < IEND) {
-      fmac_bcast<I % 16>(acc[I], I < 16 ? row.lo : row.hi, mul);
-      AxpyRow32<R, I + 1, IEND>::run(acc, row, mul);
+      fmac_bcast<I % 16>(acc[I], row.g[I / 16], mul);
+      AxpyRowN<NP, I + 1, IEND>::run(acc, row, mul);
     }
   }
 };
-template <int R, int I, int IEND>
-struct DotRow32 {  // a0 += sum_{i < 16} L[R][i] v[i], a1 likewise over i >= 16
-  static __device__ __forceinline__ void run(double& a0, double& a1, const LRow32& row, const double (&v)[32]) {
+template <int NP, int I, int IEND>
+struct DotRowN {  // a[g] += sum_{16 g <= i < 16 g + 16} L[r][i] v[i]: one accumulation chain per 16 columns
+  static __device__ __forceinline__ void run(double (&a)[NP / 16], const LRowN<NP>& row, const double (&v)[NP]) {
     if constexpr (I < IEND) {
-      if constexpr (I < 16) fmac_bcast<I>(a0, row.lo, v[I]);
-      else fmac_bcast<I - 16>(a1, row.hi, v[I]);
-      DotRow32<R, I + 1, IEND>::run(a0, a1, row, v);
+      fmac_bcast<I % 16>(a[I / 16], row.g[I / 16], v[I]);
+      DotRowN<NP, I + 1, IEND>::run(a, row, v);
     }
   }
 };
@@ -918,14 +919,14 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
     cholesky_columns32(qcol, j, sTab);  // Qm = R R^T
     RTD_ESTAMP(4);
     __syncthreads();
-    {  // F = L^T R with the rows of L spread over the lanes (LRow32)
+    {  // F = L^T R with the rows of L spread over the lanes (LRowN)
       const int t16 = j & 15;
 #pragma unroll
       for (int i = 0; i < NP; ++i) w[i] = 0.0;
       static_for<0, NP>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
-        const LRow32 row = LRow32::load<r>(L_, t16);
-        AxpyRow32<r, 0, r + 1>::run(w, row, qcol[r]);
+        const LRowN<NP> row = LRowN<NP>::template load<r, PACKED>(L_, t16);
+        AxpyRowN<NP, 0, r + 1>::run(w, row, qcol[r]);
         if constexpr ((r & 3) == 3) RTD_FENCE();
       });
     }
@@ -1018,12 +1019,16 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
     cholesky_columns<NP>(qcol, j);  // Qm = R R^T
     RTD_ESTAMP(4);
     __syncthreads();
+    {  // F = L^T R with the rows of L spread over the lanes (LRowN; round 5: as at NP = 32)
+      const int t16 = j & 15;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      double a = 0.0;
-#pragma unroll
-      for (int r = i; r < NP; ++r) a += L_[lix(r, i)] * qcol[r];
-      w[i] = a;
+      for (int i = 0; i < NP; ++i) w[i] = 0.0;
+      static_for<0, NP>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const LRowN<NP> row = LRowN<NP>::template load<r, PACKED>(L_, t16);
+        AxpyRowN<NP, 0, r + 1>::run(w, row, qcol[r]);
+        if constexpr ((r & 3) == 3) RTD_FENCE();
+      });
     }
   } else {
   // D+/D- split by parity of (l - m): Ae = 2 sum_even c_l Y_l Y_l^T, Ao likewise (:123-125)
@@ -1190,7 +1195,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
   // eigenvector blocks (:190-198): V = T^-1 L^-T Z, U = (alpha+beta) V / k = -T^-1 L Z / k; stored as
   // Y = L^-T Z and A = L Z, from which Gp = (Y - A/k)/T, Gm = (Y + A/k)/T, V^-1 = A^T T, U^-1 = -k Y^T T
   double ya[NP];
-  if constexpr (NP == 32) {  // the rows of L spread over the lanes (LRow32): ya[r] final, then its multiples leave the rows above
+  if constexpr (NP >= 32) {  // the rows of L spread over the lanes (LRowN): ya[r] final, then its multiples leave the rows above
     const int t16 = j & 15;
 #pragma unroll
     for (int i = 0; i < NP; ++i) ya[i] = zc[i];
@@ -1198,8 +1203,8 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
       constexpr int r = NP - 1 - decltype(kc)::value;
       ya[r] *= dinv[r];
       if constexpr (r > 0) {
-        const LRow32 row = LRow32::load<r>(L_, t16);
-        AxpyRow32<r, 0, r>::run(ya, row, -ya[r]);
+        const LRowN<NP> row = LRowN<NP>::template load<r, PACKED>(L_, t16);
+        AxpyRowN<NP, 0, r>::run(ya, row, -ya[r]);
       }
       if constexpr ((r & 3) == 0) RTD_FENCE();
     });
@@ -1323,21 +1328,31 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
   RTD_ESTAMP(8);
   // A = L Z after the beam stage: its 2 NP registers are not live while that stage runs
   double aa[NP];
-  if constexpr (NP == 32) {  // the rows of L spread over the lanes (LRow32)
+  if constexpr (NP == 32) {  // the rows of L spread over the lanes (LRowN)
     store_Y();
     const int t16 = j & 15;
     static_for<0, NP>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
-      const LRow32 row = LRow32::load<r>(L_, t16);
-      double a0 = 0.0, a1 = 0.0;
-      DotRow32<r, 0, r + 1>::run(a0, a1, row, zc);
-      aa[r] = r >= 16 ? a0 + a1 : a0;
+      const LRowN<NP> row = LRowN<NP>::template load<r, PACKED>(L_, t16);
+      double a[NP / 16] = {};
+      DotRowN<NP, 0, r + 1>::run(a, row, zc);
+      aa[r] = r >= 16 ? a[0] + a[1] : a[0];
       if constexpr ((r & 3) == 3) RTD_FENCE();
     });
     asm volatile("" : "+v"(aa[0]), "+v"(aa[1]), "+v"(aa[2]), "+v"(aa[3]), "+v"(aa[4]), "+v"(aa[5]), "+v"(aa[6]), "+v"(aa[7]), "+v"(aa[8]),
                       "+v"(aa[9]), "+v"(aa[10]), "+v"(aa[11]), "+v"(aa[12]), "+v"(aa[13]), "+v"(aa[14]), "+v"(aa[15]));
     asm volatile("" : "+v"(aa[16]), "+v"(aa[17]), "+v"(aa[18]), "+v"(aa[19]), "+v"(aa[20]), "+v"(aa[21]), "+v"(aa[22]), "+v"(aa[23]),
                       "+v"(aa[24]), "+v"(aa[25]), "+v"(aa[26]), "+v"(aa[27]), "+v"(aa[28]), "+v"(aa[29]), "+v"(aa[30]), "+v"(aa[31]));
+  } else if constexpr (NP == 64) {  // the same product at 128 streams: four registers per spread row, four accumulation chains
+    const int t16 = j & 15;
+    static_for<0, NP>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      const LRowN<NP> row = LRowN<NP>::template load<r, PACKED>(L_, t16);
+      double a[NP / 16] = {};
+      DotRowN<NP, 0, r + 1>::run(a, row, zc);
+      aa[r] = (a[0] + a[1]) + (a[2] + a[3]);
+      if constexpr ((r & 3) == 3) RTD_FENCE();
+    });
   } else {
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
