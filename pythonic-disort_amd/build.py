@@ -15,7 +15,7 @@ OUT_DIR = os.path.join(HERE, "pydisort_amd")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(OUT_DIR, "librtd.so")
 SOURCES = ["rtd_api.hip", "rtd_eig.hip", "rtd_eig_small.hip", "rtd_bc.hip", "rtd_bc_small.hip", "rtd_bc_tile2.hip", "rtd_bc_wide.hip", "rtd_eval.hip", "rtd_nt.hip", "rtd_bdrf.hip", "rtd_prep.hip"]
-HEADERS = [os.path.join(CSRC, "rtd_device.h"), os.path.join(CSRC, "rtd_bc_common.h"), os.path.join(CSRC, "rtd_bc_tile_common.h"), os.path.join(HERE, "..", "include", "rtd.h")]
+HEADERS = [os.path.join(CSRC, "rtd_device.h"), os.path.join(CSRC, "rtd_dd.h"), os.path.join(CSRC, "rtd_bc_common.h"), os.path.join(CSRC, "rtd_bc_tile_common.h"), os.path.join(HERE, "..", "include", "rtd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-save-temps=obj",
          "-Wno-unused-command-line-argument"] + os.environ.get("RTD_EXTRA_FLAGS", "").split()

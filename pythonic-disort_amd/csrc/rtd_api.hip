@@ -16,6 +16,7 @@
 
 #include "../../include/rtd.h"
 #include "rtd_device.h"
+#include "rtd_dd.h"
 
 namespace {
 
@@ -849,7 +850,16 @@ int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* 
   UP(d.I0, I0, C);
   UP(d.phi0, phi0, C);
   UP(d.rescale, rescale, C);
-  if (Ns > 0) UP(d.spoly, s_poly, C * L * Ns);
+  // The thermal source polynomials arrive as the reference's scaled_s_poly_coeffs: coefficients in the ABSOLUTE scaled optical
+  // depth.  The kernels keep them about the top of their own layer (rtd_dd.h): Taylor shift by taus0[l], in double-double.
+  std::vector<double> sloc;
+  if (Ns > 0) {
+    if (Ns > 16) return fail(RTD_ERR_ARG, "more than 16 source polynomial coefficients per layer are not supported");
+    sloc.assign(s_poly, s_poly + C * L * Ns);
+    for (int64_t c = 0; c < C; ++c)
+      for (int64_t l = 0; l < L; ++l) rtd_taylor_shift(sloc.data() + (c * L + l) * Ns, (int)Ns, taus0[c * (L + 1) + l]);
+    UP(d.spoly, sloc.data(), C * L * Ns);
+  }
   // pad the per-stream arrays from N to NP
   std::vector<double> bp, bn;
   if (N == NP) {

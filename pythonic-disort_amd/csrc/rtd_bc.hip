@@ -153,15 +153,10 @@ __global__ __launch_bounds__(64) void rtd_iface_kernel(RtdDev d, const int* only
       ru = (d.Bv[p1 * Q + i] - d.Bv[p0 * Q + i]) * att;
       rd = (d.Bv[p1 * Q + NP + i] - d.Bv[p0 * Q + NP + i]) * att;
     }
-    if (iso) {
-      const double* dq0 = d.dq + ((long)c * d.L + l) * d.Ns * Q;
-      const double* dq1 = dq0 + (long)d.Ns * Q;
-      double tp = 1.0;
-      for (int q = 0; q < d.Ns; ++q) {
-        ru += (dq1[q * Q + i] - dq0[q * Q + i]) * tp;
-        rd += (dq1[q * Q + NP + i] - dq0[q * Q + NP + i]) * tp;
-        tp *= tb;
-      }
+    if (iso) {  // v_{l+1} at its top minus v_l at its bottom: the eigen kernel's boundary values (vb), no polynomial evaluated here
+      const double* vb0 = d.vb + ((long)c * d.L + l) * 4 * NP;
+      ru += vb0[4 * NP + i] - vb0[2 * NP + i];
+      rd += vb0[5 * NP + i] - vb0[3 * NP + i];
     }
     const double Ti = d.T[i];
     const double a = Ti * A0[i * LD + j] * (ru + rd), b = -kj * Ti * Y0[i * LD + j] * (ru - rd);
@@ -266,14 +261,10 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
   const bool iso = d.Ns > 0 && mg == 0;
   const bool beam = d.beam != 0;
   const double mu0 = beam ? d.mu0[c] : 1.0;
-  auto vpoly = [&](int l, double t, int idx) {
-    double a = 0.0, tp = 1.0;
-    for (int q = 0; q < d.Ns; ++q) {
-      a += dq[((long)l * d.Ns + q) * Q + idx] * tp;
-      tp *= t;
-    }
-    return a;
-  };
+  // thermal particular solution of layer l at one of the layer's own boundaries (top / bottom), streams idx in [0, 2 NP): the values
+  // the eigen kernel left in vb (it holds the polynomial coefficients about the layer's top, rtd_dd.h) -- no polynomial is evaluated here
+  const double* vbp = d.vb + (long)c * L * 4 * NP;
+  auto vedge = [&](int l, bool bottom, int idx) { return vbp[((long)l * 4 + (bottom ? 2 : 0)) * NP + idx]; };
 
   // carry rows, one per lane: Ta C- + Tb C+ = t.  Top boundary (down-streams at tau = 0) (:161-179, :284-285)
   double ta_regs[ROWS_IN_LDS ? 1 : NP], tb_regs[ROWS_IN_LDS ? 1 : NP], tt;
@@ -406,16 +397,16 @@ __global__ __launch_bounds__(64, (NP <= 8 ? RTD_SWEEP_WAVES : (NP == 16 ? 2 : 1)
         }
         const double Rraw = Rij * d.T[j2];
         if (beam) rbm += Rraw * Bv[l * Q + NP + j2];
-        if (iso) rvm += Rraw * vpoly(l, ts0[L], NP + j2);
+        if (iso) rvm += Rraw * vedge(l, true, NP + j2);
       }
       if (beam) {
         const double Xs = mu0 * d.I0[c] / M_PI * d.bdrfq0[((long)c * d.NBDRF + mg) * NP + j];
         br += (Xs + rbm - Bv[l * Q + j]) * att;
       }
-      if (iso) br += rvm - vpoly(l, ts0[L], j);
+      if (iso) br += rvm - vedge(l, true, j);
     } else {
       if (beam) br -= Bv[l * Q + j] * att;
-      if (iso) br -= vpoly(l, ts0[L], j);
+      if (iso) br -= vedge(l, true, j);
     }
     double ba[NP], bb[NP];
 #pragma unroll
@@ -699,14 +690,10 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
   // declared failed and redone by pivoted_lds, the path of the rare real failures (the suite runs under both).
   const int careful = chain_needs_pivoting(d, RTD_BC_CAREFUL_ALL_MODE0 ? mg == 0 : iso, kk, L, NP) | ((d.flags >> 2) & 1);
   const int force_redo = d.flags & 1;
-  auto vpoly = [&](int l, double t, int idx) {
-    double a = 0.0, tp = 1.0;
-    for (int q = 0; q < d.Ns; ++q) {
-      a += dq[((long)l * d.Ns + q) * Q + idx] * tp;
-      tp *= t;
-    }
-    return a;
-  };
+  // thermal particular solution of layer l at one of the layer's own boundaries (top / bottom), streams idx in [0, 2 NP): the values
+  // the eigen kernel left in vb (it holds the polynomial coefficients about the layer's top, rtd_dd.h) -- no polynomial is evaluated here
+  const double* vbp = d.vb + (long)c * L * 4 * NP;
+  auto vedge = [&](int l, bool bottom, int idx) { return vbp[((long)l * 4 + (bottom ? 2 : 0)) * NP + idx]; };
   // (kq, col are passed in so that the loops can hand over an opaque copy of the lane index: the compiler then
   //  rebuilds the few address VGPRs per iteration instead of keeping dozens of hoisted ones alive and spilling)
   auto load_d = [](const double* p, const int kq, const int col) {  // row-major 16 x 16 matrix -> D layout
@@ -828,10 +815,10 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
       double v = 0.0;
       if (backward) {
         if (beam) v = Bv[l * Q + i] * d.att[(long)c * (L + 1) + l];
-        if (iso) v += vpoly(l, ts0[l], i);
+        if (iso) v += vedge(l, false, i);
       } else if (l < Lm1) {
         if (beam) v = (Bv[(l + 1) * Q + i] - Bv[l * Q + i]) * d.att[(long)c * (L + 1) + l + 1];
-        if (iso) v += vpoly(l + 1, ts0[l + 1], i) - vpoly(l, ts0[l + 1], i);
+        if (iso) v += vedge(l + 1, false, i) - vedge(l, true, i);
       }
       (&sPs[0][0])[e] = v;
     }
@@ -861,8 +848,8 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
       if (e < nl * Q) {
         double v = beam ? (backward ? b1[it] : b1[it] - b0[it]) * at[it] : 0.0;
         if (iso) {
-          if (backward) v += vpoly(l, ts0[l], i);
-          else if (l < Lm1) v += vpoly(l + 1, ts0[l + 1], i) - vpoly(l, ts0[l + 1], i);
+          if (backward) v += vedge(l, false, i);
+          else if (l < Lm1) v += vedge(l + 1, false, i) - vedge(l, true, i);
         }
         (&sPs[0][0])[e] = v;
       }
@@ -1141,12 +1128,12 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
       if (iso) {
         v4f64 vr;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) vr[q] = vpoly(l, tL, NP + 4 * q + kq);
-        br += col_dot(rtr, vr) - vpoly(l, tL, col);
+        for (int q = 0; q < 4; ++q) vr[q] = vedge(l, true, NP + 4 * q + kq);
+        br += col_dot(rtr, vr) - vedge(l, true, col);
       }
     } else {
       br -= bvc * att;
-      if (iso) br -= vpoly(l, tL, col);
+      if (iso) br -= vedge(l, true, col);
     }
     double rhs = br - col_dot(bat, col_to_row(tv, rowbase, kq));
     double none[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1297,8 +1284,8 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
         up = fma(buL, attL, up);
         dn = fma(bdL, attL, dn);
         if (iso) {
-          up += vpoly(Lm1, ts0[L], i);
-          dn += vpoly(Lm1, ts0[L], NP + i);
+          up += vedge(Lm1, true, i);
+          dn += vedge(Lm1, true, NP + i);
         }
         sOut[32 + i] = up;
         sOut[32 + NP + i] = dn;
@@ -1407,14 +1394,10 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
     }
     return;
   }
-  auto vpoly = [&](int l, double t, int idx) {
-    double a = 0.0, tp = 1.0;
-    for (int q = 0; q < d.Ns; ++q) {
-      a += dq[((long)l * d.Ns + q) * Q + idx] * tp;
-      tp *= t;
-    }
-    return a;
-  };
+  // thermal particular solution of layer l at one of the layer's own boundaries (top / bottom), streams idx in [0, 2 NP): the values
+  // the eigen kernel left in vb (it holds the polynomial coefficients about the layer's top, rtd_dd.h) -- no polynomial is evaluated here
+  const double* vbp = d.vb + (long)c * L * 4 * NP;
+  auto vedge = [&](int l, bool bottom, int idx) { return vbp[((long)l * 4 + (bottom ? 2 : 0)) * NP + idx]; };
   auto load_d = [](const double* p, const int kq, const int col) {  // row-major NP x NP matrix -> tiles in the D layout
     MatT<T> x;
 #pragma unroll
@@ -1558,8 +1541,8 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
           if (e < nl * Q) {
             double v = beam ? (mode == 2 ? b1[it] : b1[it] - b0[it]) * at[it] : 0.0;
             if (iso) {
-              if (mode == 2) v += vpoly(l, ts0[l], i);
-              else if (l < Lm1) v += vpoly(l + 1, ts0[l + 1], i) - vpoly(l, ts0[l + 1], i);
+              if (mode == 2) v += vedge(l, false, i);
+              else if (l < Lm1) v += vedge(l + 1, false, i) - vedge(l, true, i);
             }
             (&sPs[0][0])[e] = v;
           }
@@ -1864,16 +1847,16 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
 #pragma unroll
         for (int I = 0; I < T; ++I)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) vr.r[I][q] = vpoly(l, tL, NP + 16 * I + 4 * q + kq);
+          for (int q = 0; q < 4; ++q) vr.r[I][q] = vedge(l, true, NP + 16 * I + 4 * q + kq);
         const ColT<T> rv = col_dotT<T>(rtr, vr);
 #pragma unroll
-        for (int J = 0; J < T; ++J) br.c[J] += rv.c[J] - vpoly(l, tL, 16 * J + col);
+        for (int J = 0; J < T; ++J) br.c[J] += rv.c[J] - vedge(l, true, 16 * J + col);
       }
     } else {
 #pragma unroll
       for (int J = 0; J < T; ++J) {
         if (beam) br.c[J] -= Bv[l * Q + 16 * J + col] * att;
-        if (iso) br.c[J] -= vpoly(l, tL, 16 * J + col);
+        if (iso) br.c[J] -= vedge(l, true, 16 * J + col);
       }
     }
     ColT<T> rhs;
@@ -2023,8 +2006,8 @@ __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDe
           dn += Bv[Lm1 * Q + NP + i] * attv;
         }
         if (iso) {
-          up += vpoly(Lm1, ts0[L], i);
-          dn += vpoly(Lm1, ts0[L], NP + i);
+          up += vedge(Lm1, true, i);
+          dn += vedge(Lm1, true, NP + i);
         }
         sOut[Q + i] = up;
         sOut[Q + NP + i] = dn;

@@ -189,15 +189,10 @@ __global__ __launch_bounds__(64, 2) void rtd_iface_mfma_kernel(RtdDev d) {
       ru = (d.Bv[p1 * Q + lane] - d.Bv[p0 * Q + lane]) * att;
       rd = (d.Bv[p1 * Q + NP + lane] - d.Bv[p0 * Q + NP + lane]) * att;
     }
-    if (d.Ns > 0 && mg == 0) {
-      const double* dq0 = d.dq + ((long)c * d.L + l) * d.Ns * Q;
-      const double* dq1 = dq0 + (long)d.Ns * Q;
-      double tp = 1.0;
-      for (int q = 0; q < d.Ns; ++q) {
-        ru += (dq1[q * Q + lane] - dq0[q * Q + lane]) * tp;
-        rd += (dq1[q * Q + NP + lane] - dq0[q * Q + NP + lane]) * tp;
-        tp *= tb;
-      }
+    if (d.Ns > 0 && mg == 0) {  // v_{l+1} at its top minus v_l at its bottom, from the eigen kernel's boundary values (vb)
+      const double* vb0 = d.vb + ((long)c * d.L + l) * 4 * NP;
+      ru += vb0[4 * NP + lane] - vb0[2 * NP + lane];
+      rd += vb0[5 * NP + lane] - vb0[3 * NP + lane];
     }
     const double Ti = d.T[lane];
     rsum = Ti * (ru + rd);
@@ -329,14 +324,10 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
   const bool iso = d.Ns > 0 && mg == 0;
   const bool beam = d.beam != 0;
   const double mu0 = beam ? d.mu0[c] : 1.0;
-  auto vpoly = [&](int l, double t, int idx) {
-    double a = 0.0, tp = 1.0;
-    for (int qq = 0; qq < d.Ns; ++qq) {
-      a += dq[((long)l * d.Ns + qq) * Q + idx] * tp;
-      tp *= t;
-    }
-    return a;
-  };
+  // thermal particular solution of layer l at one of the layer's own boundaries (top / bottom), streams idx in [0, 2 NP): the values
+  // the eigen kernel left in vb (it holds the polynomial coefficients about the layer's top, rtd_dd.h) -- no polynomial is evaluated here
+  const double* vbp = d.vb + (long)c * L * 4 * NP;
+  auto vedge = [&](int l, bool bottom, int idx) { return vbp[((long)l * 4 + (bottom ? 2 : 0)) * NP + idx]; };
 
   // carry rows Ta C- + Tb C+ = t, top boundary (:161-179, :284-285): Ta = Gm_0, Tb = Gp_0 E_0
   double ta[NI], tb[NI], tt;
@@ -481,16 +472,16 @@ __global__ __launch_bounds__(256, RTD_WIDE_WG) void rtd_sweep_wide_kernel(RtdDev
         }
         const double Rraw = Rij * d.T[j2];
         if (beam) rbm += Rraw * Bv[l * Q + NP + j2];
-        if (iso) rvm += Rraw * vpoly(l, ts0[L], NP + j2);
+        if (iso) rvm += Rraw * vedge(l, true, NP + j2);
       }
       if (beam) {
         const double Xs = mu0 * d.I0[c] / M_PI * d.bdrfq0[((long)c * d.NBDRF + mg) * NP + j];
         br += (Xs + rbm - Bv[l * Q + j]) * att;
       }
-      if (iso) br += rvm - vpoly(l, ts0[L], j);
+      if (iso) br += rvm - vedge(l, true, j);
     } else {
       if (beam) br -= Bv[l * Q + j] * att;
-      if (iso) br -= vpoly(l, ts0[L], j);
+      if (iso) br -= vedge(l, true, j);
     }
     // am = Bb - Ba S (into ta: this wavefront's columns) and bvec = br - Ba s.  A lane needs its whole row of Ba, of which every
     // wavefront made a quarter of the columns: the rows cross in LDS sixteen columns at a time (8.5 KB, not the 33 KB of a full

@@ -9,8 +9,10 @@
 //                               V^-1 = A^T T, U^-1 = -k Y^T T   (T = diag(sqrt(mu w)))
 //   kk       [C][M][L][NP]      positive eigenvalues k;   K = [-k, +k]      (:186-187)
 //   Bv       [C][M][L][Q2]      beam particular solution  [B+ ; B-]         (:209-231)
-//   dq       [C][L][Ns][Q2]     isotropic-source particular solution as polynomial coefficient
-//                               vectors: v(tau) = sum_q dq[q] tau^q         (subroutines.py:746-862)
+//   dq       [C][L][Ns][Q2]     isotropic-source particular solution as polynomial coefficient vectors about the TOP of the
+//                               layer: v(tau*) = sum_q dq[q] (tau* - taus0[l])^q  (subroutines.py:746-862 builds it in the
+//                               absolute depth; the construction is translation invariant, rtd_dd.h says why the origin moved)
+//   spoly    [C][L][Ns]         the source polynomial itself, likewise about the layer's top (shifted in double-double on upload)
 //   zneg     [C][L][NP]         first half of G^-1 [1/mu ; -1/mu]  (second half is its negative)
 //   coef     [C][M][L][Q2]      BC coefficients [C- ; C+]                   (_solve_for_coeffs.py)
 #pragma once

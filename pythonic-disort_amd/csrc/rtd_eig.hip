@@ -1403,9 +1403,10 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
     if (valid && act) d.zneg[((long)c * d.L + l) * NP + j] = zn;
     const double* sp = d.spoly + ((long)c * d.L + l) * d.Ns;
     const double rk = rk0;
-    // v_l at the layer's own boundaries (vb: what the boundary-condition kernel of the 2 ... 16-stream path reads instead of
-    // evaluating the polynomials layer by layer): sum_q dq[q] tau^q at the scaled tau of the top and of the bottom
-    const double ts_top = d.taus0[(long)c * (d.L + 1) + l], ts_bot = d.taus0[(long)c * (d.L + 1) + l + 1];
+    // v_l at the layer's own boundaries (vb: what every boundary-condition kernel reads -- none evaluates a polynomial).  The
+    // coefficients sp are about the layer's TOP (rtd_dd.h), so v_l(x) = sum_q dq[q] x^q with x the scaled depth below the top:
+    // the top is x = 0 (the constant term alone), the bottom x = the layer's scaled thickness.
+    const double ts_top = 0.0, ts_bot = d.taus0[(long)c * (d.L + 1) + l + 1] - d.taus0[(long)c * (d.L + 1) + l];
     double vtu = 0.0, vtd = 0.0, vbu = 0.0, vbd = 0.0, tpt = 1.0, tpb = 1.0;
     for (int q = 0; q < d.Ns; ++q) {
       // b_q(K) = sum_{jj>=q} jj!/q! a_jj K^-(jj-q+1), K = -k (first N eigen-columns) and +k

@@ -411,7 +411,8 @@ __global__ __launch_bounds__(64, 1) void rtd_eigen_lane_kernel(RtdDev d) {
 #pragma unroll
       for (int e = 0; e < NP; ++e) d.zneg[cl * NP + e] = zn[e];
     const double* sp = d.spoly + cl * d.Ns;
-    const double ts_top = d.taus0[(long)c * (L + 1) + l], ts_bot = d.taus0[(long)c * (L + 1) + l + 1];
+    // (the coefficients sp are about the layer's top, rtd_dd.h: the top is x = 0, the bottom x = the layer's scaled thickness)
+    const double ts_top = 0.0, ts_bot = d.taus0[(long)c * (L + 1) + l + 1] - d.taus0[(long)c * (L + 1) + l];
     double vtu[NP], vtd[NP], vbu[NP], vbd[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) vtu[i] = vtd[i] = vbu[i] = vbd[i] = 0.0;

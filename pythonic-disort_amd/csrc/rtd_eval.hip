@@ -126,13 +126,35 @@ __global__ __launch_bounds__(EVAL_THREADS) void rtd_eval_kernel(RtdDev d, RtdEva
       vd += d.Bv[ml * Q + NP + jj] * bfac;
     }
     if (d.m0 + d.mstep * (mb + m) == 0 && d.Ns > 0) {  // isotropic-source particular solution (subroutines.py:786-862)
+      // The coefficient vectors dq are about the TOP of the layer (rtd_dd.h): v(x) = sum_q dq[q] x^q, x = ts - ts0[l] = dtop.
       const double* dq = d.dq + ((long)c * L + l) * d.Ns * Q;
-      double tp = antider ? ts : 1.0;
-      for (int q = 0; q < d.Ns; ++q) {
-        const double f = antider ? tp / ((q + 1) * sc) : tp;
-        vu += dq[q * Q + jj] * f;
-        vd += dq[q * Q + NP + jj] * f;
-        tp *= ts;
+      if (!antider) {
+        double tp = 1.0;
+        for (int q = 0; q < d.Ns; ++q) {
+          vu += dq[q * Q + jj] * tp;
+          vd += dq[q * Q + NP + jj] * tp;
+          tp *= dtop;
+        }
+      } else {
+        // The reference's antiderivative is the one of the ABSOLUTE form, sum_q b_q ts^(q+1) / ((q + 1) scale) (:792-793, :812-815,
+        // :855-858): an antiderivative whose constant is fixed by tau = 0, not by the layer.  b_q = sum_{i >= q} dq[i] C(i, q)
+        // (-ts0[l])^(i - q) re-expands the local coefficients (the cancellation of the absolute form comes back with it: it is
+        // what the reference's closure is defined to return).
+        const double t0 = ts0[l];
+        double tp = ts;
+        for (int q = 0; q < d.Ns; ++q) {
+          double bu = 0.0, bd = 0.0, binom = 1.0, pw = 1.0;  // C(i, q) and (-t0)^(i - q) for i = q, q + 1, ...
+          for (int i = q; i < d.Ns; ++i) {
+            bu += dq[i * Q + jj] * binom * pw;
+            bd += dq[i * Q + NP + jj] * binom * pw;
+            binom = binom * (double)(i + 1) / (double)(i + 1 - q);
+            pw *= -t0;
+          }
+          const double f = tp / ((q + 1) * sc);
+          vu += bu * f;
+          vd += bd * f;
+          tp *= ts;
+        }
       }
     }
     um[m * Q + jj] = vu;

@@ -7,6 +7,7 @@
 // the per-layer scalars (a running sum over the layers) and the layer order of the eigen stage; one thread per (column,
 // layer, moment) for the weighted scaled Legendre coefficients.
 #include "rtd_device.h"
+#include "rtd_dd.h"
 
 namespace {
 
@@ -37,21 +38,17 @@ __global__ void rtd_prepare_columns_kernel(RtdDev d, RtdRaw r) {
     omega_s[l] = (1.0 - fl) / sc * om[l];
     tau_o[l] = tau[l];
     if (Ns > 0) {
-      // p(tau) = sum_j a_j tau^j with tau = (tau* - shift) / sc  ->  coefficients in tau*, then / sc, (1 - omega)
+      // s(tau) = sum_j a_j tau^j in the layer; the kernels want it about the layer's top in the scaled depth (rtd_dd.h):
+      // tau = top + x / sc  ->  b = Taylor shift of a by `top` (double-double), coefficient i divided by sc^i; then / sc, (1 - omega)
       const double* a = r.spoly + (c * L + l) * Ns;
       double* o = sp + (long)l * Ns;
-      for (int i = 0; i < Ns; ++i) o[i] = 0.0;
+      for (int i = 0; i < Ns; ++i) o[i] = a[i];
+      rtd_taylor_shift(o, Ns, top);
       const double rsc = 1.0 / sc;
-      double scj = 1.0;  // sc^-j
-      for (int j = 0; j < Ns; ++j) {
-        // (x)^j = sum_i C(j,i) (-shift)^(j-i) tau*^i / sc^j
-        double binom = 1.0, pw = 1.0;  // C(j, i) and (-shift)^(j - i), walked from i = j down to 0
-        for (int i = j; i >= 0; --i) {
-          o[i] += a[j] * binom * pw * scj;
-          binom = binom * (double)i / (double)(j - i + 1);
-          pw *= -shift;
-        }
-        scj *= rsc;
+      double sci = 1.0;  // sc^-i
+      for (int i = 0; i < Ns; ++i) {
+        o[i] *= sci;
+        sci *= rsc;
       }
       const double k = (1.0 - om[l]) * rsc;
       for (int i = 0; i < Ns; ++i) o[i] *= k;
@@ -70,11 +67,12 @@ __global__ void rtd_prepare_columns_kernel(RtdDev d, RtdRaw r) {
   else
     big = fmax(big, 0.0);
   if (Ns > 0) {
-    big = fmax(big, sp[0]);
+    big = fmax(big, sp[0]);  // s*(0): the top layer's own origin
     double v = 0.0, tp = 1.0;
+    const double dlast = ts0[L] - ts0[L - 1];  // s*(tau*_L) of the bottom layer, in its local variable
     for (int j = 0; j < Ns; ++j) {
       v += sp[(long)(L - 1) * Ns + j] * tp;
-      tp *= acc;
+      tp *= dlast;
     }
     big = fmax(big, v);
   }

@@ -32,8 +32,12 @@ PW_TOL = 1e-6               # north star: intensities within 1e-6 relative of th
 # largest (9e-11 of the field scale), and the reference's own captured result is 5.0e-5 pointwise off the 40-digit solution
 # (tools/hp_truth_case.py golden 8ARTS_A).  Against the reference the pointwise metric is therefore not held for this case
 # (None: the report says null); it is held against the 40-digit solution instead, in
-# test_golden_case_against_high_precision_truth.
+# test_golden_case_against_high_precision_truth, at PW_TRUTH_TOL: since round 5 the kernels keep the source polynomials about
+# the top of their own layer (csrc/rtd_dd.h) and are 3.7e-6 from the truth there (2.6e-5 before) -- the float64 floor of the
+# polynomial particular solution itself: in the 1.7e-6-thin bottom layer its constant term is 1.4e4 times the intensity (1.4e-6 of
+# the largest) it leaves after cancelling against the homogeneous part; the absolute error there is 5e-12.
 PW_EXCEPT = {"8ARTS_A": None}
+PW_TRUTH_TOL = {"8ARTS_A": 5e-6}
 
 
 @pytest.fixture(scope="module")
@@ -89,8 +93,8 @@ def test_golden_case_against_high_precision_truth(amd, test_id):
     """The reference-captured cases whose pointwise metric cannot be held against the reference's own float64 output are
     held against the 40-digit solution of the same inputs (tests/golden/hp/golden_<id>.npz, tools/hp_truth_case.py): HIP
     within 1e-9 of the field scale of the truth and, pointwise, within 1e-6 or -- 8ARTS_A: the reference's captured result is
-    5.0e-5 from the truth (the inputs' own conditioning, test_hp_truth_fixtures.py), HIP 2.6e-5 -- at least as close to the
-    truth as the reference is."""
+    5.0e-5 from the truth (test_hp_truth_fixtures.py), HIP 3.7e-6 -- within PW_TRUTH_TOL (5e-6: ten times closer to the
+    truth than the reference is; see the comment at PW_EXCEPT for what the rest is)."""
     from conftest import record_parity
     z = np.load(f"{goldens.HERE}/golden/hp/golden_{test_id}.npz")
     worst = worst_pw = ref_pw = 0.0
@@ -106,7 +110,8 @@ def test_golden_case_against_high_precision_truth(amd, test_id):
         ref_pw = max(ref_pw, goldens.max_rel_err(ev["out"], z[f"c{ci}.u"])[1])
     # pointwise: the north star's 1e-6, or -- where the reference's own float64 result is farther than that from the truth --
     # at least as close to the truth as the reference is
-    record_parity("golden/" + test_id + " vs truth", worst, worst_pw, 1e-9, max(PW_TOL, ref_pw), against="40-digit truth",
+    assert ref_pw > PW_TRUTH_TOL[test_id]  # (the exception exists because the reference itself is further than this from the truth)
+    record_parity("golden/" + test_id + " vs truth", worst, worst_pw, 1e-9, PW_TRUTH_TOL[test_id], against="40-digit truth",
                   reference_vs_truth_pointwise_rel=ref_pw)
 
 
