@@ -215,3 +215,41 @@ def test_assemble_shim_has_the_references_signature():
     params = list(inspect.signature(shim).parameters)
     assert params[:34] == ref_names and params[34:] == ["device"]
     assert len([f for f in os.listdir(d) if f.endswith(".npz")]) >= 8
+
+
+def test_double_double_taylor_shift_is_exact_to_the_last_bit():
+    """csrc/rtd_dd.h moves the origin of the thermal source polynomials to the top of their layer (one double-double Taylor shift
+    on upload instead of a cancelling float64 evaluation at every use, subroutines.py:746-862 / pydisort.py:316-338).  Compiled
+    for the CPU here (the header is host + device) and held to exact rational arithmetic: every shifted coefficient is the
+    correctly rounded value, also where the terms cancel over ten digits (8ARTS_A's bottom layers: a0 = -3.6e5, a1 tau = +3.6e5)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from fractions import Fraction
+    from math import comb
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    rng = np.random.default_rng(3)
+    cases = [(2, 21.99325904, [-3.61508536e+05, 1.63496454e+04]), (2, 21.9931618, [-5.36654739e+04, 2.42711395e+03]),
+             (1, 5.0, [1.25]), (3, 0.0, [1.0, -2.0, 0.5])]
+    for _ in range(200):
+        n = int(rng.integers(1, 7))
+        t = float(rng.uniform(0.0, 60.0))
+        c = (rng.normal(size=n) * 10.0 ** rng.uniform(-3, 6, size=n)).tolist()
+        if n >= 2 and rng.random() < 0.5:  # make the constant term cancel against the rest at t
+            c[0] = -sum(c[j] * t**j for j in range(1, n)) * (1.0 + 1e-9 * rng.normal())
+        cases.append((n, t, c))
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "dd_shift")
+        subprocess.run([gxx, "-O2", "-std=c++17", "-ffp-contract=off", os.path.join(ROOT, "tests", "cpu", "dd_shift.cpp"), "-o", exe], check=True)
+        text = "".join(f"{n} {t!r} " + " ".join(repr(float(x)) for x in c) + "\n" for n, t, c in cases)
+        out = subprocess.run([exe], input=text, capture_output=True, text=True, check=True).stdout.splitlines()
+    assert len(out) == len(cases)
+    for (n, t, c), line in zip(cases, out):
+        got = [float(x) for x in line.split()]
+        tf, cf = Fraction(t), [Fraction(float(x)) for x in c]
+        for i in range(n):
+            exact = sum(cf[j] * comb(j, i) * tf ** (j - i) for j in range(i, n))
+            want = float(exact)  # correctly rounded
+            assert got[i] == want or abs(got[i] - want) <= abs(want) * 2.3e-16, (n, t, c, i, got[i], want)
