@@ -878,7 +878,7 @@ def spawn_ranks(n, argv, timeout=None):
 # one rank
 # ---------------------------------------------------------------------------------------------------------
 def run_rank(a, rank, world, local):
-    # gloo ("[Gloo] Rank 0 is connected to ...") and RCCL (its version banner) write to the C-level stdout: file descriptor 1
+    # RCCL (its version banner) writes to the C-level stdout: file descriptor 1
     # points at stderr for the whole run and the result line goes out through a private duplicate of the real stdout, so that
     # the JSON line is the only thing this program writes there
     sys.stdout.flush()

@@ -27,7 +27,7 @@ def test_bench_force_dist_runs_the_rccl_path_with_one_rank(gather, prefix):
                 "--total-columns", "6000", "--gather", gather])
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]          # the JSON line is the only thing on stdout (RCCL / gloo banners go to stderr)
+    assert len(lines) == 1, r.stdout[-2000:]          # the JSON line is the only thing on stdout (RCCL banners go to stderr)
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["config"]["ranks_joined"] == 1
     assert out["config"]["collective"].startswith(prefix), out["config"]["collective"]
