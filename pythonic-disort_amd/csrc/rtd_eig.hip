@@ -1531,9 +1531,12 @@ void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part) {
   const dim3 grid((unsigned)((long)d.C * d.M * ((d.ln + gpw - 1) / gpw)));
   // RTD_EIG_MFMA=1: the assembly of Pm, Qm on the matrix cores (NP = 16; A/B runs and a regression test)
   static const bool mfma = getenv("RTD_EIG_MFMA") != nullptr;
+#ifndef RTD_EIG_LDS_PAD
+#define RTD_EIG_LDS_PAD 0  /* profiling builds only: dynamic LDS requested per workgroup, caps the eigen kernel's wavefronts per CU */
+#endif
 #define RTD_EIG_CASE(NPV)                                                                        \
   case NPV:                                                                                      \
-    hipLaunchKernelGGL((rtd_eigen_kernel<NPV, 2>), grid, dim3(64), 0, s, d);                     \
+    hipLaunchKernelGGL((rtd_eigen_kernel<NPV, 2>), grid, dim3(64), RTD_EIG_LDS_PAD, s, d);       \
     break;
   // 2 ... 8 streams: the one-lane-per-problem kernel (rtd_eig_small.hip) unless RTD_EIG_SMALL_V1 asks for rtd_eigen_kernel<4, 2>
   static const bool small_v1 = getenv("RTD_EIG_SMALL_V1") != nullptr;
