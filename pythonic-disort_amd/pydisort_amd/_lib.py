@@ -14,7 +14,8 @@ class rtd_dims(C.Structure):
                 ("ncols", "nlayers", "nquad", "nleg", "nfourier", "nscoeffs", "nbdrf", "beam")]
 
 
-_dp = C.POINTER(C.c_double)
+_dp = C.c_void_p  # double* arguments are passed as plain addresses (an int from the array interface: 3 x cheaper to form than a
+#                    ctypes pointer object, and a one-column pydisort() call hands over twenty of them)
 _vp = C.c_void_p
 
 
@@ -113,7 +114,7 @@ def dptr(a):
     if a is None:
         return None
     assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
-    return a.ctypes.data_as(_dp)
+    return a.__array_interface__["data"][0]
 
 
 def check(rc):
