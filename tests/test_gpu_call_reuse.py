@@ -1,0 +1,70 @@
+"""One-column pydisort() calls reuse idle device plans (pydisort_amd/pydisort.py: _plan_for / _release): a plan serves the next call
+of the same shape once no closure of an earlier call refers to it -- never while one does.  The reference's closures stay valid for
+as long as the caller keeps them (_assemble_intensity_and_fluxes.py:170-613 close over GC_collect, K_collect, B_collect)."""
+import gc
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "pythonic-disort_amd")]
+import goldens  # noqa: E402
+
+
+def _kw(scale=1.0):
+    kw = dict(goldens.load("9c")[0]["kwargs"])
+    kw["omega_arr"] = np.asarray(kw["omega_arr"]) * scale
+    return kw
+
+
+def test_closures_of_an_earlier_call_stay_valid_and_idle_plans_are_reused():
+    import pydisort_amd as amd
+    tau, phi = np.array([0.0, 0.7, 3.1]), np.array([0.0, 1.0])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = amd.pydisort(**_kw(1.0))
+        ua = a[4](tau, phi)
+        b = amd.pydisort(**_kw(0.5))                       # a's closures are alive: b must get a plan of its own
+        plan_a, plan_b = a[1].__self__.plan, b[1].__self__.plan
+        assert plan_a is not plan_b
+        assert np.array_equal(a[4](tau, phi), ua)           # ... and a's results are untouched by b's solve
+        ub = b[4](tau, phi)
+        assert not np.array_equal(ua, ub)
+        del a
+        gc.collect()
+        c = amd.pydisort(**_kw(0.5))                       # a's plan is idle now: the same shape takes it
+        assert c[1].__self__.plan is plan_a
+        assert np.array_equal(c[4](tau, phi), ub)           # same inputs as b, solved on the reused plan: the same bits
+        assert np.array_equal(b[4](tau, phi), ub)
+        # Nakajima-Tanaka state does not leak from one tenant of a plan to the next
+        kw5 = dict(goldens.load("5a")[0]["kwargs"])
+        n1 = amd.pydisort(**kw5)
+        un = n1[4](np.array([0.0, 1.0]), phi)
+        p5 = n1[1].__self__.plan
+        del n1
+        gc.collect()
+        kw5_plain = dict(kw5, NT_cor=False)
+        n2 = amd.pydisort(**kw5_plain)
+        assert n2[1].__self__.plan is p5
+        fresh = amd.pydisort(**kw5_plain)                   # (n2 alive: a new plan)
+        assert fresh[1].__self__.plan is not p5
+        assert np.array_equal(n2[4](np.array([0.0, 1.0]), phi), fresh[4](np.array([0.0, 1.0]), phi))
+        assert not np.array_equal(un, n2[4](np.array([0.0, 1.0]), phi))
+
+
+def test_a_plan_closed_by_hand_is_not_handed_out_again():
+    import pydisort_amd as amd
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = amd.pydisort(**_kw(0.9))
+        plan = a[1].__self__.plan
+        plan.close()
+        del a
+        gc.collect()
+        b = amd.pydisort(**_kw(0.9))
+        assert b[1].__self__.plan is not plan
+        assert np.all(np.isfinite(b[1](np.array([0.5]))))
