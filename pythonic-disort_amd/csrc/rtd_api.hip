@@ -131,6 +131,8 @@ struct rtd_plan {
   // cfg4 window).  Plans of one window keep them in d.Y0 / d.att; larger plans in these arrays when C M P doubles fit 2 GiB.
   double *Y0_all = nullptr, *att_all = nullptr;
   bool tables_cached = false, tables_valid = false;
+  bool quad_tables_valid = false;  // the column-independent table Y[m][l][i] matches the quadrature and the mode shard (a plan that is
+  //                                 reused for another column of the same shape keeps it: one launch less per one-column solve)
   bool pipelined = false;
   // Retained plan (rtd_plan_create_retained): the eigen stage's hand-off arrays and the coefficients cover ALL columns instead
   // of one window (two slots), so that the evaluators can be called again after a solve without solving again -- what the
@@ -347,7 +349,10 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
     all.Y0 = p->Y0_all;
     all.att = p->att_all;
     if (pipe) all_tables = &all;  // launched by the first eigen stage, behind its wait: the previous run may still read them
-    else rtd_launch_tables(all, se, true);
+    else {
+      rtd_launch_tables(all, se, !p->quad_tables_valid);
+      p->quad_tables_valid = true;
+    }
     p->tables_valid = true;
   }
   const bool per_window_tables = !p->tables_cached;
@@ -361,10 +366,14 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
     if (p->bc_recorded[slot]) (void)hipStreamWaitEvent(se, p->ev_bc[slot], 0);
     if (w == 0) (void)clear_status(se);  // (a failure here shows up as the launch error checked below)
     if (w == 0 && all_tables) {
-      rtd_launch_tables(*all_tables, se, true);
+      rtd_launch_tables(*all_tables, se, !p->quad_tables_valid);
+      p->quad_tables_valid = true;
       all_tables = nullptr;
     }
-    if (per_window_tables) rtd_launch_tables(d, se, w == 0);
+    if (per_window_tables) {
+      rtd_launch_tables(d, se, w == 0 && !p->quad_tables_valid);
+      p->quad_tables_valid = true;
+    }
     rtd_launch_eig(d, se, 1);
     (void)hipEventRecord(p->ev_eig[slot], se);
   };
@@ -389,7 +398,10 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
       rtd_launch_bc(d, s, 1);
     } else if (with_solve) {
       mark(0);
-      if (per_window_tables) rtd_launch_tables(d, s, w == 0);
+      if (per_window_tables) {
+        rtd_launch_tables(d, s, w == 0 && !p->quad_tables_valid);
+        p->quad_tables_valid = true;
+      }
       mark(1);
       rtd_launch_eig(d, s, 0);
       mark(2);
@@ -789,6 +801,7 @@ int rtd_plan_set_quadrature(rtd_plan* p, const double* mu_pos, const double* wei
   p->have_quad = true;
   p->fork_needed = true;
   p->tables_valid = false;
+  p->quad_tables_valid = false;
   p->solved = false;
   return 0;
 }
@@ -1012,12 +1025,14 @@ int rtd_plan_set_mode_shard(rtd_plan* p, int32_t first, int32_t stride, int32_t 
   d.mtot = total;
   p->solved = false;
   p->tables_valid = false;
+  p->quad_tables_valid = false;
   return 0;
 }
 
 int rtd_plan_invalidate_tables(rtd_plan* p) {
   if (!p) return fail(RTD_ERR_ARG, "null plan");
   p->tables_valid = false;
+  p->quad_tables_valid = false;  // (everything a fresh call would compute, the column-independent table included)
   p->fork_needed = true;  // as after an upload: the next solve starts behind everything queued on the plan's stream
   return 0;
 }
@@ -1660,7 +1675,8 @@ int rtd_plan_solve_layers(rtd_plan* p, int32_t first, int32_t count) {
   HIP_TRY(hipMemsetAsync(d.status, 0, sizeof(int), p->stream));  // as launch_windows: a new solve starts clean
   HIP_TRY(hipMemsetAsync(d.col_status, 0, sizeof(int) * (size_t)d.C, p->stream));
   p->numeric_status = 0;
-  rtd_launch_tables(d, p->stream, true);
+  rtd_launch_tables(d, p->stream, !p->quad_tables_valid);
+  p->quad_tables_valid = true;
   p->tables_valid = true;  // (one-window plan: d.Y0 / d.att are the all-columns tables)
   rtd_launch_eig(d, p->stream, 1);
   hipError_t e = hipGetLastError();
