@@ -498,7 +498,7 @@ extern "C" {
 
 int rtd_comm_destroy(rtd_plan* p);
 
-int rtd_version(void) { return 200; }
+int rtd_version(void) { return 210; }  // 210: rtd_plan_create_retained, rtd_plan_retained, rtd_comm_size (round 5)
 
 const char* rtd_last_error(void) { return g_err.c_str(); }
 
