@@ -14,7 +14,10 @@ warnings.simplefilter("ignore")
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 bad = 0
 t0 = time.time()
+only = int(os.environ["FUZZ_ONLY"]) if os.environ.get("FUZZ_ONLY") else None  # FUZZ_ONLY=1552: that batch alone, with per-column detail
 for b in range(nb):
+    if only is not None and b != only:
+        continue
     rng = np.random.default_rng([77, b])
     NQuad = int(rng.choice([2, 4, 6, 8, 12, 16, 18, 24, 32, 40, 64, 72]))
     N = NQuad // 2
@@ -90,6 +93,15 @@ for b in range(nb):
             d = np.max(np.abs(res["u"] - u)) / max(np.max(np.abs(u)), 1e-300)
             if d > 1e-11:
                 bad += 1; print(tag, "streamed raw path differs: %.2e" % d, flush=True)
+            if only is not None:  # per column: both preparations against the oracle
+                for i in range(C):
+                    kw = synthetic.column_kwargs(cfg, i)
+                    kw["NFourier"] = M
+                    ur = np.reshape(O.pydisort(**kw)[4](tau[i], phi), u[i].shape)
+                    sc = max(np.max(np.abs(ur)), 1e-300)
+                    print("  column %d: numpy-prepared vs oracle %.2e, raw vs oracle %.2e, raw vs numpy-prepared %.2e, mu0 %.6f, max omega %.6f"
+                          % (i, np.max(np.abs(u[i] - ur)) / sc, np.max(np.abs(res["u"][i] - ur)) / sc, np.max(np.abs(res["u"][i] - u[i])) / sc,
+                             cfg["mu0"][i], cfg["omega_arr"][i].max()), flush=True)
         sol.plan.close(); solw.plan.close()
     except Exception as e:
         bad += 1; print(tag, "EXCEPTION", type(e).__name__, str(e)[:160], flush=True)
