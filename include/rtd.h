@@ -76,6 +76,15 @@ int rtd_plan_destroy(rtd_plan* plan);
 int rtd_plan_synchronize(rtd_plan* plan);
 /* bytes of device memory held by the plan */
 int rtd_plan_device_bytes(rtd_plan* plan, int64_t* bytes);
+/* The library keeps the device memory of destroyed plans for the next plan of about the same size (blocks up to 64 MB: 512 MB in
+ * all; larger blocks: up to RTD_POOL_BYTES, default an eighth of the device's memory, oldest out first) -- creating and destroying a
+ * plan per call then costs neither hipMalloc nor the seconds-long stalls the runtime's lazy reclaim of freed gigabytes puts on
+ * later allocations (profiles/r05_alloc_outliers.txt).  No counterpart in the reference (NumPy's allocator).
+ * rtd_pool_bytes: what is held right now; rtd_pool_trim: give it back to the runtime (device -1: every device; released may be
+ * NULL).  An allocation of the library that fails with out-of-memory trims the pool and is tried again by itself; a caller that
+ * shares the device with another allocator (a framework's caching allocator) calls rtd_pool_trim before that one needs the room. */
+int rtd_pool_bytes(int64_t* cached);
+int rtd_pool_trim(int32_t device, int64_t* released);
 /* Which columns of the batch failed numerically in the last solve: status[ncols], 0 = fine.  Bits 1..4 of the low byte:
  * 2 eigen-iteration not converged, 4 non-positive Cholesky pivot / non-finite eigenvalue, 8 singular boundary-condition
  * system, 16 non-finite beam particular solution -- raised by Fourier mode 0; the same bits shifted left by 8: raised by
@@ -299,6 +308,8 @@ enum {
  * parity (tests/test_gpu_parity.py runs the suite under each), size buffers, or print diagnostics.  Timing experiments whose
  * results are NOT valid (e.g. the aliased hand-off reads of DESIGN.md section 7a) exist only behind compile-time -D flags.
  *   RTD_WORK_BYTES        bytes of solve intermediates per plan (default 24 GiB): sizes the automatic column window
+ *   RTD_POOL_BYTES        bytes of device memory of destroyed plans kept for the next plan in blocks above 64 MB (default: an
+ *                         eighth of the device's memory; 0: large blocks go straight back to the runtime); see rtd_pool_trim
  *   RTD_NO_PIPELINE       windows one after the other on one stream (no second hand-off slot, no eigen stream)
  *   RTD_BC_FORCE_PIVOT    fused boundary-condition kernels: =1 every elimination is redone by the column-pivoted LDS path (the
  *                         path of a failed speculation); =2 every chain of the 32-stream kernel takes the register-resident

@@ -45,38 +45,84 @@ int pad_pow2(int n) {
 }
 
 // Device-buffer and stream pool (SURVEY section 8(b) "threading": the library owns only device scratch, pooled and
-// guarded by a mutex).  One-column pydisort() calls create and destroy a plan per call; recycling small arenas and
-// streams removes the hipMalloc/hipFree/hipStreamCreate cost (milliseconds) from that path.
+// guarded by a mutex).  Two reasons, two tiers:
+//  * one-column pydisort() calls create and destroy a plan per call; recycling small arenas (blocks <= 64 MB, 512 MB in all, a
+//    block serves requests down to a quarter of its size) and streams removes the hipMalloc / hipFree / hipStreamCreate cost
+//    (milliseconds) from that path;
+//  * batch calls create and destroy plans of gigabytes.  hipFree of such a block returns in ~2 ms, but the runtime reclaims the
+//    memory lazily, and every so often a later hipMalloc pays for it: 0.4 ... 4.8 s, growing with the bytes freed since
+//    (profiles/r05_alloc_outliers.txt: 9 of 40 creations of a 14 GB plan, the same with bare hipMalloc / hipFree).  Blocks above
+//    64 MB are therefore kept too, oldest out first, up to RTD_POOL_BYTES (default: an eighth of the device's memory); they serve
+//    requests down to 7/8 of their size -- a serving loop repeats its shapes.  rtd_pool_trim gives everything back; a hipMalloc
+//    that fails trims the pool and tries again, so the pool never costs a caller of THIS library an allocation.
 struct DevPool {
   struct Block { void* p; size_t bytes; int dev; };
   std::mutex m;
-  std::vector<Block> free_blocks;
+  std::vector<Block> free_blocks, big_blocks;  // (big_blocks in order of arrival)
   std::vector<std::pair<hipStream_t, int>> free_streams;
-  size_t cached = 0;
+  size_t cached = 0, big_cached = 0;
+  int64_t big_cap = -1;  // bytes; -1: not sized yet
   static constexpr size_t MAX_BLOCK = 64u << 20, MAX_CACHED = 512u << 20;
 
   void* get(size_t bytes, int dev, size_t* got) {
     std::lock_guard<std::mutex> g(m);
+    const bool big = bytes > MAX_BLOCK;
+    std::vector<Block>& list = big ? big_blocks : free_blocks;
+    const size_t most = big ? bytes + bytes / 7 : 4 * bytes + 4096;
     int best = -1;
-    for (int i = 0; i < (int)free_blocks.size(); ++i) {
-      const Block& b = free_blocks[i];
-      if (b.dev == dev && b.bytes >= bytes && b.bytes <= 4 * bytes + 4096 &&
-          (best < 0 || b.bytes < free_blocks[best].bytes))
-        best = i;
+    for (int i = 0; i < (int)list.size(); ++i) {
+      const Block& b = list[i];
+      if (b.dev == dev && b.bytes >= bytes && b.bytes <= most && (best < 0 || b.bytes < list[best].bytes)) best = i;
     }
     if (best < 0) return nullptr;
-    Block b = free_blocks[best];
-    free_blocks.erase(free_blocks.begin() + best);
-    cached -= b.bytes;
+    Block b = list[best];
+    list.erase(list.begin() + best);
+    (big ? big_cached : cached) -= b.bytes;
     *got = b.bytes;
     return b.p;
   }
   bool put(void* p, size_t bytes, int dev) {
     std::lock_guard<std::mutex> g(m);
-    if (bytes > MAX_BLOCK || cached + bytes > MAX_CACHED) return false;
-    free_blocks.push_back({p, bytes, dev});
-    cached += bytes;
+    if (bytes <= MAX_BLOCK) {
+      if (cached + bytes > MAX_CACHED) return false;
+      free_blocks.push_back({p, bytes, dev});
+      cached += bytes;
+      return true;
+    }
+    if (big_cap < 0) {
+      const char* env = getenv("RTD_POOL_BYTES");
+      size_t fr = 0, total = 0;
+      if (env) big_cap = std::max<long long>(0, atoll(env));
+      else big_cap = hipMemGetInfo(&fr, &total) == hipSuccess ? (int64_t)(total / 8) : 0;
+    }
+    if ((int64_t)bytes > big_cap) return false;
+    while (!big_blocks.empty() && (int64_t)(big_cached + bytes) > big_cap) {  // oldest out first
+      big_cached -= big_blocks.front().bytes;
+      (void)hipFree(big_blocks.front().p);
+      big_blocks.erase(big_blocks.begin());
+    }
+    big_blocks.push_back({p, bytes, dev});
+    big_cached += bytes;
     return true;
+  }
+  // gives the cached blocks of `dev` (-1: every device) back to the runtime; returns the bytes released
+  size_t trim(int dev) {
+    std::lock_guard<std::mutex> g(m);
+    size_t released = 0;
+    for (std::vector<Block>* list : {&free_blocks, &big_blocks}) {
+      std::vector<Block> keep;
+      for (const Block& b : *list) {
+        if (dev >= 0 && b.dev != dev) {
+          keep.push_back(b);
+          continue;
+        }
+        (void)hipFree(b.p);
+        released += b.bytes;
+        (list == &free_blocks ? cached : big_cached) -= b.bytes;
+      }
+      list->swap(keep);
+    }
+    return released;
   }
   hipStream_t get_stream(int dev) {
     std::lock_guard<std::mutex> g(m);
@@ -104,7 +150,12 @@ hipError_t pooled_malloc(void** q, size_t bytes, int dev, size_t* got) {
   *q = pool().get(bytes, dev, got);
   if (*q) return hipSuccess;
   *got = bytes;
-  return hipMalloc(q, bytes);
+  hipError_t e = hipMalloc(q, bytes);
+  if (e == hipErrorOutOfMemory && pool().trim(dev) > 0) {  // what the pool holds is this library's to give up first
+    (void)hipGetLastError();
+    e = hipMalloc(q, bytes);
+  }
+  return e;
 }
 void pooled_free(void* q, size_t bytes, int dev) {
   if (!pool().put(q, bytes, dev)) (void)hipFree(q);
@@ -498,7 +549,7 @@ extern "C" {
 
 int rtd_comm_destroy(rtd_plan* p);
 
-int rtd_version(void) { return 210; }  // 210: rtd_plan_create_retained, rtd_plan_retained, rtd_comm_size (round 5)
+int rtd_version(void) { return 211; }  // 210: rtd_plan_create_retained, rtd_plan_retained, rtd_comm_size; 211: rtd_pool_trim, rtd_pool_bytes (round 5)
 
 const char* rtd_last_error(void) { return g_err.c_str(); }
 
@@ -765,6 +816,20 @@ int rtd_plan_get_column_status(rtd_plan* p, int32_t* status) {
 int rtd_plan_device_bytes(rtd_plan* p, int64_t* bytes) {
   if (!p || !bytes) return fail(RTD_ERR_ARG, "null argument");
   *bytes = p->bytes;
+  return 0;
+}
+
+int rtd_pool_trim(int32_t device, int64_t* released) {
+  const size_t n = pool().trim(device);
+  if (released) *released = (int64_t)n;
+  return 0;
+}
+
+int rtd_pool_bytes(int64_t* cached) {
+  if (!cached) return fail(RTD_ERR_ARG, "null argument");
+  DevPool& q = pool();
+  std::lock_guard<std::mutex> g(q.m);
+  *cached = (int64_t)(q.cached + q.big_cached);
   return 0;
 }
 

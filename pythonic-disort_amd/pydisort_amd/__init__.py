@@ -7,5 +7,8 @@ numerics run in hand-written HIP kernels (librtd.so) reached through the C ABI o
 from .pydisort import pydisort  # noqa: F401
 from .batch import pydisort_batch, BatchSolution, solve_columns_streamed  # noqa: F401
 from . import subroutines  # noqa: F401
+from ._engine import Plan as _Plan
 
-__all__ = ["pydisort", "pydisort_batch", "BatchSolution", "solve_columns_streamed", "subroutines"]
+pool_bytes, pool_trim = _Plan.pool_bytes, _Plan.pool_trim  # device memory of closed plans kept for the next one (include/rtd.h)
+
+__all__ = ["pydisort", "pydisort_batch", "BatchSolution", "solve_columns_streamed", "subroutines", "pool_bytes", "pool_trim"]

@@ -146,6 +146,20 @@ class Plan:
         _lib.check(self._lib.rtd_plan_device_bytes(self._h, C.byref(b)))
         return b.value
 
+    @staticmethod
+    def pool_bytes():
+        """Device memory of closed plans that the library keeps for the next plan (include/rtd.h: rtd_pool_bytes)."""
+        b = C.c_int64()
+        _lib.check(_lib.load().rtd_pool_bytes(C.byref(b)))
+        return b.value
+
+    @staticmethod
+    def pool_trim(device=-1):
+        """Gives that memory back to the runtime (include/rtd.h: rtd_pool_trim); returns the bytes released."""
+        b = C.c_int64()
+        _lib.check(_lib.load().rtd_pool_trim(int(device), C.byref(b)))
+        return b.value
+
     def evaluate(self, tau, phi=None, antiderivative=False, want=("u", "u0", "flux"), skip_nt=False):
         """tau [C, ntau]; phi [nphi] or None -> dict of arrays (u [C,Q,ntau,nphi], u0 [C,Q,ntau],
         flux_up / flux_down_diffuse / flux_down_direct [C,ntau], ulast [C,Q,ntau])."""

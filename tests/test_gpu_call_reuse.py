@@ -68,3 +68,37 @@ def test_a_plan_closed_by_hand_is_not_handed_out_again():
         b = amd.pydisort(**_kw(0.9))
         assert b[1].__self__.plan is not plan
         assert np.all(np.isfinite(b[1](np.array([0.5]))))
+
+
+def test_device_memory_of_closed_batch_plans_serves_the_next_plan():
+    """The device arena of a closed plan -- whatever a previous tenant left in it -- is what the next plan of the same shape is
+    built in (include/rtd.h: rtd_pool_bytes / rtd_pool_trim): same bits as from fresh memory, for a retained windowed plan with
+    thermal sources and a BDRF and for a plain one; rtd_pool_trim gives everything back."""
+    import pydisort_amd as amd
+    from pydisort_amd import synthetic
+    amd.pool_trim()
+    assert amd.pool_bytes() == 0
+    rng = np.random.default_rng(3)
+    for maker, kw, cols, win in (("cfg5_columns", dict(L=12, NQuad=64), 24, 8), ("cfg4_columns", {}, 300, 128)):
+        cfg = getattr(synthetic, maker)(cols, **kw)
+        other = getattr(synthetic, maker)(cols, first=500, **kw)
+        tau = np.sort(rng.uniform(0, 1, (cols, 4)), axis=1) * cfg["tau_arr"][:, -1:]
+        tau_o = np.sort(rng.uniform(0, 1, (cols, 4)), axis=1) * other["tau_arr"][:, -1:]
+        phi = np.array([0.2, 2.9])
+        _, first = amd.pydisort_batch(work_columns=win, **cfg)           # fresh memory
+        want = first.u(tau, phi), first.flux_up(tau)
+        nbytes = first.plan.device_bytes()
+        assert nbytes > (64 << 20) and first.plan.retained()
+        first.plan.close()
+        held = amd.pool_bytes()
+        assert held >= 0.9 * nbytes                                       # the arena (and the evaluation buffers) are kept
+        _, dirty = amd.pydisort_batch(work_columns=win, **other)         # a tenant that leaves other columns' state behind
+        assert amd.pool_bytes() < held                                    # ... it was built in the kept memory
+        dirty.u(tau_o, phi)
+        dirty.plan.close()
+        _, again = amd.pydisort_batch(work_columns=win, **cfg)
+        got = again.u(tau, phi), again.flux_up(tau)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        again.plan.close()
+    assert amd.pool_bytes() > 0
+    assert amd.pool_trim() > 0 and amd.pool_bytes() == 0
