@@ -60,7 +60,8 @@ struct DevPool {
   std::mutex m;
   std::vector<Block> free_blocks, big_blocks;  // (big_blocks in order of arrival)
   std::vector<std::pair<hipStream_t, int>> free_streams;
-  size_t cached = 0, big_cached = 0;
+  std::vector<Block> host_blocks;  // pinned staging slabs of rtd_plan_run_fetch (hipHostMalloc + hipHostFree: ~3 ms per plan)
+  size_t cached = 0, big_cached = 0, host_cached = 0;
   int64_t big_cap = -1;  // bytes; -1: not sized yet
   static constexpr size_t MAX_BLOCK = 64u << 20, MAX_CACHED = 512u << 20;
 
@@ -105,10 +106,36 @@ struct DevPool {
     big_cached += bytes;
     return true;
   }
-  // gives the cached blocks of `dev` (-1: every device) back to the runtime; returns the bytes released
+  void* get_host(size_t bytes, size_t* got) {
+    std::lock_guard<std::mutex> g(m);
+    int best = -1;
+    for (int i = 0; i < (int)host_blocks.size(); ++i) {
+      const Block& b = host_blocks[i];
+      if (b.bytes >= bytes && b.bytes <= 2 * bytes + 4096 && (best < 0 || b.bytes < host_blocks[best].bytes)) best = i;
+    }
+    if (best < 0) return nullptr;
+    Block b = host_blocks[best];
+    host_blocks.erase(host_blocks.begin() + best);
+    host_cached -= b.bytes;
+    *got = b.bytes;
+    return b.p;
+  }
+  bool put_host(void* p, size_t bytes) {
+    std::lock_guard<std::mutex> g(m);
+    if (host_cached + bytes > (256u << 20)) return false;
+    host_blocks.push_back({p, bytes, -1});
+    host_cached += bytes;
+    return true;
+  }
+  // gives the cached blocks of `dev` (-1: every device) back to the runtime; returns the device bytes released
   size_t trim(int dev) {
     std::lock_guard<std::mutex> g(m);
     size_t released = 0;
+    if (dev < 0) {
+      for (const Block& b : host_blocks) (void)hipHostFree(b.p);
+      host_blocks.clear();
+      host_cached = 0;
+    }
     for (std::vector<Block>* list : {&free_blocks, &big_blocks}) {
       std::vector<Block> keep;
       for (const Block& b : *list) {
@@ -242,7 +269,7 @@ struct rtd_plan {
   bool gathered_here = false;  // the last results collective left the gathered arrays of ALL ranks on this rank
   // host-to-host pipeline (rtd_plan_run_fetch): two pinned staging slabs, one per window in flight
   char* stage[2] = {nullptr, nullptr};
-  size_t stage_bytes = 0;
+  size_t stage_bytes = 0, stage_cap[2] = {0, 0};  // bytes in use of each slab; true size of each (a pooled slab may be larger)
   hipEvent_t ev_win[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
   // timing
   bool timing = false;
@@ -715,7 +742,8 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
       if (Ns > 0) HIP_TRY(hipMemsetAsync(h1.dq, 0, (size_t)(Cw * L * Ns * Q2) * 8, p->stream));
     }
     // (stream priorities either way changed nothing: profiles/r03_experiments.json)
-    HIP_TRY(hipStreamCreateWithFlags(&p->eig_stream, hipStreamNonBlocking));
+    p->eig_stream = pool().get_stream(device);
+    if (!p->eig_stream) HIP_TRY(hipStreamCreateWithFlags(&p->eig_stream, hipStreamNonBlocking));
     for (hipEvent_t* e : {&p->ev_eig[0], &p->ev_eig[1], &p->ev_bc[0], &p->ev_bc[1], &p->ev_fork})
       HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
@@ -785,11 +813,12 @@ int rtd_plan_destroy(rtd_plan* p) {
   for (hipEvent_t e : {p->ev_results, p->ev_gathered, p->ev_win[0], p->ev_win[1], p->ev_copied[0], p->ev_copied[1], p->ev_eig[0],
                        p->ev_eig[1], p->ev_bc[0], p->ev_bc[1], p->ev_fork})
     if (e) (void)hipEventDestroy(e);
-  if (p->eig_stream) (void)hipStreamDestroy(p->eig_stream);
-  for (char* st : p->stage)
-    if (st) (void)hipHostFree(st);
+  // (every stream was drained above: the streams and the pinned slabs can serve another plan at once)
+  if (p->eig_stream) pool().put_stream(p->eig_stream, p->device);
+  for (int k = 0; k < 2; ++k)
+    if (p->stage[k] && !pool().put_host(p->stage[k], p->stage_cap[k])) (void)hipHostFree(p->stage[k]);
   if (p->comm_stream) (void)hipStreamDestroy(p->comm_stream);
-  if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
+  if (p->copy_stream) pool().put_stream(p->copy_stream, p->device);
   if (p->stream) pool().put_stream(p->stream, p->device);
   delete p;
   return 0;
@@ -1211,16 +1240,18 @@ int rtd_plan_run_fetch(rtd_plan* p, double* u, double* u0, double* flux_up, doub
   const int64_t per_u = (u && np > 0) ? Qr * nt * np : 0, per_u0 = u0 ? Qr * nt : 0, per_fl = nt;
   const int nfl = (flux_up ? 1 : 0) + (fdn ? 1 : 0) + (fdir ? 1 : 0);
   const size_t slab = (size_t)p->Cw * (size_t)(per_u + per_u0 + nfl * per_fl) * 8;
+  if (!p->copy_stream) p->copy_stream = pool().get_stream(p->device);
   if (!p->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
   for (int k = 0; k < 2; ++k) {
     if (!p->ev_win[k]) HIP_TRY(hipEventCreateWithFlags(&p->ev_win[k], hipEventDisableTiming));
     if (!p->ev_copied[k]) HIP_TRY(hipEventCreateWithFlags(&p->ev_copied[k], hipEventDisableTiming));
   }
   if (slab > p->stage_bytes) {
-    for (char*& st : p->stage) {
-      if (st) (void)hipHostFree(st);
-      st = nullptr;
-      HIP_TRY(hipHostMalloc((void**)&st, slab, hipHostMallocDefault));
+    for (int k = 0; k < 2; ++k) {
+      char*& st = p->stage[k];
+      if (st && !pool().put_host(st, p->stage_cap[k])) (void)hipHostFree(st);
+      st = static_cast<char*>(pool().get_host(slab, &p->stage_cap[k]));
+      if (!st) HIP_TRY(hipHostMalloc((void**)&st, p->stage_cap[k] = slab, hipHostMallocDefault));
     }
     p->stage_bytes = slab;
   }
