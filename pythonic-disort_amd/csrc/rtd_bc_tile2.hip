@@ -28,6 +28,21 @@ namespace {
 #include "rtd_bc_tile_common.h"
 
 constexpr int T2 = 2, NP2 = 32, Q2 = 64, NN2 = 1024;
+
+// Diagnostic build (-DRTD_T2_STAMPS, never shipped; tools/build_variant.py): s_memtime at the phase boundaries of a chain, summed
+// over its layers, printed by a few wavefronts (T2STAMP lines; tools/eig_phase_cycles.py formats them too).
+#ifdef RTD_T2_STAMPS
+#define RTD_T2STAMP(k)                                              \
+  {                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    const long long now_ = (long long)__builtin_amdgcn_s_memtime(); \
+    t2acc[k] += now_ - t2last;                                      \
+    t2last = now_;                                                  \
+    __builtin_amdgcn_sched_barrier(0);                              \
+  }
+#else
+#define RTD_T2STAMP(k)
+#endif
 using Mat = MatT<2>;
 using Row = RowT<2>;
 using Col = ColT<2>;
@@ -103,6 +118,11 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
   const long cm = blockIdx.x;
   const int m = (int)(cm % d.M), c = (int)(cm / d.M);
   const int L = d.L, Lm1 = L - 1;
+#ifdef RTD_T2_STAMPS
+  long long t2acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long t2last = (long long)__builtin_amdgcn_s_memtime();
+  const long long t2start = t2last;
+#endif
   const double* Ym = d.Ym + cm * L * NN;
   const double* Am = d.Am + cm * L * NN;
   const double* kk = d.kk + cm * L * NP;
@@ -127,6 +147,15 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
     }
     return;
   }
+  constexpr int LDM = NP + 1;
+  // forward sweep: Y and A of ONE layer, row-major, filled by LDS-DMA (global_load_lds_dwordx4: no registers, no wait) while the
+  // elimination of the layer above runs -- every matrix of the hand-off is fetched from memory ONCE in the forward sweep and read
+  // from here twice (as the lower layer of one interface, then as the upper layer of the next); backward sweep: staging area
+  __shared__ double sBuf[2 * NN];
+  // ... and the vectors of the interface below it, by the same route: [B_l, B_(l+1) | v_l bottom, v_(l+1) top | k_l, k_(l+1), E_l, E_(l+1)]
+  __shared__ double sVec[4 * Q + 2 * Q];
+  constexpr int VB = 0, VV = 2 * Q, VK = 4 * Q, VE = 4 * Q + 2 * NP;
+  static_assert(2 * NN >= NP * LDM, "the staging area of the backward sweep lives in the forward sweep's layer buffers");
   // (kq, col are passed in: the callers hand over an opaque copy of the lane index, so that the compiler rebuilds the few
   //  address registers where they are needed instead of keeping dozens of hoisted ones alive)
   auto load_d = [](const double* p, const int kq, const int col) {  // row-major NP x NP matrix -> tiles in the D layout
@@ -137,6 +166,53 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
       for (int J = 0; J < T; ++J)
 #pragma unroll
         for (int q = 0; q < 4; ++q) x.t[I][J][q] = p[(16 * I + 4 * q + kq) * NP + 16 * J + col];
+    return x;
+  };
+  auto lds_d = [&](const int which, const int kq, const int col) {  // the same tiles from the layer buffers (0: Y, 1: A)
+    Mat x;
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+      for (int J = 0; J < T; ++J)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x.t[I][J][q] = sBuf[which * NN + (16 * I + 4 * q + kq) * NP + 16 * J + col];
+    return x;
+  };
+  // Y and A of `layer` into the layer buffers: 16 wave-instructions of 1 KB (lane: 16 bytes), in flight behind whatever follows
+  auto prefetch_layer = [&](const int layer, const int lv) {
+    {  // the vectors of interface layer - 1: three instructions
+      const int l = layer - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bv + l * Q + 2 * lv),
+                                       (__attribute__((address_space(3))) void*)(sVec + VB), 16, 0, 0);
+      if (iso)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbp + (l * 4 + 2) * NP + 2 * lv),
+                                         (__attribute__((address_space(3))) void*)(sVec + VV), 16, 0, 0);
+      const double* ke = (lv < 32 ? kk + l * NP : Ek + l * NP - 2 * NP) + 2 * lv;  // lanes 0-31: k_l, k_(l+1); lanes 32-63: E_l, E_(l+1)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ke,
+                                       (__attribute__((address_space(3))) void*)(sVec + VK), 16, 0, 0);
+    }
+    const double* gy = Ym + (long)layer * NN + 2 * lv;
+    const double* ga = Am + (long)layer * NN + 2 * lv;
+#pragma unroll
+    for (int i = 0; i < NN / 128; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gy + 128 * i),
+                                       (__attribute__((address_space(3))) void*)(sBuf + 128 * i), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + 128 * i),
+                                       (__attribute__((address_space(3))) void*)(sBuf + NN + 128 * i), 16, 0, 0);
+    }
+  };
+  auto vec_row = [&](const int off, const int kq) {  // a vector of the interface from sVec, row form
+    Row x;
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x.r[I][q] = sVec[off + 16 * I + 4 * q + kq];
+    return x;
+  };
+  auto vec_col = [&](const int off, const int col) {
+    Col x;
+#pragma unroll
+    for (int J = 0; J < T; ++J) x.c[J] = sVec[off + 16 * J + col];
     return x;
   };
   auto load_row = [](const double* p, const int kq) {
@@ -174,8 +250,6 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
       *d.split_any = 1;  // (they do not evaluate at the interfaces: the evaluation kernel then does it for the window)
     }
   };
-  constexpr int LDM = NP + 1;
-  __shared__ double sX[NP * LDM];  // transposes of the forward sweep; staging area of the backward sweep
   __shared__ int sPerm[NP];
   __shared__ double sT[2][NP];  // T and 1 / T
   for (int e = lane; e < NP; e += 64) {
@@ -185,24 +259,6 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
   }
   __syncthreads();
 
-  // transposed copy of a D-layout matrix through LDS, added to / subtracted from acc:  acc += sign * mm^T
-  auto add_transposed = [&](Mat& acc, const Mat& mm, const double sign, const int kq, const int col) {
-    __syncthreads();
-#pragma unroll
-    for (int I = 0; I < T; ++I)
-#pragma unroll
-      for (int J = 0; J < T; ++J)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sX[(16 * I + 4 * q + kq) * LDM + 16 * J + col] = mm.t[I][J][q];
-    __syncthreads();
-#pragma unroll
-    for (int I = 0; I < T; ++I)
-#pragma unroll
-      for (int J = 0; J < T; ++J)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc.t[I][J][q] += sign * sX[(16 * J + col) * LDM + 16 * I + 4 * q + kq];
-    __syncthreads();
-  };
   // after GjPivT: unknown (J, col) sits in the column that was the pivot of step 16 J + col
   auto unpermute = [&](Mat& xb, Col& xv, const bool with_tb, const int rowbase, const int col) {
     __syncthreads();
@@ -283,12 +339,30 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
   //   Ta'^T = -(Wq^T H E + Wp^T),  Tb'^T = -E' (Wp^T H E + Wq^T),  t' = rho_t - E (s - S rho_b),
   //   Wp/Wq = (M1 +- M2s)/2,  M1 = A_l^T Y',  M2s = diag(k) Y_l^T A' diag(1/k').  Every operand is requested where it is used.
   //   (a0, y0s: A_l, Y_l -- requested by the caller ahead of the elimination that precedes this call, unless `have` is false)
-  auto carry = [&](const int l, Mat& ta, Mat& tb, Col& tv, Mat& a0, Mat& y0s, const bool have) {
+  auto carry = [&](const int l, Mat& ta, Mat& tb, Col& tv, Mat& a0, Mat& y0s, const bool have, const bool below_in_lds) {
     const int lv = opaque_lane(), kq = lv >> 4, col = lv & 15, rowbase = lv & 48;
     double* ws = wsb + (long)l * Ws<NP>::SLOT;
     if (!have) {
       a0 = load_d(Am + (long)l * NN, kq, col);
       y0s = load_d(Ym + (long)l * NN, kq, col);
+    }
+    // Everything this call reads of the layer below and of the interface is in LDS since the elimination above (below_in_lds; a
+    // repeated carry asks memory instead).  Loads, stores and the DMA share one in-order counter: the wait here finds only requests
+    // that are an elimination old, and H_l, s_l leave AFTER it -- the call has no request of its own behind them, so nothing in
+    // the forward sweep ever waits for a store's acknowledgement (which cost 12 k cycles per layer when the stores went first).
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (have) {  // (a repeated carry has reloaded them from there)
+#ifndef RTD_T2_NO_STORES_EXPERIMENT  /* timing experiment only: the results are wrong without H */
+#pragma unroll
+      for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int J = 0; J < T; ++J)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ws[Ws<NP>::S + (16 * I + 4 * q + kq) * NP + 16 * J + col] = tb.t[I][J][q];
+#endif
+      if (kq == 0)
+#pragma unroll
+        for (int J = 0; J < T; ++J) ws[Ws<NP>::SV + 16 * J + col] = tv.c[J];
     }
     // the jump of the particular solution at the interface, rows: r_l = p_(l+1)(tau_(l+1)) - p_l(tau_(l+1)) (:184-205, :242-245)
     Row vs, vd;  // T (r_up + r_dn), -T (r_up - r_dn)
@@ -300,8 +374,10 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
         for (int q = 0; q < 4; ++q) ru.r[I][q] = rd.r[I][q] = 0.0;
       if (beam) {
         const double a = att[l + 1];
-        const Row bu1 = load_row(Bv + (l + 1) * Q, kq), bu0 = load_row(Bv + l * Q, kq);
-        const Row bd1 = load_row(Bv + (l + 1) * Q + NP, kq), bd0 = load_row(Bv + l * Q + NP, kq);
+        const Row bu1 = below_in_lds ? vec_row(VB + Q, kq) : load_row(Bv + (l + 1) * Q, kq);
+        const Row bu0 = below_in_lds ? vec_row(VB, kq) : load_row(Bv + l * Q, kq);
+        const Row bd1 = below_in_lds ? vec_row(VB + Q + NP, kq) : load_row(Bv + (l + 1) * Q + NP, kq);
+        const Row bd0 = below_in_lds ? vec_row(VB + NP, kq) : load_row(Bv + l * Q + NP, kq);
 #pragma unroll
         for (int I = 0; I < T; ++I)
 #pragma unroll
@@ -311,8 +387,10 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
           }
       }
       if (iso) {  // v_(l+1) at its top minus v_l at its bottom
-        const Row tu = load_row(vbp + ((l + 1) * 4 + 0) * NP, kq), td = load_row(vbp + ((l + 1) * 4 + 1) * NP, kq);
-        const Row bu = load_row(vbp + (l * 4 + 2) * NP, kq), bd = load_row(vbp + (l * 4 + 3) * NP, kq);
+        const Row tu = below_in_lds ? vec_row(VV + 2 * NP, kq) : load_row(vbp + ((l + 1) * 4 + 0) * NP, kq);
+        const Row td = below_in_lds ? vec_row(VV + 3 * NP, kq) : load_row(vbp + ((l + 1) * 4 + 1) * NP, kq);
+        const Row bu = below_in_lds ? vec_row(VV, kq) : load_row(vbp + (l * 4 + 2) * NP, kq);
+        const Row bd = below_in_lds ? vec_row(VV + NP, kq) : load_row(vbp + (l * 4 + 3) * NP, kq);
 #pragma unroll
         for (int I = 0; I < T; ++I)
 #pragma unroll
@@ -331,7 +409,7 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
         }
     }
     {
-      const Col k0c = load_col(kk + l * NP, col);
+      const Col k0c = below_in_lds ? vec_col(VK, col) : load_col(kk + l * NP, col);
 #pragma unroll
       for (int J = 0; J < T; ++J)
 #pragma unroll
@@ -354,10 +432,8 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
       rt.c[J] = 0.25 * sum_kq(pa + pb);
       rb.c[J] = 0.25 * sum_kq(pa - pb);
     }
-    if (kq == 0)
-#pragma unroll
-      for (int J = 0; J < T; ++J) ws[Ws<NP>::RB + 16 * J + col] = rb.c[J];
-    const Col e0c = load_col(Ek + l * NP, col);
+    RTD_T2STAMP(6)  // carry: vectors of the interface, rho
+    const Col e0c = below_in_lds ? vec_col(VE, col) : load_col(Ek + l * NP, col);
     Col tnew;
     {
       const Col srb = col_dotT<T>(tb, col_to_rowT<T>(rb, rowbase, kq));
@@ -370,17 +446,28 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
       for (int J = 0; J < T; ++J)
 #pragma unroll
         for (int q = 0; q < 4; ++q) tb.t[I][J][q] *= e0c.c[J];
-    Mat s1;  // X + M1^T,  X = M1^T H E
+    // X + M1^T = M1^T (H E + I) and Z - M2s^T = M2s^T (H E - I): the unit matrix goes onto the diagonal of H E before each product
+    // (eight selects and adds), so that neither M1^T nor M2s^T is ever formed -- no transposed copy through LDS (two round trips and
+    // six barriers per layer), and the 8 KB of LDS they went through are free in the forward sweep
+    auto add_to_diagonal = [&](Mat& x, const double v) {
+#pragma unroll
+      for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x.t[I][I][q] += (4 * q + kq == col) ? v : 0.0;
+    };
+    RTD_T2STAMP(7)  // carry: t', H E
+    Mat s1;  // M1^T (H E + I)
     {
-      const Mat y1 = load_d(Ym + (long)(l + 1) * NN, kq, col);
+      const Mat y1 = below_in_lds ? lds_d(0, kq, col) : load_d(Ym + (long)(l + 1) * NN, kq, col);
       const Mat m1 = mmT<T>(a0, y1);
+      add_to_diagonal(tb, 1.0);
       s1 = mmT<T>(m1, tb);
-      add_transposed(s1, m1, 1.0, kq, col);
     }
-    Mat dd;  // Z - M2s^T,  Z = M2s^T H E
+    RTD_T2STAMP(8)  // carry: M1, M1^T (H E + I)
+    Mat dd;  // M2s^T (H E - I)
     {
-      Mat a1s = load_d(Am + (long)(l + 1) * NN, kq, col);
-      const Col k1c = load_col(kk + (l + 1) * NP, col);
+      Mat a1s = below_in_lds ? lds_d(1, kq, col) : load_d(Am + (long)(l + 1) * NN, kq, col);
+      const Col k1c = below_in_lds ? vec_col(VK + NP, col) : load_col(kk + (l + 1) * NP, col);
 #pragma unroll
       for (int J = 0; J < T; ++J) {
         const double rk1 = fast_rcp(k1c.c[J]);
@@ -390,10 +477,11 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
           for (int q = 0; q < 4; ++q) a1s.t[I][J][q] *= rk1;
       }
       const Mat m2s = mmT<T>(y0s, a1s);
+      add_to_diagonal(tb, -2.0);
       dd = mmT<T>(m2s, tb);
-      add_transposed(dd, m2s, -1.0, kq, col);
     }
-    const Row e1r = load_row(Ek + (l + 1) * NP, kq);
+    RTD_T2STAMP(9)  // carry: M2s, M2s^T (H E - I)
+    const Row e1r = below_in_lds ? vec_row(VE + NP, kq) : load_row(Ek + (l + 1) * NP, kq);
 #pragma unroll
     for (int I = 0; I < T; ++I)
 #pragma unroll
@@ -404,6 +492,10 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
           tb.t[I][J][q] = -0.5 * (s1.t[I][J][q] + dd.t[I][J][q]) * e1r.r[I][q];
         }
     tv = tnew;
+    // (stored last: a store ahead of the operand reads above would put its acknowledgement in front of them)
+    if (kq == 0)
+#pragma unroll
+      for (int J = 0; J < T; ++J) ws[Ws<NP>::RB + 16 * J + col] = rb.c[J];
   };
 
   // One call site for each producer (they are large: instruction cache): the loop asks for the inputs of layer l's elimination,
@@ -415,18 +507,30 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
     int l = 0;
     int produce = -1;  // -1: the top boundary rows; >= 0: the carry across that interface (tb, tv hold H, s of the layer above it)
     bool pivot_now = careful != 0;
-    Mat pa, py;             // A_l, Y_l for the carry across interface l: requested BEFORE the elimination of layer l (its 68 registers
-    bool have_pre = false;  // leave room), so that two of a layer's four matrix requests are hidden behind it
+    Mat pa, py;             // A_l, Y_l for the carry across interface l: in registers BEFORE the elimination of layer l (its 68 registers
+    bool have_pre = false;  // leave room) -- from the layer buffers, where the carry across interface l - 1 has left them
+    int in_lds = -1;        // the layer whose Y, A the layer buffers hold (or are being filled with)
     for (;;) {
       if (produce < 0) top_rows(ta, tb, tv);
-      else carry(produce, ta, tb, tv, pa, py, have_pre);
+      else carry(produce, ta, tb, tv, pa, py, have_pre, in_lds == produce + 1);
+      RTD_T2STAMP(0)  // producer: top rows / carry
       const int lv = opaque_lane(), kq = lv >> 4, col = lv & 15, rowbase = lv & 48;
-      {
-        const int lp = min(l, max(Lm1 - 1, 0));  // (unconditional requests: past the last interface they repeat it)
-        pa = load_d(Am + (long)lp * NN, kq, col);
-        py = load_d(Ym + (long)lp * NN, kq, col);
+      if (l < Lm1) {  // (wave-uniform) the operands of the carry across interface l, which follows this elimination
+        if (in_lds == l) {
+          pa = lds_d(1, kq, col);
+          py = lds_d(0, kq, col);
+          __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): they have left the buffers ...
+        } else {  // first layer, or a repeated carry
+          pa = load_d(Am + (long)l * NN, kq, col);
+          py = load_d(Ym + (long)l * NN, kq, col);
+        }
         have_pre = true;
+        if (in_lds != l + 1) {  // ... which take the layer below while the elimination runs
+          prefetch_layer(l + 1, lv);
+          in_lds = l + 1;
+        }
       }
+      RTD_T2STAMP(1)  // operands into registers, DMA issued
       // ---- elimination: [Ta^T ; Tb^T ; t^T] -> H = S^T (in tb), s (in tv)
       if (!pivot_now) {
         int bad = 0;
@@ -453,22 +557,11 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
         }
       }
       pivot_now = careful != 0;
+      RTD_T2STAMP(2)  // elimination
       if (l == Lm1) break;
-      // (loads and stores share one in-order counter: the requests above are waited for HERE, then the stores go out and have
-      //  the whole carry to complete -- see rtd_bc_mfma_kernel)
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      double* ws = wsb + (long)l * Ws<NP>::SLOT;
-#pragma unroll
-      for (int I = 0; I < T; ++I)
-#pragma unroll
-        for (int J = 0; J < T; ++J)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) ws[Ws<NP>::S + (16 * I + 4 * q + kq) * NP + 16 * J + col] = tb.t[I][J][q];
-      if (kq == 0)
-#pragma unroll
-        for (int J = 0; J < T; ++J) ws[Ws<NP>::SV + 16 * J + col] = tv.c[J];
       produce = l;
       ++l;
+      RTD_T2STAMP(3)  // wait for the requests + stores of H, s
     }
   }
 
@@ -611,10 +704,12 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
   //      layer), and they ARE the intensity at the top of that layer (see rtd_bc_mfma_kernel): with the fused evaluation (d.um)
   //      a slot of the staging area also takes u^m there.  The coefficients and u^m leave as full-width stores every NSLOT
   //      layers -- a store inside the sweep would turn every wait for an operand into a wait for that store's acknowledgement.
+  RTD_T2STAMP(4)  // bottom boundary
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // (no LDS-DMA of the forward sweep may still be on its way into what is the staging area now)
   double* um = d.um ? d.um + cm * (L + 1) * Q : nullptr;
   constexpr int SLOTW = 2 * Q;  // [C-, C+ | u^m up, down]
   constexpr int NSLOT = (NP * LDM) / SLOTW;
-  double* const sOut = sX;
+  double* const sOut = sBuf;
   int nstage = 0, ltop = L;  // slot s holds the rows of layer / interface ltop - s (row L: u^m only)
   auto flush = [&]() {
     __syncthreads();
@@ -768,6 +863,12 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
     stage(kq, col, pu, pd);
   }
   flush();
+  RTD_T2STAMP(5)  // backward sweep
+#ifdef RTD_T2_STAMPS
+  if (lane == 0 && cm % 1021 == 0)
+    printf("T2STAMP np 32 m %d sweeps 0 : carry_rho %lld carry_tHE %lld carry_M1 %lld carry_M2 %lld carry_rest %lld operands %lld elimination %lld stores %lld bottom %lld backward %lld total %lld\n", mg,
+           t2acc[6], t2acc[7], t2acc[8], t2acc[9], t2acc[0], t2acc[1], t2acc[2], t2acc[3], t2acc[4], t2acc[5], (long long)__builtin_amdgcn_s_memtime() - t2start);
+#endif
   double chk = 0.0;
 #pragma unroll
   for (int J = 0; J < T; ++J) chk += fabs(cminus.c[J]) + fabs(cplus.c[J]);

@@ -8,10 +8,12 @@ import sys
 
 rows = collections.defaultdict(list)
 for line in sys.stdin:
-    if not line.startswith("EIGSTAMP"):
+    if not line.startswith(("EIGSTAMP", "T2STAMP")):
         continue
-    np_ = int(re.search(r"np (\d+)", line).group(1))
-    sweeps = int(re.search(r"sweeps (\d+)", line).group(1))
+    m_np, m_sw = re.search(r"np (\d+)", line), re.search(r"sweeps (\d+)", line)
+    if not (m_np and m_sw and ":" in line):  # (interleaved device printf output)
+        continue
+    np_, sweeps = int(m_np.group(1)), int(m_sw.group(1))
     vals = {k: int(v) for k, v in re.findall(r"(\S+) (-?\d+)", line.split(":", 1)[1])}
     vals["sweeps"] = sweeps
     if "total" in vals:  # (device printf output of concurrent wavefronts can interleave: incomplete lines are dropped)
