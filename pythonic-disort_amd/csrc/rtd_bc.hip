@@ -1008,40 +1008,28 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
       for (int q = 0; q < 4; ++q) he[q] = tb[q] * e0c;
       const v4f64 hcur = {tb[0], tb[1], tb[2], tb[3]};
       const double tnew = rt - e0c * (tv - col_dot(hcur, col_to_row(rb, rowbase, kq)));  // t' = rho_t - E (s - S rho_b)
-      // The transposes M1^T = Y'^T A_l and M2s^T come through LDS (the save area is free once the elimination is over), not
-      // from a second MFMA chain: FP64 MFMAs and FP64 vector instructions share the DP ALUs on gfx950
-      // (tools/hiptests/dp_coissue.hip), so the 8 MFMAs were 512 cycles of the very resource the kernel is short of.
-#ifndef RTD_BC_LDS_TRANSPOSE
-#define RTD_BC_LDS_TRANSPOSE 1
-#endif
-      auto transposed = [&](const v4f64& mm, const v4f64& x, const v4f64& y) -> v4f64 {  // mm = x^T y  ->  y^T x
-        if constexpr (!RTD_BC_LDS_TRANSPOSE) return mm_t(y, x);
-        double* const sT17 = &sSaveFlat[0];  // 16 rows of 17 doubles
-        __syncthreads();
+      // X + M1^T = M1^T (H E + I) and Z - M2s^T = M2s^T (H E - I): the unit matrix goes onto the diagonal of H E before each product,
+      // so that neither transpose is ever formed -- not by a second MFMA chain (FP64 MFMAs and FP64 vector instructions share the DP
+      // ALUs on gfx950, tools/hiptests/dp_coissue.hip: 8 MFMAs were 512 cycles of the very resource the kernel is short of), and not
+      // through LDS either (rounds 3-4: two round trips on the chain's critical path per layer)
+      v4f64 hep, hem;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sT17[(4 * q + kq) * 17 + col] = mm[q];
-        __syncthreads();
-        v4f64 t;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) t[q] = sT17[col * 17 + 4 * q + kq];
-        __syncthreads();
-        return t;
-      };
-      v4f64 s1;  // X + M1^T
+      for (int q = 0; q < 4; ++q) {
+        const double one = (4 * q + kq == col) ? 1.0 : 0.0;
+        hep[q] = he[q] + one;
+        hem[q] = he[q] - one;
+      }
+      v4f64 s1;  // M1^T (H E + I)
       {
         const v4f64 m1 = mm_t(a0, y1);
-        const v4f64 xx = mm_t(m1, he);
-        const v4f64 m1t = transposed(m1, a0, y1);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s1[q] = xx[q] + m1t[q];
+        s1 = mm_t(m1, hep);
       }
       {
         const v4f64 m2s = mm_t(y0, a1s);
-        const v4f64 zz = mm_t(m2s, he);
-        const v4f64 m2st = transposed(m2s, y0, a1s);
+        const v4f64 dd4 = mm_t(m2s, hem);  // M2s^T (H E - I)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const double dd = zz[q] - m2st[q];
+          const double dd = dd4[q];
           ta[q] = -0.5 * (s1[q] - dd);
           tb[q] = -0.5 * (s1[q] + dd) * e1r_g[q];
         }

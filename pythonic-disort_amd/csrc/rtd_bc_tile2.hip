@@ -155,7 +155,6 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
   // ... and the vectors of the interface below it, by the same route: [B_l, B_(l+1) | v_l bottom, v_(l+1) top | k_l, k_(l+1), E_l, E_(l+1)]
   __shared__ double sVec[4 * Q + 2 * Q];
   constexpr int VB = 0, VV = 2 * Q, VK = 4 * Q, VE = 4 * Q + 2 * NP;
-  static_assert(2 * NN >= NP * LDM, "the staging area of the backward sweep lives in the forward sweep's layer buffers");
   // (kq, col are passed in: the callers hand over an opaque copy of the lane index, so that the compiler rebuilds the few
   //  address registers where they are needed instead of keeping dozens of hoisted ones alive)
   auto load_d = [](const double* p, const int kq, const int col) {  // row-major NP x NP matrix -> tiles in the D layout
@@ -179,18 +178,7 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
     return x;
   };
   // Y and A of `layer` into the layer buffers: 16 wave-instructions of 1 KB (lane: 16 bytes), in flight behind whatever follows
-  auto prefetch_layer = [&](const int layer, const int lv) {
-    {  // the vectors of interface layer - 1: three instructions
-      const int l = layer - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bv + l * Q + 2 * lv),
-                                       (__attribute__((address_space(3))) void*)(sVec + VB), 16, 0, 0);
-      if (iso)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbp + (l * 4 + 2) * NP + 2 * lv),
-                                         (__attribute__((address_space(3))) void*)(sVec + VV), 16, 0, 0);
-      const double* ke = (lv < 32 ? kk + l * NP : Ek + l * NP - 2 * NP) + 2 * lv;  // lanes 0-31: k_l, k_(l+1); lanes 32-63: E_l, E_(l+1)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ke,
-                                       (__attribute__((address_space(3))) void*)(sVec + VK), 16, 0, 0);
-    }
+  auto dma_matrices = [&](const int layer, const int lv) {
     const double* gy = Ym + (long)layer * NN + 2 * lv;
     const double* ga = Am + (long)layer * NN + 2 * lv;
 #pragma unroll
@@ -200,6 +188,19 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + 128 * i),
                                        (__attribute__((address_space(3))) void*)(sBuf + NN + 128 * i), 16, 0, 0);
     }
+  };
+  // forward sweep: the layer below interface layer - 1, and that interface's vectors (three more instructions)
+  auto prefetch_layer = [&](const int layer, const int lv) {
+    const int l = layer - 1;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bv + l * Q + 2 * lv),
+                                     (__attribute__((address_space(3))) void*)(sVec + VB), 16, 0, 0);
+    if (iso)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbp + (l * 4 + 2) * NP + 2 * lv),
+                                       (__attribute__((address_space(3))) void*)(sVec + VV), 16, 0, 0);
+    const double* ke = (lv < 32 ? kk + l * NP : Ek + l * NP - 2 * NP) + 2 * lv;  // lanes 0-31: k_l, k_(l+1); lanes 32-63: E_l, E_(l+1)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ke,
+                                     (__attribute__((address_space(3))) void*)(sVec + VK), 16, 0, 0);
+    dma_matrices(layer, lv);
   };
   auto vec_row = [&](const int off, const int kq) {  // a vector of the interface from sVec, row form
     Row x;
@@ -702,14 +703,15 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
   //      Wq x + Wp y = [A_l^T Y' (x + y) + k_l Y_l^T A' ((y - x)/k')] / 2:  the row sums  w1 = Y' (C-' + E' C+'),
   //      w2 = A' (E' C+' - C-') / k'  of the layer below are carried from step to step (a step touches the operands of ONE
   //      layer), and they ARE the intensity at the top of that layer (see rtd_bc_mfma_kernel): with the fused evaluation (d.um)
-  //      a slot of the staging area also takes u^m there.  The coefficients and u^m leave as full-width stores every NSLOT
-  //      layers -- a store inside the sweep would turn every wait for an operand into a wait for that store's acknowledgement.
+  //      a slot of the staging area also takes u^m there.  The operands of step l are requested while step l + 1 computes: Y_l, A_l
+  //      by LDS-DMA into the layer buffers, H_l and the step's vectors into registers.  The coefficients and u^m leave as full-width
+  //      stores every NSLOT layers, at the top of a step, AHEAD of that step's requests: the wait of the next step is then a step old.
   RTD_T2STAMP(4)  // bottom boundary
   __builtin_amdgcn_s_waitcnt(0x0F70);  // (no LDS-DMA of the forward sweep may still be on its way into what is the staging area now)
   double* um = d.um ? d.um + cm * (L + 1) * Q : nullptr;
   constexpr int SLOTW = 2 * Q;  // [C-, C+ | u^m up, down]
-  constexpr int NSLOT = (NP * LDM) / SLOTW;
-  double* const sOut = sBuf;
+  constexpr int NSLOT = (4 * Q + 2 * Q) / SLOTW;  // (the staging area is the forward sweep's sVec)
+  double* const sOut = sVec;
   int nstage = 0, ltop = L;  // slot s holds the rows of layer / interface ltop - s (row L: u^m only)
   auto flush = [&]() {
     __syncthreads();
@@ -725,8 +727,7 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
         }
       }
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the slots are free (the stores themselves are not waited for)
     ltop -= nstage;
     nstage = 0;
   };
@@ -789,6 +790,20 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
     w1 = row_dotT<T>(yl, xpy);
     w2 = row_dotT<T>(al, ymx);
   };
+  Mat hN;
+  Col rbvN, klN, slN, elN;
+  double puN = 0.0, pdN = 0.0;
+  auto request = [&](const int l, const int lv) {  // the operands of step l
+    const int kq = lv >> 4, col = lv & 15;
+    const double* ws = wsb + (long)l * Ws<NP>::SLOT;
+    dma_matrices(l, lv);
+    hN = load_d(ws + Ws<NP>::S, kq, col);
+    rbvN = load_col(ws + Ws<NP>::RB, col);
+    klN = load_col(kk + l * NP, col);
+    slN = load_col(ws + Ws<NP>::SV, col);
+    elN = load_col(Ek + l * NP, col);
+    psol_top(l, kq, col, puN, pdN);
+  };
   {
     const int lv = opaque_lane(), kq = lv >> 4, col = lv & 15;
     const Mat yL = load_d(Ym + (long)Lm1 * NN, kq, col), aL = load_d(Am + (long)Lm1 * NN, kq, col);
@@ -831,23 +846,20 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
     row_sums(yL, aL, kL, eL);
     double pu, pd;
     psol_top(Lm1, kq, col, pu, pd);
+    if (Lm1 > 0) request(Lm1 - 1, opaque_lane());
     stage(kq, col, pu, pd);
   }
   for (int l = Lm1 - 1; l >= 0; --l) {
     const int lv = opaque_lane(), kq = lv >> 4, col = lv & 15, rowbase = lv & 48;
-    const double* ws = wsb + (long)l * Ws<NP>::SLOT;
-    double pu, pd;
-    psol_top(l, kq, col, pu, pd);
-    const Col rbv = load_col(ws + Ws<NP>::RB, col), kl = load_col(kk + l * NP, col), sl = load_col(ws + Ws<NP>::SV, col);
-    const Col el = load_col(Ek + l * NP, col);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // what the step before has requested for this one
+    const Mat al = lds_d(1, kq, col), yl = lds_d(0, kq, col), h = hN;
+    const Col rbv = rbvN, kl = klN, sl = slN, el = elN;
+    const double pu = puN, pd = pdN;
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): Y_l, A_l have left the layer buffers
+    if (nstage == NSLOT) flush();
+    if (l > 0) request(l - 1, lv);
     Col cp;
     {
-      // (the three operand matrices of the step are requested together: one memory latency per step, not three; 96 of the 256
-      //  registers, and little else is live in this loop)
-      const Mat al = load_d(Am + (long)l * NN, kq, col);
-      const Mat yl = load_d(Ym + (long)l * NN, kq, col);
-      const Mat h = load_d(ws + Ws<NP>::S, kq, col);
-      __builtin_amdgcn_sched_barrier(0);
       const Col t1 = col_dotT<T>(al, w1);
       const Col t2 = col_dotT<T>(yl, w2);
 #pragma unroll
