@@ -8,13 +8,17 @@
 //   VGPRs), the inputs of the running elimination in a 17 KB LDS save area (read back only when the speculation fails) and the
 //   chain's small vectors in an 18 KB LDS window: ONE wavefront per SIMD, whose dependency stalls nothing hides (VALU issue
 //   30 % + matrix pipe 22 % of the SIMD cycles, profiles/r03_pmc_traffic_cfg5.json), and no room for an eigen-stage wavefront
-//   of the next window beside it.  Here every operand matrix is requested where it is used and dies there (each layer is read
-//   twice in the forward sweep, the second time from the L2 / the Infinity Cache), nothing is prefetched across an
-//   elimination, the small vectors come straight from memory, and a failed speculation RECOMPUTES its inputs -- from the H, s
-//   of the layer above, which the forward sweep stores anyway -- and eliminates them again with column pivoting IN REGISTERS
-//   (GjPivT): no save area.  <= 256 VGPRs and 9 KB of LDS: two chains per SIMD hide each other's stalls, and the chains that
-//   are pivoted throughout (near-conservative mode 0: chain_needs_pivoting) cost 1.3 x instead of 10 x.
-//   The memory latency a wavefront now sees (six exposed requests per layer) is what the second wavefront is there for.
+//   of the next window beside it.  Here no operand matrix lives across an elimination in more than 64 registers, and a failed
+//   speculation RECOMPUTES its inputs -- from the H, s of the layer above, which the forward sweep stores anyway -- and eliminates
+//   them again with column pivoting IN REGISTERS (GjPivT): no save area.  <= 256 VGPRs and 20 KB of LDS: two chains per SIMD
+//   hide each other's stalls, and the chains that are pivoted throughout (near-conservative mode 0: chain_needs_pivoting) cost
+//   1.3 x instead of 10 x.
+//   End of round 5 (profiles/r05_bc_tile2_phases.txt): what the carry across an interface reads -- Y, A of the layer below and the
+//   interface's vectors -- arrives by LDS-DMA (global_load_lds_dwordx4: no registers, no wait) while the elimination above runs;
+//   the carry's only wait finds requests that are an elimination old, H and s are stored BEHIND it (loads, stores and the DMA share
+//   one in-order counter: the ~80 vector loads that used to follow the stores each waited for a store's acknowledgement), and the
+//   next carry takes its own layer's Y, A from the same LDS images: every matrix is fetched once per forward sweep.  The backward
+//   sweep requests a step ahead in the same way.
 //
 // rtd_bc_tile_kernel<2> stays selectable (RTD_BC_TILE_V1=1: A/B runs, and the suite passes under it).
 #include <cstdlib>
@@ -353,14 +357,12 @@ __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need
     // the forward sweep ever waits for a store's acknowledgement (which cost 12 k cycles per layer when the stores went first).
     __builtin_amdgcn_s_waitcnt(0x0F70);
     if (have) {  // (a repeated carry has reloaded them from there)
-#ifndef RTD_T2_NO_STORES_EXPERIMENT  /* timing experiment only: the results are wrong without H */
 #pragma unroll
       for (int I = 0; I < T; ++I)
 #pragma unroll
         for (int J = 0; J < T; ++J)
 #pragma unroll
           for (int q = 0; q < 4; ++q) ws[Ws<NP>::S + (16 * I + 4 * q + kq) * NP + 16 * J + col] = tb.t[I][J][q];
-#endif
       if (kq == 0)
 #pragma unroll
         for (int J = 0; J < T; ++J) ws[Ws<NP>::SV + 16 * J + col] = tv.c[J];
