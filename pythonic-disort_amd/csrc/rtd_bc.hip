@@ -657,7 +657,7 @@ struct GjPiv {
 __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
   constexpr int NP = 16, Q = 32, NN = NP * NP;
   const int lane = threadIdx.x, kq = lane >> 4, col = lane & 15, rowbase = lane & 48;
-  const long cm = blockIdx.x;
+  const long cm = chain_of_block(blockIdx.x, d.C, d.M);
   const int m = (int)(cm % d.M), c = (int)(cm / d.M);
   const int L = d.L, Lm1 = L - 1;
 #ifdef RTD_BC_ALIAS_EXPERIMENT
@@ -1357,7 +1357,7 @@ template <int T>
 __global__ __launch_bounds__(64, (T == 1 ? 2 : 1)) void rtd_bc_tile_kernel(RtdDev d, int* need_split) {
   constexpr int NP = 16 * T, Q = 2 * NP, NN = NP * NP;
   const int lane = threadIdx.x, kq = lane >> 4, col = lane & 15, rowbase = lane & 48;
-  const long cm = blockIdx.x;
+  const long cm = chain_of_block(blockIdx.x, d.C, d.M);
   const int m = (int)(cm % d.M), c = (int)(cm / d.M);
   const int L = d.L, Lm1 = L - 1;
   const double* Ym = d.Ym + cm * L * NN;

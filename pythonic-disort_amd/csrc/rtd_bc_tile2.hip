@@ -119,7 +119,7 @@ struct GjPivT {
 __global__ __launch_bounds__(64, 2) void rtd_bc_tile2_kernel(RtdDev d, int* need_split) {
   constexpr int T = T2, NP = NP2, Q = Q2, NN = NN2;
   const int lane = threadIdx.x, kq = lane >> 4, col = lane & 15, rowbase = lane & 48;
-  const long cm = blockIdx.x;
+  const long cm = chain_of_block(blockIdx.x, d.C, d.M);
   const int m = (int)(cm % d.M), c = (int)(cm / d.M);
   const int L = d.L, Lm1 = L - 1;
 #ifdef RTD_T2_STAMPS

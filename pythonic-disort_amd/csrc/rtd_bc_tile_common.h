@@ -81,6 +81,17 @@ __device__ __forceinline__ double readlane_f64(const double v, const int lane_un
                                        batch with a conservative cloud layer in every column; with GjPiv (registers) it is the default.
                                        The tiled 64-stream kernel keeps the thermal-only rule (its pivoted path is the LDS redo). */
 #endif
+// Which chain (column c, local mode m: index c M + m) a workgroup takes.  Mode 0 of every column first, then the other modes column
+// by column: the chains that are pivoted throughout (above: mode 0 only) take 3 ... 7 times as long as the others, and handed out in
+// index order the last of them started when three quarters of the launch were over -- a batch with a conservative cloud layer in
+// every column spent a third of its boundary-condition kernel waiting for 1/32 of its chains (0.80 against 0.53 ms per 256 cfg4 columns).
+// Longest first costs nothing where mode 0 is a chain like the others.
+__device__ __forceinline__ long chain_of_block(const long b, const int C, const int M) {
+  if (M == 1 || b < C) return b * M;
+  const long r = b - C;
+  return (r / (M - 1)) * M + 1 + r % (M - 1);
+}
+
 __device__ __forceinline__ int chain_needs_pivoting(const RtdDev& d, const bool iso, const double* kk, const int L, const int np) {
   int careful = 0;
   if (iso) {  // (wave-uniform condition: one chain per wavefront.  The scan is lane-parallel -- one memory latency, then a wave

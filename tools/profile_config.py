@@ -15,7 +15,8 @@ from pydisort_amd import synthetic  # noqa: E402
 
 name, C, window, passes = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 maker, kw = {"cfg3_small": (synthetic.cfg3_columns, dict(big=False)), "cfg3_big": (synthetic.cfg3_columns, dict(big=True)),
-             "cfg4": (synthetic.cfg4_columns_block, {}), "cfg5": (synthetic.cfg5_columns, {})}[name]
+             "cfg4": (synthetic.cfg4_columns_block, {}), "cfg5": (synthetic.cfg5_columns, {}),
+             "cfg4_cloud": (synthetic.cfg4_cloud_columns, {})}[name]  # (cfg4_cloud: a layer with omega = 1 - 1e-6 in every column)
 cfg = maker(C, **kw)
 _, sol = pydisort_amd.pydisort_batch(work_columns=window, _defer_solve=True, **cfg)
 plan = sol.plan
