@@ -450,12 +450,21 @@ __device__ __forceinline__ ProbId locate(const RtdDev& d, const int tx = threadI
   constexpr int GPW = 64 / NP;
   // layer shard (rtd_plan_solve_layers): only the layers [l0, l0 + ln) are decomposed; ln = L without shards
   const int nchunk = (d.ln + GPW - 1) / GPW;
-  const long cmi = (long)blockIdx.x / nchunk;
+  const long cmi_b = (long)blockIdx.x / nchunk;
   const int chunk = (int)((long)blockIdx.x % nchunk);
   ProbId p;
-  p.m = (int)(cmi % d.M);
+  // Workgroups are handed out mode by mode (all columns of mode 0, then of mode 1, ...): the sweep count falls with the Fourier mode
+  // (5.8 sweeps at m = 0, 1.8 at m = 31 on cfg4), so the longest problems start first and the launch ends on its shortest ones
+  // instead of on the last column's mode 0; the mode's table rows are shared by everything that runs at the same time.
+#ifdef RTD_EIG_COLUMN_MAJOR  /* A/B builds: the order of rounds 1-5 */
+  p.m = (int)(cmi_b % d.M);
+  p.c = (int)(cmi_b / d.M);
+#else
+  p.m = (int)(cmi_b / d.C);
+  p.c = (int)(cmi_b % d.C);
+#endif
   p.mg = d.m0 + d.mstep * p.m;
-  p.c = (int)(cmi / d.M);
+  const long cmi = (long)p.c * d.M + p.m;
   const int slot = chunk * GPW + tx / NP;
   p.valid = slot < d.ln;
   const int sl = p.valid ? slot : d.ln - 1;  // invalid groups redo the last slot and skip the stores
@@ -734,7 +743,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
   // kernel's own stores leave them alone) that waited for those stores' acknowledgements: loads and stores share one in-order counter.
   double mu0_c = 1.0, I0_c = 0.0;
   if (d.beam) {
-    const int c0 = (int)(((long)blockIdx.x / ((d.ln + GPW - 1) / GPW)) / d.M);  // as locate()
+    const int c0 = locate<NP>(d).c;
     mu0_c = d.mu0[c0];
     I0_c = d.I0[c0];
   }
