@@ -3,7 +3,7 @@
 note records of the offload bundle), written to profiles/<round>_kernel_resources.json.  Comments and DESIGN.md quote these
 numbers: regenerate the file after every build that changes a kernel instead of editing the numbers by hand.
 
-Usage: python tools/kernel_resources.py [--out profiles/r04_kernel_resources.json]
+Usage: python tools/kernel_resources.py [--out profiles/rNN_kernel_resources.json]   (without --out: prints only)
 """
 import argparse
 import json
@@ -68,15 +68,16 @@ def waves_per_simd(rec):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default=os.path.join(ROOT, "pythonic-disort_amd", "pydisort_amd", "librtd.so"))
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_kernel_resources.json"))
+    ap.add_argument("--out", default=None, help="also write the figures as JSON there (default: print only)")
     a = ap.parse_args()
     ks = kernels_of(a.lib)
     for rec in ks.values():
         rec["waves_per_simd_by_registers"] = waves_per_simd(rec)
     doc = {"source": "AMDGPU code-object metadata (llvm-readelf --notes) of " + os.path.relpath(a.lib, ROOT),
            "tool": "tools/kernel_resources.py", "kernels": dict(sorted(ks.items()))}
-    with open(a.out, "w") as f:
-        json.dump(doc, f, indent=1)
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump(doc, f, indent=1)
     for n, r in sorted(ks.items()):
         print(f"{r.get('vgpr_count', 0):4d} vgpr {r.get('agpr_count', 0):4d} agpr {r.get('vgpr_spill_count', 0):4d} vspill "
               f"{r.get('sgpr_spill_count', 0):4d} sspill {r.get('group_segment_fixed_size', 0):6d} lds  {n[:110]}")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the time of a one-column pydisort() call goes (Test Problem 9c): wall-clock spans of the host stages and of every
+"""Where the time of a one-column pydisort() call goes (Test Problem 9c by default; any golden test id as argument): wall-clock spans of the host stages and of every
 C-ABI call, median over 200 calls (run on the GPU box)."""
 import os, sys, time, warnings, collections
 import numpy as np
@@ -10,7 +10,8 @@ import importlib
 from pydisort_amd import _engine, _prepare, _lib
 P = importlib.import_module("pydisort_amd.pydisort")
 warnings.simplefilter("ignore")
-kw = goldens.load("9c")[0]["kwargs"]
+TID = sys.argv[1] if len(sys.argv) > 1 else "9c"  # a golden test id: 9c (6 layers, 8 streams), 5a (Cloud C.1, 48 streams, NT corrections), ...
+kw = goldens.load(TID)[0]["kwargs"]
 spans = collections.defaultdict(list)
 
 
