@@ -1184,6 +1184,13 @@ def run_rank(a, rank, world, local):
                                       "profiles/r05_pmc_traffic.json (committed passes)")
             if live_main:
                 roof["traffic_all_kernels_per_window"] = float(sum(live_main.values()))
+                ok_ = roof.get("other_kernel")
+                if ok_ and ok_.get("kernel") in live_main and ok_.get("ms_per_launch"):
+                    # the second kernel of the step against ITS roofline: it moves its bytes at a rate near what the memory system gives
+                    # (MI355X_MICROARCH.md: 6.29 TB/s attainable of the 8 TB/s peak) while its FP64 units are a quarter busy
+                    rate = live_main[ok_["kernel"]] / (ok_["ms_per_launch"] * 1e-3) / 1e12
+                    ok_.update(hbm_bytes_per_launch=live_main[ok_["kernel"]], hbm_TB_per_s=rate, hbm_frac_of_8_TB_per_s=rate / 8.0,
+                               bound="hbm + latency of its dependent chains: see DESIGN.md section 4")
             roof["launches_per_step"] = nwin
             roof["whole_path_tflops"] = fl["total"] * value / world / 1e12
             roof["whole_path_frac"] = fl["total"] * value / world / 1e12 / FP64_PEAK_TFLOPS
