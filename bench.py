@@ -904,6 +904,9 @@ def run_rank(a, rank, world, local):
     plan = None
     cfg = None
     mine = {"rank": rank, "local_rank": local, "pid": os.getpid(), "columns": C}  # this rank's own timings: where a poor curve comes from
+    shared_gpu = bool(os.environ.get("RTD_RCCL_STUB")) and multi
+    dev = local
+    transport = None
     if not stub:
         phase("generate inputs")
         from pydisort_amd import synthetic
@@ -911,7 +914,12 @@ def run_rank(a, rank, world, local):
         from pydisort_amd._engine import Plan
         from pydisort_amd._prepare import prepare_columns
         ndev = _engine.device_count()  # hipGetDeviceCount: does not initialise a device
-        if ndev <= local:
+        if shared_gpu:
+            # RTD_RCCL_STUB (tests only): every rank process on device 0 over the tests' stand-in transport -- RCCL refuses two
+            # ranks on one GPU, and this is how the rank > 0 code of the data plane executes on a one-GPU box.  NOT a scaling run.
+            dev = 0
+            mine["device"] = 0
+        elif ndev <= local:
             print(f"[bench] rank {rank}: LOCAL_RANK {local} but only {ndev} HIP device(s) visible: one rank per GPU is the "
                   "contract (check ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES and --gpus)", file=sys.stderr)
             sys.stderr.flush()
@@ -926,7 +934,7 @@ def run_rank(a, rank, world, local):
             Plan.comm_preload()  # RCCL from the ROCm install, bound to librtd's HIP runtime (the only one in this process)
         phase("create plan, upload inputs")
         t0 = time.perf_counter()
-        plan = Plan(prep, device=local, work_columns=a.columns)  # uploads: inputs now resident in HBM
+        plan = Plan(prep, device=dev, work_columns=a.columns)  # uploads: inputs now resident in HBM
         tau = np.concatenate((np.zeros((C, 1)), cfg["tau_arr"]), axis=1)
         plan.set_eval_points(tau, np.array([0.0, np.pi / 2, np.pi]))
         plan.synchronize()
@@ -984,6 +992,10 @@ def run_rank(a, rank, world, local):
                     plan.comm_init(uid, rank, world)
                     mine["rccl_comm_init_s"] = time.perf_counter() - t0
                     rccl_says = plan.comm_size()  # ncclCommCount / ncclCommUserRank / ncclCommCuDevice: RCCL's own statement
+                    transport = plan.comm_transport()  # "rccl", or "stub:..." under RTD_RCCL_STUB
+                    mine["transport"] = transport
+                    if shared_gpu != transport.startswith("stub"):
+                        raise RuntimeError(f"transport is {transport!r} with RTD_RCCL_STUB {'set' if shared_gpu else 'unset'}")
                     mine["rccl_nranks"], mine["rccl_rank"], mine["rccl_device"] = rccl_says
                     if rccl_says[0] != world or rccl_says[1] != rank:
                         raise RuntimeError(f"RCCL reports rank {rccl_says[1]} of {rccl_says[0]}, launched as rank {rank} of {world}")
@@ -1087,7 +1099,7 @@ def run_rank(a, rank, world, local):
             phase("verify the gathered arrays against local solves")
             if holds:
                 try:
-                    ok, nver, detail = verify_gathered(plan, local, world, a.columns, a.total_columns)
+                    ok, nver, detail = verify_gathered(plan, dev, world, a.columns, a.total_columns)
                 except Exception as e:
                     ok, detail = False, repr(e)
                 if not ok:
@@ -1124,7 +1136,7 @@ def run_rank(a, rank, world, local):
     if rank == 0 and world == 1 and not a.no_extras and not stub:
         plan.close()  # the extras build their own plans: give the arena back first
         plan = None
-        extras = extra_measurements(local, cfg if strong else None, a.columns, live)
+        extras = extra_measurements(dev, cfg if strong else None, a.columns, live)
     if rank == 0:
         value = total_cols * a.steps / elapsed
         out = {
@@ -1153,6 +1165,15 @@ def run_rank(a, rank, world, local):
             out["gather_verification"] = verified
         elif multi and not stub:
             out["config"].update(gather_verified=None, ranks_verified=0)  # --gather none: nothing is gathered
+        if multi and not stub:
+            out["transport"] = transport  # what carried the collectives: "rccl" -- or the tests' stand-in
+            if shared_gpu:
+                out["devices_used"] = 1
+                out["not_a_rate"] = True
+                out["transport_note"] = ("RTD_RCCL_STUB: every rank process ran on device 0 over the tests' stand-in for RCCL (tests/stub/"
+                                         "rccl_stub.cpp: hipIpc / shared memory, host-synchronous).  This line proves that the N-rank data "
+                                         "plane EXECUTES and that what it gathers is right; `value` is N processes sharing one GPU through a "
+                                         "synchronous transport and must not be quoted as a rate or a scaling point.")
         if multi:
             out["control_plane"] = "sockets between the rank processes (pydisort_amd/_control.py); torch imported: " + str("torch" in sys.modules)
             out["per_rank"] = per_rank  # every rank's own seconds: input generation, plan creation + upload, RCCL bootstrap, its own ms per step

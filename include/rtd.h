@@ -254,6 +254,9 @@ int rtd_comm_init(rtd_plan* plan, const char id[128], int32_t rank, int32_t nran
 /* RCCL's own statement about the plan's communicator: ncclCommCount, ncclCommUserRank, ncclCommCuDevice (any pointer may be
  * null).  RTD_ERR_STATE when they disagree with the arguments of rtd_comm_init. */
 int rtd_comm_size(rtd_plan* plan, int32_t* nranks, int32_t* rank, int32_t* device);
+/* Which transport carries the collectives, as text: "rccl", or "stub:ipc" / "stub:shm" when RTD_RCCL_STUB named the tests'
+ * stand-in (plan may be null: "stub" without the communicator's mode).  Never a rate through the stub. */
+int rtd_comm_transport(rtd_plan* plan, char* buf, int32_t nbuf);
 int rtd_comm_allgather_fluxes(rtd_plan* plan);               /* asynchronous on the plan's stream */
 int rtd_comm_fetch_gathered(rtd_plan* plan, double* out);    /* host [nranks][3][C][ntau] */
 /* u AND fluxes of the last rtd_plan_run: the rank's results are snapshot into its own slot of the gathered arrays (device
@@ -325,6 +328,8 @@ enum {
  *                         instead of the one-lane-per-problem kernel of rtd_eig_small.hip
  *   RTD_SMALL_SPLIT       2 ... 16 streams through the separate interface / sweep / evaluation kernels instead of the fused
  *                         rtd_bc_small_kernel
+ *   RTD_RCCL_STUB         TESTS ONLY: path of a stand-in for the RCCL entry points (tests/stub/librccl_stub.so) for rank processes
+ *                         that share one GPU, where RCCL itself refuses a second rank; rtd_comm_transport() then says "stub"
  *   RTD_DEBUG             diagnostics on stderr
  */
 #ifdef __cplusplus

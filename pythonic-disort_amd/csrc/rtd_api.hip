@@ -961,7 +961,6 @@ int rtd_plan_set_columns(rtd_plan* p, const double* scaled_omega, const double* 
   // depth.  The kernels keep them about the top of their own layer (rtd_dd.h): Taylor shift by taus0[l], in double-double.
   std::vector<double> sloc;
   if (Ns > 0) {
-    if (Ns > 16) return fail(RTD_ERR_ARG, "more than 16 source polynomial coefficients per layer are not supported");
     sloc.assign(s_poly, s_poly + C * L * Ns);
     for (int64_t c = 0; c < C; ++c)
       for (int64_t l = 0; l < L; ++l) rtd_taylor_shift(sloc.data() + (c * L + l) * Ns, (int)Ns, taus0[c * (L + 1) + l]);
@@ -1510,6 +1509,8 @@ struct RcclApi {
   ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  const char* (*StubTransport)(const ncclComm_t) = nullptr;  // only the tests' stand-in transport exports it
+  bool stub = false;
 };
 RcclApi* rccl() {
   static RcclApi api;
@@ -1517,9 +1518,20 @@ RcclApi* rccl() {
   std::call_once(once, [] {
     // The ROCm install's RCCL first, by absolute path: a process that also imports PyTorch carries a second,
     // bundled RCCL/HIP pair under the same SONAMEs, and RCCL must bind to the HIP runtime librtd itself uses.
-    for (const char* name : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) {
-      api.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (api.h) break;
+    // RTD_RCCL_STUB (tests only; never set by the library or its Python package): the path of a stand-in for these entry
+    // points, for rank processes that share ONE GPU -- RCCL refuses a second rank on a device, so this is the only way the
+    // rank > 0 code of rtd_comm_* can execute on a one-GPU box (tests/stub/rccl_stub.cpp).  When it is set nothing else is
+    // tried: a stub that fails to load is an error, not a silent switch to RCCL; rtd_comm_transport() reports which one runs.
+    const char* stub = getenv("RTD_RCCL_STUB");
+    if (stub && *stub) {
+      api.h = dlopen(stub, RTLD_NOW | RTLD_LOCAL);
+      api.stub = true;
+      if (!api.h) fprintf(stderr, "[rtd] RTD_RCCL_STUB=%s: %s\n", stub, dlerror());
+    } else {
+      for (const char* name : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) {
+        api.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (api.h) break;
+      }
     }
     if (api.h) {
       api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
@@ -1535,6 +1547,8 @@ RcclApi* rccl() {
       api.CommCount = (decltype(api.CommCount))dlsym(api.h, "ncclCommCount");
       api.CommUserRank = (decltype(api.CommUserRank))dlsym(api.h, "ncclCommUserRank");
       api.CommCuDevice = (decltype(api.CommCuDevice))dlsym(api.h, "ncclCommCuDevice");
+      if (api.stub) api.StubTransport = (decltype(api.StubTransport))dlsym(api.h, "rcclStubTransport");
+      if (api.stub && !api.StubTransport) api.h = nullptr;  // RTD_RCCL_STUB must name the stub, not some other RCCL
       if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy || !api.GetErrorString) api.h = nullptr;
     }
   });
@@ -1590,6 +1604,17 @@ int rtd_comm_size(rtd_plan* p, int32_t* nranks, int32_t* rank, int32_t* device) 
   if (nranks) *nranks = n;
   if (rank) *rank = me;
   if (device) *device = dev;
+  return 0;
+}
+
+// Which transport carries the collectives: "rccl" (librccl.so of the ROCm install), or "stub:ipc" / "stub:shm" when the
+// environment named the tests' stand-in (RTD_RCCL_STUB).  A caller that reports a multi-rank rate must report this beside it.
+int rtd_comm_transport(rtd_plan* p, char* buf, int32_t nbuf) {
+  if (!buf || nbuf < 2) return fail(RTD_ERR_ARG, "transport: no buffer");
+  RcclApi* r = rccl();
+  if (!r) return fail(RTD_ERR_HIP, "librccl.so could not be loaded");
+  const char* name = !r->stub ? "rccl" : r->StubTransport(p ? p->comm : nullptr);
+  std::snprintf(buf, (size_t)nbuf, "%s", name);
   return 0;
 }
 

@@ -39,12 +39,19 @@ RTD_HD rtd_dd rtd_dd_mul_d(const rtd_dd x, const double t) {  // x * t
   p.lo = fma(x.lo, t, p.lo);
   return rtd_two_sum(p.hi, p.lo);
 }
-// coefficients c[0..n) of p(x) = sum_j c_j x^j  ->  coefficients of the same polynomial in (x - t), in place (n <= 16).
-// Horner / Ruffini scheme in double-double: n (n - 1) / 2 multiply-adds.
+// coefficients c[0..n) of p(x) = sum_j c_j x^j  ->  coefficients of the same polynomial in (x - t), in place.
+// Horner / Ruffini scheme: n (n - 1) / 2 multiply-adds, in double-double for n <= 16 (every practical source polynomial; the
+// work array is 16 double-doubles of a thread's stack); longer polynomials -- the reference puts no limit on Nscoeffs -- take
+// the same scheme in plain float64, in place.
 RTD_HD void rtd_taylor_shift(double* c, const int n, const double t) {
+  if (n > 16) {
+    for (int k = 0; k < n - 1; ++k)
+      for (int j = n - 2; j >= k; --j) c[j] = fma(c[j + 1], t, c[j]);
+    return;
+  }
   rtd_dd w[16];
-  for (int j = 0; j < n && j < 16; ++j) w[j] = {c[j], 0.0};
-  for (int k = 0; k < n - 1 && k < 15; ++k)
+  for (int j = 0; j < n; ++j) w[j] = {c[j], 0.0};
+  for (int k = 0; k < n - 1; ++k)
     for (int j = n - 2; j >= k; --j) w[j] = rtd_dd_add(w[j], rtd_dd_mul_d(w[j + 1], t));
-  for (int j = 0; j < n && j < 16; ++j) c[j] = w[j].hi + w[j].lo;
+  for (int j = 0; j < n; ++j) c[j] = w[j].hi + w[j].lo;
 }

@@ -270,6 +270,13 @@ class Plan:
         _lib.check(self._lib.rtd_comm_size(self._h, C.byref(n), C.byref(r), C.byref(d)))
         return int(n.value), int(r.value), int(d.value)
 
+    def comm_transport(self):
+        """Which transport carries the collectives: "rccl", or "stub:ipc" / "stub:shm" when the environment named the tests'
+        stand-in (include/rtd.h: rtd_comm_transport)."""
+        buf = C.create_string_buffer(32)
+        _lib.check(self._lib.rtd_comm_transport(self._h, buf, 32))
+        return buf.value.decode()
+
     def allgather_fluxes(self):
         _lib.check(self._lib.rtd_comm_allgather_fluxes(self._h))
 

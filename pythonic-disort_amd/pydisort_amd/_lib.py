@@ -69,6 +69,7 @@ SIGNATURES = {
     "rtd_comm_unique_id": (C.c_int, [C.c_char_p]),
     "rtd_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int32, C.c_int32]),
     "rtd_comm_size": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "rtd_comm_transport": (C.c_int, [_vp, C.c_char_p, C.c_int32]),
     "rtd_comm_allgather_fluxes": (C.c_int, [_vp]),
     "rtd_comm_allreduce_results": (C.c_int, [_vp]),
     "rtd_plan_solve_layers": (C.c_int, [_vp, C.c_int32, C.c_int32]),

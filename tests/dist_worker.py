@@ -73,6 +73,7 @@ def main():
             plan.set_eval_points(np.concatenate((np.zeros((per, 1)), mine["tau_arr"]), axis=1), phi)
             plan.comm_init(exchange_id(a, Plan, name), R, W)  # one communicator per plan (the library's model)
             checks[name + "_rccl_says"] = list(plan.comm_size())  # ncclCommCount / ncclCommUserRank / ncclCommCuDevice
+            checks["transport"] = plan.comm_transport()
             ok = ok and plan.comm_size() == (W, R, dev)
             for _ in range(2):  # the second step's gather overlaps nothing stale: its snapshot waits for the first gather
                 plan.run()
@@ -114,6 +115,7 @@ def main():
             _, part = pydisort_amd.pydisort_batch(device=dev, mode_shard=(R, W), _defer_solve=True, **cfg)
             part.plan.set_eval_points(tau, phi)
             part.plan.comm_init(exchange_id(a, Plan, name), R, W)
+            checks["transport"] = part.plan.comm_transport()
             part.plan.run()
             part.plan.allreduce_results()
             got = part.plan.fetch()
@@ -133,6 +135,7 @@ def main():
         _, sh = pydisort_amd.pydisort_batch(device=dev, _defer_solve=True, **cfg)
         plan = sh.plan
         plan.comm_init(uid, R, W)
+        checks["transport"] = plan.comm_transport()
         cnt = Ltot // W
         plan.solve_layers(R * cnt, cnt)   # this rank's layers only: the others hold nothing until the gather
         plan.allgather_layers(cnt)        # ONE collective stitches the boundary-condition system
