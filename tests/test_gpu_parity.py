@@ -37,6 +37,7 @@ PW_TOL = 1e-6               # north star: intensities within 1e-6 relative of th
 # polynomial particular solution itself: in the 1.7e-6-thin bottom layer its constant term is 1.4e4 times the intensity (1.4e-6 of
 # the largest) it leaves after cancelling against the homogeneous part; the absolute error there is 5e-12.
 PW_EXCEPT = {"8ARTS_A": None}
+WIDE_TOL, WIDE_PW_TOL = 1e-8, 4e-7  # 66 ... 128 streams against the reference: 10 x the measured 7.3e-10 / 3.5e-8 (round 5 held 1e-7 / 1e-6)
 PW_TRUTH_TOL = {"8ARTS_A": 5e-6}
 
 
@@ -88,31 +89,49 @@ def test_reference_golden(amd, test_id):
     record_parity("golden/" + test_id, worst, worst_pw, tol, pw_tol, against="reference")
 
 
-@pytest.mark.parametrize("test_id", sorted(PW_EXCEPT))
+# The reference's own ill-conditioned test problems (omega = 1 - 1e-6: 1b, 1e, 2b, 2d, 3a, 3b, 4a, 5a; pydisotest/4_test.py:35-45,
+# 5_test.py:53-63) pass test_reference_golden with little margin -- 4a at 9.49e-7 of the 1e-6 pointwise bound -- against a reference
+# result that is itself ~1e-8 of the field scale off.  Round 6 arbitrates every one of them with a 40-digit solution
+# (tools/hp_truth_case.py golden <id>; calls with NT_cor get the input-only correction terms added): the reference's captured
+# result is 9.49e-7 (4a), 2.4e-7 (5a), 4.4e-8 (2d) pointwise from the truth -- the whole of the HIP-vs-reference distance is the
+# reference's own error -- and the HIP path is held to the truth at (scale, pointwise) = 10 x what it measures there.
+# Measured (profiles/r06_parity_report.json): HIP vs truth 3e-15 ... 9e-13 of the scale and 9e-15 ... 1.7e-11 pointwise on all
+# eleven; 4a: 5.0e-14 / 2.0e-12 where the reference is 2.6e-8 / 9.49e-7.  Held at ten times the largest measured.
+_ILL_TOL = (1e-11, 2e-10)
+HP_TOL = {"8ARTS_A": (1e-9, 5e-6), **{k: _ILL_TOL for k in ("1b", "1e", "2b", "2d", "3a", "3b", "4a", "5a")},
+          **{k: _ILL_TOL for k in ("2c", "4b", "5b")}}  # (the last three: well-conditioned siblings, the machinery's check)
+
+
+@pytest.mark.parametrize("test_id", sorted(HP_TOL))
 def test_golden_case_against_high_precision_truth(amd, test_id):
-    """The reference-captured cases whose pointwise metric cannot be held against the reference's own float64 output are
-    held against the 40-digit solution of the same inputs (tests/golden/hp/golden_<id>.npz, tools/hp_truth_case.py): HIP
-    within 1e-9 of the field scale of the truth and, pointwise, within 1e-6 or -- 8ARTS_A: the reference's captured result is
-    5.0e-5 from the truth (test_hp_truth_fixtures.py), HIP 3.7e-6 -- within PW_TRUTH_TOL (5e-6: ten times closer to the
-    truth than the reference is; see the comment at PW_EXCEPT for what the rest is)."""
+    """The reference-captured cases whose float64 reference result is itself the weak side -- 8ARTS_A (pointwise metric not
+    held against the reference at all) and the eight omega = 1 - 1e-6 test problems (held against the reference at 1e-7 of the
+    scale instead of 1e-9) -- against the 40-digit solution of the same inputs (tests/golden/hp/golden_<id>.npz,
+    tools/hp_truth_case.py): HIP within 1e-9 of the field scale of the truth and within the north star's 1e-6 pointwise (8ARTS_A:
+    5e-6, where the reference is 5.0e-5 from the truth; see the comment at PW_EXCEPT).  Where the reference sits is recorded."""
     from conftest import record_parity
     z = np.load(f"{goldens.HERE}/golden/hp/golden_{test_id}.npz")
-    worst = worst_pw = ref_pw = 0.0
+    worst = worst_pw = ref_pw = ref_scale = 0.0
     for ci, call in enumerate(goldens.load(test_id)):
         if f"c{ci}.u" not in z.files:
             continue
         ev = next(e for e in call["evals"] if e["name"] == "u" and not e["kwargs"] and len(e["args"]) == 2)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            got = amd.pydisort(**call["kwargs"])[4](*ev["args"])
+            res = amd.pydisort(**call["kwargs"])
+        got = res[4](*ev["args"])
         a, b = goldens.max_rel_err(got, z[f"c{ci}.u"])
         worst, worst_pw = max(worst, a), max(worst_pw, b)
-        ref_pw = max(ref_pw, goldens.max_rel_err(ev["out"], z[f"c{ci}.u"])[1])
-    # pointwise: the north star's 1e-6, or -- where the reference's own float64 result is farther than that from the truth --
-    # at least as close to the truth as the reference is
-    assert ref_pw > PW_TRUTH_TOL[test_id]  # (the exception exists because the reference itself is further than this from the truth)
-    record_parity("golden/" + test_id + " vs truth", worst, worst_pw, 1e-9, PW_TRUTH_TOL[test_id], against="40-digit truth",
-                  reference_vs_truth_pointwise_rel=ref_pw)
+        ra, rb = goldens.max_rel_err(ev["out"], z[f"c{ci}.u"])
+        ref_scale, ref_pw = max(ref_scale, ra), max(ref_pw, rb)
+        if f"c{ci}.flux_up" in z.files:  # (fixtures of round 6 carry the flux of the truth too)
+            fu = np.atleast_1d(res[1](ev["args"][0]))
+            assert np.max(np.abs(fu - z[f"c{ci}.flux_up"])) <= 1e-9 * np.max(np.abs(z[f"c{ci}.flux_up"])), test_id
+    tol, pw_tol = HP_TOL[test_id]
+    if test_id in PW_EXCEPT:  # (the exception exists because the reference itself is further than this from the truth)
+        assert ref_pw > pw_tol
+    record_parity("golden/" + test_id + " vs truth", worst, worst_pw, tol, pw_tol, against="40-digit truth",
+                  reference_vs_truth_pointwise_rel=ref_pw, reference_vs_truth_scale_rel=ref_scale)
 
 
 # ---- the reference's own pass criteria vs Fortran DISORT (pydisotest/*_test.py, e.g. 1_test.py:78-81)
@@ -654,8 +673,9 @@ def test_beyond_64_streams_vs_reference(amd, name):
     """72 / 96 / 128 streams -- the reference has no cap on NQuad (pydisort.py:258-264); these sizes run on the NP = 64 instances
     (one eigenproblem per wavefront; a boundary-condition chain per workgroup of four wavefronts, csrc/rtd_bc_wide.hip; one chain per
     wavefront on the row-per-lane kernels under RTD_BC_WIDE_V1) -- against the reference's own outputs
-    (tests/golden/synth/q*.npz, make_synthetic_goldens.py).  Tolerances: the north star's 1e-6 pointwise; 1e-7 of the field
-    scale (the reference's float64 algorithm and its restatement in oracle/ differ by 3e-10 from each other here)."""
+    (tests/golden/synth/q*.npz, make_synthetic_goldens.py).  Tolerances (round 6: ten times what is measured, not 1e-7 / 1e-6):
+    WIDE_TOL = 1e-8 of the field scale (measured 8e-11 ... 7.3e-10; the reference's float64 algorithm and its restatement in
+    oracle/ differ by 3e-10 from each other here), WIDE_PW_TOL = 4e-7 pointwise (measured 3e-10 ... 3.5e-8)."""
     from conftest import record_parity
     from pydisort_amd import synthetic
     kw, tau_pts = synthetic.many_stream_cases()[name]
@@ -664,10 +684,10 @@ def test_beyond_64_streams_vs_reference(amd, name):
         warnings.simplefilter("ignore")
         mu_arr, Fp, Fm, u0, u = amd.pydisort(**kw)
     a, b = goldens.max_rel_err(u(tau_pts, z["phi"]), z["u"])
-    record_parity("synthetic/" + name, a, b, 1e-7, PW_TOL, against="reference")
-    assert a < 1e-7 and b < PW_TOL
+    record_parity("synthetic/" + name, a, b, WIDE_TOL, WIDE_PW_TOL, against="reference")
+    assert a < WIDE_TOL and b < WIDE_PW_TOL
     scale = np.max(np.abs(z["u"]))
-    assert np.max(np.abs(u0(tau_pts) - z["u0"])) / scale < 1e-7
+    assert np.max(np.abs(u0(tau_pts) - z["u0"])) / scale < WIDE_TOL
     assert np.allclose(Fp(tau_pts), z["flux_up"], rtol=1e-8, atol=1e-10 * scale)
     fd = Fm(tau_pts)
     assert np.allclose(fd[0], z["flux_down_diffuse"], rtol=1e-8, atol=1e-10 * scale)
@@ -697,12 +717,12 @@ def test_timed_many_stream_workloads_at_full_depth_vs_reference(amd, name):
         a, b = goldens.max_rel_err(u[i], z[f"c{i}.u"])
         worst, worst_pw = max(worst, a), max(worst_pw, b)
         scale = np.max(np.abs(z[f"c{i}.u"]))
-        assert np.max(np.abs(u0[i] - z[f"c{i}.u0"])) / scale < 1e-7
+        assert np.max(np.abs(u0[i] - z[f"c{i}.u0"])) / scale < WIDE_TOL
         assert np.allclose(fu[i], z[f"c{i}.flux_up"], rtol=1e-8, atol=1e-10 * scale)
         assert np.allclose(fdd[i], z[f"c{i}.flux_down_diffuse"], rtol=1e-8, atol=1e-10 * scale)
         assert np.allclose(fdir[i], z[f"c{i}.flux_down_direct"], rtol=1e-12, atol=1e-300)
-    record_parity("synthetic/" + name, worst, worst_pw, 1e-7, PW_TOL, against="reference")
-    assert worst < 1e-7 and worst_pw < PW_TOL
+    record_parity("synthetic/" + name, worst, worst_pw, WIDE_TOL, WIDE_PW_TOL, against="reference")
+    assert worst < WIDE_TOL and worst_pw < WIDE_PW_TOL
     assert sol.plan.max_sweeps() <= 14
     sol.plan.close()
 

@@ -360,8 +360,9 @@ def make_case_128_streams(seed):
 
 @pytest.mark.parametrize("seed", range(10))
 def test_random_128_stream_case_matches_oracle(seed):
-    """Beyond 64 streams: scale tolerance 1e-7 (the oracle and the reference themselves differ by ~3e-10 at these sizes,
-    tests/test_oracle_vs_reference_goldens.py), the north star's 1e-6 pointwise."""
+    """Beyond 64 streams: scale tolerance 2e-8 (round 6: ten times the largest measured, 1.2e-9; 1e-7 until then -- the oracle
+    and the reference themselves differ by ~3e-10 at these sizes, tests/test_oracle_vs_reference_goldens.py), pointwise 1e-7
+    (measured <= 2.1e-9; the north star asks 1e-6)."""
     import pydisort_amd
     from conftest import record_parity
     import goldens
@@ -374,9 +375,9 @@ def test_random_128_stream_case_matches_oracle(seed):
     want, gotu = ref[4](tau, phi), got[4](tau, phi)
     scale = max(float(np.max(np.abs(want))), 1e-300)
     a, b = goldens.max_rel_err(gotu, want)
-    record_parity("random128/%d" % seed, a, b, 1e-7, 1e-6)
-    assert np.allclose(got[1](tau), ref[1](tau), rtol=1e-7, atol=1e-8 * scale)
-    assert np.allclose(got[2](tau)[0], ref[2](tau)[0], rtol=1e-7, atol=1e-8 * scale)
+    record_parity("random128/%d" % seed, a, b, 2e-8, 1e-7)
+    assert np.allclose(got[1](tau), ref[1](tau), rtol=2e-8, atol=2e-8 * scale)
+    assert np.allclose(got[2](tau)[0], ref[2](tau)[0], rtol=2e-8, atol=2e-8 * scale)
 
 
 @pytest.mark.parametrize("nquad", [66, 94, 96, 98, 126])
@@ -384,7 +385,7 @@ def test_stream_counts_either_side_of_the_48_stream_instances(nquad):
     """66 ... 96 streams (N <= 48) run on boundary-condition kernels that leave the padding columns 48 ... 63 out
     (rtd_sweep_wide_kernel<12>, rtd_iface_mfma_kernel<48>), 98 ... 128 on the full instances: the same three-layer atmosphere
     with a thermal source, a beam and a Lambertian surface at stream counts on both sides of that switch, and at the ends of the
-    range, against the oracle (tolerances of the 128-stream cases)."""
+    range, against the oracle."""
     import pydisort_amd
     import goldens
     from oracle import disort_oracle as O
@@ -401,6 +402,7 @@ def test_stream_counts_either_side_of_the_48_stream_instances(nquad):
     want, gotu = ref[4](tau, phi), got[4](tau, phi)
     scale = float(np.max(np.abs(want)))
     a, b = goldens.max_rel_err(gotu, want)
-    assert a < 1e-7 and b < 1e-6, (nquad, a, b)
-    assert np.allclose(got[1](tau), ref[1](tau), rtol=1e-7, atol=1e-8 * scale)
-    assert np.allclose(got[2](tau)[0], ref[2](tau)[0], rtol=1e-7, atol=1e-8 * scale)
+    from conftest import record_parity
+    record_parity("streams_%d" % nquad, a, b, 1e-8, 3e-8)  # round 6: ten times the measured 9.3e-10 / 3.0e-9 (1e-7 / 1e-6 until then)
+    assert np.allclose(got[1](tau), ref[1](tau), rtol=1e-8, atol=1e-8 * scale)
+    assert np.allclose(got[2](tau)[0], ref[2](tau)[0], rtol=1e-8, atol=1e-8 * scale)

@@ -73,6 +73,40 @@ def test_arts_thermal_case_reference_is_5e_5_pointwise_from_the_truth():
     assert abs(worst - float(z["reference_u_pointwise_rel"])) < 1e-12
 
 
+ILL = {"1b": 3.7e-9, "1e": 2.1e-8, "2b": 1.2e-8, "2d": 4.4e-8, "3a": 2.5e-8, "3b": 1.0e-8, "4a": 9.49e-7, "5a": 2.36e-7}
+
+
+@pytest.mark.parametrize("name", sorted(ILL))
+def test_reference_is_the_weak_side_on_its_own_ill_conditioned_test_problems(name):
+    """The omega = 1 - 1e-6 test problems (pydisotest/1_test.py ... 5_test.py; 4_test.py:35-45, 5_test.py:53-63): the
+    reference's captured float64 intensities against the 40-digit solution of the same inputs (tests/golden/hp/golden_<id>.npz,
+    round 6), pointwise: 4a 9.49e-7, 5a 2.4e-7, 2d 4.4e-8 ... -- exactly the distance at which the HIP path passes
+    test_reference_golden (4a: 9.49e-7 of the 1e-6 bound).  So that margin is the reference's rounding, not the library's."""
+    z = np.load(os.path.join(HP, f"golden_{name}.npz"))
+    call = goldens.load(name)[0]
+    ev = next(e for e in call["evals"] if e["name"] == "u" and not e["kwargs"] and len(e["args"]) == 2)
+    a, b = goldens.max_rel_err(ev["out"], z["c0.u"])
+    assert abs(b - ILL[name]) <= 0.03 * ILL[name], (name, a, b)
+    assert abs(b - float(z["reference_u_pointwise_rel"])) < 1e-12 and a < 3e-8
+    assert ("c0.nt" in z.files) == goldens.nt_is_active(call["kwargs"])
+
+
+@pytest.mark.parametrize("name", ["2c", "4b", "5b"])
+def test_truth_with_nakajima_tanaka_terms_agrees_with_the_reference_on_the_well_conditioned_siblings(name):
+    """The same machinery on the well-conditioned siblings of those problems (omega = 0.9; 4b / 5b with the Nakajima-Tanaka
+    corrections on, whose input-only terms the fixture adds in float64): the reference's captured result is within 1e-12 of
+    the field scale / 1e-10 pointwise of the 40-digit one.  What is seen on 4a / 5a is conditioning, not the arbiter."""
+    z = np.load(os.path.join(HP, f"golden_{name}.npz"))
+    call = goldens.load(name)[0]
+    ev = next(e for e in call["evals"] if e["name"] == "u" and not e["kwargs"] and len(e["args"]) == 2)
+    a, b = goldens.max_rel_err(ev["out"], z["c0.u"])
+    assert a < 2e-12 and b < 1e-10, (name, a, b)
+    assert ("c0.nt" in z.files) == (name != "2c")
+    fu = next(e for e in call["evals"] if e["name"] == "flux_up" and len(e["args"]) == 1)
+    if np.array_equal(np.atleast_1d(fu["args"][0]), np.atleast_1d(ev["args"][0])):
+        assert np.allclose(np.atleast_1d(fu["out"]), z["c0.flux_up"], rtol=0, atol=1e-11 * np.max(np.abs(z["c0.flux_up"])))
+
+
 @pytest.mark.parametrize("name", ["1a", "9c", "8b", "6d"])
 def test_arbiter_agrees_with_the_reference_itself_on_well_conditioned_goldens(name):
     """The 40-digit machinery against outputs the builder did not write: PythonicDISORT's own captured results
