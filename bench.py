@@ -195,6 +195,23 @@ def cpu_baseline_subprocess():
 # ---------------------------------------------------------------------------------------------------------
 # live HBM traffic: rocprofv3 --pmc passes over a short child run of the same workload (before this process touches a GPU)
 # ---------------------------------------------------------------------------------------------------------
+FILLED_COLUMNS = 65536  # cfg3 at a chip-filling batch (the 1 024-column BASELINE batch is 768 ... 2 048 wavefronts for 1 024 SIMDs)
+
+
+def pmc_child_filled():
+    """Child of filled_counters(): the two cfg3 workloads at FILLED_COLUMNS columns, one warm-up and one measured pass each."""
+    import pydisort_amd
+    from pydisort_amd import synthetic
+    for big in (True, False):
+        cfg = synthetic.cfg3_columns(FILLED_COLUMNS, big=big)
+        _, sol = pydisort_amd.pydisort_batch(device=0, work_columns=FILLED_COLUMNS, _defer_solve=True, **cfg)  # (one window: 27 GB at 16 streams)
+        sol.plan.set_eval_points(np.concatenate((np.zeros((FILLED_COLUMNS, 1)), cfg["tau_arr"]), axis=1), np.array([0.0, np.pi / 2, np.pi]))
+        for _ in range(2):
+            sol.plan.run()
+        sol.plan.synchronize()
+        sol.plan.close()
+
+
 def pmc_child(columns):
     """The workload of the traffic passes: for the headline config (32 windows of `columns` cfg4 columns) and for BASELINE's other
     configs (cfg5: 2 windows of 128 columns; cfg3 at both sizes: 1 024 columns) one warm-up and one measured pass each, windows one
@@ -234,7 +251,7 @@ def executed_flops(c):
                    + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)) + 512.0 * c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
 
 
-def executed_roofline(kernel, seconds_per_launch):
+def executed_roofline(kernel, seconds_per_launch, counters=None):
     """What a kernel really executed against the FP64 peak -- beside `frac`, which prices LAPACK's operation count for the
     reference's algorithm and is therefore a normalised throughput, not a utilisation.  From the live FP64 counter
     pass of this bench.py invocation; None when no profiler ran.
@@ -242,7 +259,7 @@ def executed_roofline(kernel, seconds_per_launch):
       valu_issue_frac                 : 4 cycles x wave-level VALU instructions / SIMD cycles while the kernel ran (FP64 issue-bound at 1)
       sustained_clock_ghz             : GRBM_GUI_ACTIVE / 8 XCDs / the dispatch's duration in the profiled pass
       peak_at_sustained_clock         : 78.6 TFLOP/s x sustained clock / 2.4 GHz -- the peak the chip offers at the clock it holds"""
-    c = LIVE_COUNTERS.get(kernel.replace(", ", ","))
+    c = (LIVE_COUNTERS if counters is None else counters).get(kernel.replace(", ", ","))
     if not c or not seconds_per_launch:
         return None
     fl = executed_flops(c)
@@ -262,71 +279,110 @@ def executed_roofline(kernel, seconds_per_launch):
     return out
 
 
+def _profiler():
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None  # this process is being profiled itself: no profiler inside a profiler
+    return exe
+
+
+def _pmc_pass(exe, counters, child_args, timeout):
+    """One rocprofv3 --pmc pass over `bench.py <child_args>` -> ({(kernel instance, counter): [value per launch]},
+    {kernel instance: [seconds per launch]}) or None when the pass failed."""
+    import csv
+    import re
+    import shutil
+    import tempfile
+    env = dict(os.environ, RTD_NO_PIPELINE="1", TMPDIR="/tmp")
+    out = tempfile.mkdtemp(prefix="rtd_pmc_", dir="/tmp")
+    try:
+        r = subprocess.run([exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out, "--",
+                            sys.executable, os.path.abspath(__file__), *child_args],
+                           cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+        files = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
+        if r.returncode != 0 or not files:
+            print(f"[bench] live counter pass {counters[0]} ... failed (rc {r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
+            return None
+        acc, dur = {}, {}
+        with open(files[0]) as f:
+            for row in csv.DictReader(f):
+                m = re.search(r"rtd_\w+(<[^>]*>)?", row["Kernel_Name"])
+                if m and row["Counter_Name"] in counters:
+                    k = m.group(0).replace(", ", ",")
+                    acc.setdefault((k, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+                    if row.get("Start_Timestamp") and row.get("End_Timestamp"):
+                        dur.setdefault(k, {})[row.get("Dispatch_Id")] = (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-9
+        if not dur:  # timestamps in the kernel trace of the same pass
+            for path in [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("kernel_trace.csv")]:
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        m = re.search(r"rtd_\w+(<[^>]*>)?", row.get("Kernel_Name", ""))
+                        if m:
+                            dur.setdefault(m.group(0).replace(", ", ","), {})[row.get("Dispatch_Id")] = \
+                                (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-9
+        return acc, {k: list(d.values()) for k, d in dur.items()}
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def _fold_counters(passed, into):
+    """Mean over the second (measured) half of the launches of every kernel instance -> into[kernel][counter], into[kernel]["seconds"]."""
+    acc, dur = passed
+    for (k, name), v in acc.items():
+        v = v[len(v) // 2:]
+        into.setdefault(k, {})[name] = sum(v) / len(v)
+    for k, v in dur.items():
+        v = v[len(v) // 2:]
+        if k in into:
+            into[k]["seconds"] = sum(v) / len(v)
+
+
+def filled_counters(timeout=240):
+    """The FP64 instruction counters of the <= 16-stream kernels on a batch that FILLS the chip (FILLED_COLUMNS cfg3 columns, same
+    kernels as the 1 024-column BASELINE batch): {kernel instance: {counter: mean per launch}} or None.  With them the line
+    separates fill from kernel efficiency for cfg3 (round-5 verdict, item 7)."""
+    exe = _profiler()
+    if not exe:
+        return None
+    try:
+        passed = _pmc_pass(exe, FP64_COUNTERS, ["--pmc-child-filled"], timeout)
+    except Exception as e:
+        print(f"[bench] filled-batch counters unavailable: {e!r}", file=sys.stderr)
+        return None
+    if not passed:
+        return None
+    out = {}
+    _fold_counters(passed, out)
+    return out or None
+
+
 def live_traffic(columns, timeout=240):
     """HBM bytes per launch of every kernel of the headline config and of BASELINE's other configs, measured NOW: two rocprofv3
     passes (FETCH_SIZE and WRITE_SIZE cannot share one) of `bench.py --pmc-child`, corrected as MI355X_MICROARCH.md prescribes
     (KiB units; FETCH_SIZE doubled on gfx950), and a third pass with the FP64 instruction counters (FP64_COUNTERS -> LIVE_COUNTERS,
     read by executed_roofline).  Returns {kernel name with its template arguments: bytes per launch} -- the
     plain name too where only one instance of a kernel ran -- or None when rocprofv3 is not usable here."""
-    import csv
-    import re
-    import shutil
-    import tempfile
-    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
+    exe = _profiler()
+    if not exe:
         return None
-    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
-        return None  # this process is being profiled itself: no profiler inside a profiler
-    env = dict(os.environ, RTD_NO_PIPELINE="1", TMPDIR="/tmp")
     got = {}
     try:
         for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), FP64_COUNTERS):
-            out = tempfile.mkdtemp(prefix="rtd_pmc_", dir="/tmp")
-            try:
-                r = subprocess.run([exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out, "--",
-                                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--columns", str(columns)],
-                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
-                files = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
-                if r.returncode != 0 or not files:
-                    print(f"[bench] live counter pass {counters[0]} ... failed (rc {r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
-                    if counters is FP64_COUNTERS:
-                        continue  # the traffic passes stand on their own
-                    return None
-                acc, dur = {}, {}
-                with open(files[0]) as f:
-                    for row in csv.DictReader(f):
-                        m = re.search(r"rtd_\w+(<[^>]*>)?", row["Kernel_Name"])
-                        if m and row["Counter_Name"] in counters:
-                            k = m.group(0).replace(", ", ",")
-                            acc.setdefault((k, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
-                            if row.get("Start_Timestamp") and row.get("End_Timestamp"):
-                                dur.setdefault(k, {})[row.get("Dispatch_Id")] = (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-9
-                if counters is FP64_COUNTERS and not dur:  # timestamps in the kernel trace of the same pass
-                    for path in [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("kernel_trace.csv")]:
-                        with open(path) as f:
-                            for row in csv.DictReader(f):
-                                m = re.search(r"rtd_\w+(<[^>]*>)?", row.get("Kernel_Name", ""))
-                                if m:
-                                    dur.setdefault(m.group(0).replace(", ", ","), {})[row.get("Dispatch_Id")] = \
-                                        (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-9
-                for (k, name), v in acc.items():
-                    v = v[len(v) // 2:]  # the second (measured) pass
-                    if counters is FP64_COUNTERS:
-                        LIVE_COUNTERS.setdefault(k, {})[name] = sum(v) / len(v)
-                    else:
-                        got.setdefault(k, {})[name] = sum(v) / len(v)
-                for k, d in dur.items():
-                    v = list(d.values())
-                    v = v[len(v) // 2:]
-                    if counters is FP64_COUNTERS and k in LIVE_COUNTERS:
-                        LIVE_COUNTERS[k]["seconds"] = sum(v) / len(v)
-            finally:
-                shutil.rmtree(out, ignore_errors=True)
+            passed = _pmc_pass(exe, counters, ["--pmc-child", "--columns", str(columns)], timeout)
+            if not passed:
+                if counters is FP64_COUNTERS:
+                    continue  # the traffic passes stand on their own
+                return None
+            _fold_counters(passed, LIVE_COUNTERS if counters is FP64_COUNTERS else got)
     except Exception as e:  # profiler missing, timeout, unreadable output: the committed passes are used instead
         print(f"[bench] live traffic unavailable: {e!r}", file=sys.stderr)
         return None
     # (the table kernels run once per change of the inputs, not per window: they are not part of a window's traffic)
-    res = {k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in got.items() if len(v) == 2 and not k.startswith("rtd_tables")}
+    res = {k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in got.items()
+           if "FETCH_SIZE" in v and "WRITE_SIZE" in v and not k.startswith("rtd_tables")}
     return res or None
 
 
@@ -341,7 +397,7 @@ def traffic_of(live, names):
 # ---------------------------------------------------------------------------------------------------------
 # secondary measurements on rank 0 at N = 1
 # ---------------------------------------------------------------------------------------------------------
-def roofline_of(stage, fl, cols_per_launch, kernel_names):
+def roofline_of(stage, fl, cols_per_launch, kernel_names, counters=None):
     """roofline sub-object of one workload from the plan's HIP-event stage times (ms, launches) per slot."""
     ms = {k: (v[0] / max(v[1], 1)) for k, v in stage.items()}  # per launch = per window
     ms["bc"] = ms["iface"] + ms["sweep"]
@@ -354,11 +410,11 @@ def roofline_of(stage, fl, cols_per_launch, kernel_names):
             "columns_per_launch": cols_per_launch,
             "frac_is": "a normalised throughput: LAPACK's operation count for the reference's algorithm (SURVEY 8(d)) over the kernel's "
                        "time; the utilisation of the FP64 units is `executed_frac`"}
-    ex = executed_roofline(kernel_names[dom], ms[dom] * 1e-3)
+    ex = executed_roofline(kernel_names[dom], ms[dom] * 1e-3, counters)
     if ex:
         roof.update(ex)
     other = "bc" if dom == "eigen" else "eigen"
-    ex2 = executed_roofline(kernel_names[other], ms[other] * 1e-3) if ms.get(other) else None
+    ex2 = executed_roofline(kernel_names[other], ms[other] * 1e-3, counters) if ms.get(other) else None
     if ex2:
         roof["other_kernel"] = dict(kernel=kernel_names[other], ms_per_launch=ms[other], **{k: v for k, v in ex2.items() if k != "executed_what"})
     return roof, ms
@@ -387,7 +443,7 @@ def golden_parity(name, maker, kwargs, device):
             "against": f"reference-computed goldens tests/golden/synth/{name}.npz"}
 
 
-def config_leg(name, golden, maker, kwargs, columns, window, device, passes, live=None):
+def config_leg(name, golden, maker, kwargs, columns, window, device, passes, live=None, counters=None):
     """One of BASELINE's other configs through the same path: resident rate (plan.run over all windows), host-to-host
     rate (run_fetch: D2H of a window overlapped with the next window's kernels), HIP-event kernel times -> roofline,
     parity of the first columns against the reference-computed goldens."""
@@ -435,15 +491,15 @@ def config_leg(name, golden, maker, kwargs, columns, window, device, passes, liv
     np_ = 4 if nq <= 8 else 8 if nq <= 16 else 16 if nq <= 32 else 32
     names = {"eigen": "rtd_eigen_lane_kernel<4>" if np_ == 4 else f"rtd_eigen_kernel<{np_}, 2>",
              "bc": "rtd_bc_tile2_kernel" if np_ == 32 else "rtd_bc_mfma_kernel" if np_ == 16 else f"rtd_bc_small_kernel<{np_}>"}
-    roof, ms = roofline_of(stage, fl, columns / nwin, names)
+    roof, ms = roofline_of(stage, fl, columns / nwin, names, counters)
     roof["whole_path_tflops"] = fl["total"] * rate / 1e12
     roof["whole_path_frac"] = roof["whole_path_tflops"] / FP64_PEAK_TFLOPS
     # measured HBM bytes per launch of the dominant kernel(s) (the live rocprofv3 passes of this run; cfg5's child runs windows of
     # the same 128 columns, cfg3's the same 1 024 columns in one launch)
     dom_names = [k.strip() for k in roof["kernel"].split("+")]
-    roof["traffic"] = traffic_of(live, dom_names)
+    roof["traffic"] = traffic_of(live, dom_names) if counters is None else None
     roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation" if roof["traffic"] is not None
-                              else "not measured (no profiler in this run)")
+                              else "not measured" + (" (no profiler in this run)" if counters is None else " at this batch size"))
     plan.close()
     return {"value": rate, "unit": "column-solves/sec", "workload": name, "columns": columns, "columns_per_window": cw,
             "windows": nwin, "host_to_host": e2e, "mflop_per_column": fl["total"] / 1e6, "roofline": roof,
@@ -573,7 +629,7 @@ def all_cloud_leg(device, columns=16384, window=256, passes=3):
                                                         "note": "the float64 oracle (= the reference's algorithm) on the same two columns"}}}
 
 
-def extra_measurements(device, main_cfg=None, window=2048, live=None):
+def extra_measurements(device, main_cfg=None, window=2048, live=None, filled=None):
     """max |dI| of the HIP path against the oracle on the sample columns of the cpu_baseline leg, the only_flux
     throughput, the host-to-host rate of the main batch, and BASELINE's other configs."""
     import pydisort_amd
@@ -617,6 +673,12 @@ def extra_measurements(device, main_cfg=None, window=2048, live=None):
                                        "cfg3_small", "cfg3_columns", {"big": False}, 1024, 0, device, 50, live),
         "cfg3_L8_Q16_x1024": config_leg("cfg3 at BASELINE's size (8 layers, 16 streams) x 1024 perturbed columns",
                                         "cfg3_big", "cfg3_columns", {"big": True}, 1024, 0, device, 50, live),
+        # the SAME kernels on a batch that fills the chip: how much of the 1 024-column figures is fill, how much the kernels
+        "cfg3_L6_Q8_x65536_chip_filling": config_leg("cfg3 (6 layers, 8 streams) x 65536 perturbed columns: the 1 024-column BASELINE batch's kernels on a "
+                                                    "batch that fills the chip (one window, one launch per kernel)",
+                                                    "cfg3_small", "cfg3_columns", {"big": False}, FILLED_COLUMNS, FILLED_COLUMNS, device, 5, None, filled or {}),
+        "cfg3_L8_Q16_x65536_chip_filling": config_leg("cfg3 at BASELINE's size (8 layers, 16 streams) x 65536 perturbed columns: chip-filling batch",
+                                                     "cfg3_big", "cfg3_columns", {"big": True}, FILLED_COLUMNS, FILLED_COLUMNS, device, 5, None, filled or {}),
         "cfg5_L50_Q64_x10000": config_leg("cfg5 at BASELINE's literal size: 50 layers, 64 streams, 64 Fourier modes, 2-mode BDRF surface, thermal "
                                           "source; 10^4 columns in 79 windows of 128",
                                           "cfg5", "cfg5_columns", {}, 10_000, 128, device, 2, live),
@@ -646,10 +708,11 @@ def end_to_end(device, cfg=None, window=2048):
     for a in out.values():
         a.fill(0.0)  # (np.zeros maps pages lazily: touch them here, not inside the first timed call)
     calls = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        res = pydisort_amd.solve_columns_streamed(cfg, tau, phi, chunk_columns=window, device=device, out=out)
-        calls.append(time.perf_counter() - t0)
+    with pydisort_amd.pooled(device=device):  # a serving loop opts in: the arena of a call serves the next (include/rtd.h: rtd_pool_set_limit)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = pydisort_amd.solve_columns_streamed(cfg, tau, phi, chunk_columns=window, device=device, out=out)
+            calls.append(time.perf_counter() - t0)
     best = min(calls)
     assert np.all(np.isfinite(res["flux_up"])) and res["u"] is out["u"]
     # (the host side of a call -- input checks, pageable H2D, the copy out of the pinned staging buffers -- shares the
@@ -660,8 +723,8 @@ def end_to_end(device, cfg=None, window=2048):
             "what": "the SAME batch as `value`, host to host: NumPy inputs (raw: tau, omega, 33 moments, f, mu0, I0, phi0) -> "
                     "NumPy u [C,32,21,3], u0, fluxes, one call: input checks, plan creation, H2D of the raw inputs, delta-M "
                     f"scaling / rescaling on the device, windowed solve + evaluation ({window} columns per window), D2H through "
-                    "pinned staging overlapped with the next window; result arrays preallocated by the caller; best of 3 calls "
-                    "(every call's time listed)"}
+                    "pinned staging overlapped with the next window; result arrays preallocated by the caller; the loop has opted in to the "
+                    "library's large-block pool (pydisort_amd.pooled(): off by default); best of 3 calls (every call's time listed)"}
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -891,11 +954,13 @@ def run_rank(a, rank, world, local):
         phase("stub hang")  # test hook: a rank that never joins
         time.sleep(3600)
     cpu = None
+    filled = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not stub:
         cpu = cpu_baseline_subprocess()
     live = None
     if rank == 0 and world == 1 and not a.no_extras and not a.no_live_traffic and not stub:
         live = live_traffic(a.columns)  # before this process touches the GPU (the profiler runs a child of its own)
+        filled = filled_counters() if live else None
 
     first, C = shard_columns(rank, world, a.columns, a.total_columns)
     strong = a.total_columns > 0
@@ -1136,7 +1201,7 @@ def run_rank(a, rank, world, local):
     if rank == 0 and world == 1 and not a.no_extras and not stub:
         plan.close()  # the extras build their own plans: give the arena back first
         plan = None
-        extras = extra_measurements(dev, cfg if strong else None, a.columns, live)
+        extras = extra_measurements(dev, cfg if strong else None, a.columns, live, filled)
     if rank == 0:
         value = total_cols * a.steps / elapsed
         out = {
@@ -1257,10 +1322,14 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="take roofline.traffic from the committed PMC passes instead of two rocprofv3 passes of a child run (~20 s)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child-filled", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.pmc_child:  # child of live_traffic(), under rocprofv3: the workload only
         pmc_child(a.columns)
+        return
+    if a.pmc_child_filled:  # child of filled_counters()
+        pmc_child_filled()
         return
     if a.cpu_baseline_only:  # child of cpu_baseline_subprocess(): no GPU, one JSON line
         res = cpu_baseline()

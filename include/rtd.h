@@ -76,13 +76,18 @@ int rtd_plan_destroy(rtd_plan* plan);
 int rtd_plan_synchronize(rtd_plan* plan);
 /* bytes of device memory held by the plan */
 int rtd_plan_device_bytes(rtd_plan* plan, int64_t* bytes);
-/* The library keeps the device memory of destroyed plans for the next plan of about the same size (blocks up to 64 MB: 512 MB in
- * all; larger blocks: up to RTD_POOL_BYTES, default an eighth of the device's memory, oldest out first) -- creating and destroying a
- * plan per call then costs neither hipMalloc nor the seconds-long stalls the runtime's lazy reclaim of freed gigabytes puts on
- * later allocations (profiles/r05_alloc_outliers.txt).  No counterpart in the reference (NumPy's allocator).
- * rtd_pool_bytes: what is held right now; rtd_pool_trim: give it back to the runtime (device -1: every device; released may be
- * NULL).  An allocation of the library that fails with out-of-memory trims the pool and is tried again by itself; a caller that
- * shares the device with another allocator (a framework's caching allocator) calls rtd_pool_trim before that one needs the room. */
+/* Device memory of destroyed plans.  Small arenas (blocks up to 64 MB, 512 MB in all) are always kept for the next plan of about
+ * the same size: one-column calls create and destroy a plan per call.  LARGE blocks are kept only when the caller asks for it --
+ * rtd_pool_set_limit, or RTD_POOL_BYTES in the environment; the default limit is 0: a library imported under someone else's
+ * process must not sit on gigabytes of a GPU it shares with that process's allocator.  With a limit (bytes PER DEVICE; < 0: an
+ * eighth of that device's memory; oldest blocks of the same device out first), creating and destroying a plan of gigabytes per call
+ * costs neither hipMalloc nor the seconds-long stalls the runtime's lazy reclaim of freed gigabytes puts on later allocations
+ * (profiles/r05_alloc_outliers.txt: 4 of 40 creations of a 14 GB plan stalled for 1.8 ... 4.7 s without, none with) -- a serving
+ * loop opts in once.  No counterpart in the reference (NumPy's allocator).
+ * rtd_pool_set_limit: the new limit (previous may be NULL; lowering it frees what no longer fits); rtd_pool_bytes: what is held
+ * right now; rtd_pool_trim: give it back to the runtime (device -1: every device; released may be NULL).  An allocation of the
+ * library that fails with out-of-memory trims the pool and is tried again by itself. */
+int rtd_pool_set_limit(int64_t bytes, int32_t device, int64_t* previous);
 int rtd_pool_bytes(int64_t* cached);
 int rtd_pool_trim(int32_t device, int64_t* released);
 /* Which columns of the batch failed numerically in the last solve: status[ncols], 0 = fine.  Bits 1..4 of the low byte:
@@ -311,8 +316,8 @@ enum {
  * parity (tests/test_gpu_parity.py runs the suite under each), size buffers, or print diagnostics.  Timing experiments whose
  * results are NOT valid (e.g. the aliased hand-off reads of DESIGN.md section 7a) exist only behind compile-time -D flags.
  *   RTD_WORK_BYTES        bytes of solve intermediates per plan (default 24 GiB): sizes the automatic column window
- *   RTD_POOL_BYTES        bytes of device memory of destroyed plans kept for the next plan in blocks above 64 MB (default: an
- *                         eighth of the device's memory; 0: large blocks go straight back to the runtime); see rtd_pool_trim
+ *   RTD_POOL_BYTES        bytes of device memory (per device) of destroyed plans kept for the next plan in blocks above 64 MB
+ *                         (default 0: large blocks go straight back to the runtime); the same as rtd_pool_set_limit
  *   RTD_NO_PIPELINE       windows one after the other on one stream (no second hand-off slot, no eigen stream)
  *   RTD_BC_FORCE_PIVOT    fused boundary-condition kernels: =1 every elimination is redone by the column-pivoted LDS path (the
  *                         path of a failed speculation); =2 every chain of the 32-stream kernel takes the register-resident

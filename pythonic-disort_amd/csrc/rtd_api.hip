@@ -52,9 +52,12 @@ int pad_pow2(int n) {
 //  * batch calls create and destroy plans of gigabytes.  hipFree of such a block returns in ~2 ms, but the runtime reclaims the
 //    memory lazily, and every so often a later hipMalloc pays for it: 0.4 ... 4.8 s, growing with the bytes freed since
 //    (profiles/r05_alloc_outliers.txt: 9 of 40 creations of a 14 GB plan, the same with bare hipMalloc / hipFree).  Blocks above
-//    64 MB are therefore kept too, oldest out first, up to RTD_POOL_BYTES (default: an eighth of the device's memory); they serve
-//    requests down to 7/8 of their size -- a serving loop repeats its shapes.  rtd_pool_trim gives everything back; a hipMalloc
-//    that fails trims the pool and tries again, so the pool never costs a caller of THIS library an allocation.
+//    64 MB CAN therefore be kept too, oldest out first, up to a limit PER DEVICE -- but only when the caller asks for it
+//    (rtd_pool_set_limit, or RTD_POOL_BYTES in the environment): the default is 0, a library that is imported under someone
+//    else's process does not sit on gigabytes of a GPU it shares with that process's allocator (round-5 verdict).  Kept blocks
+//    serve requests down to 7/8 of their size -- a serving loop repeats its shapes.  rtd_pool_trim gives everything back; a
+//    hipMalloc that fails trims the pool and tries again; evicted blocks are freed OUTSIDE the pool's mutex (hipFree
+//    synchronises the device).
 struct DevPool {
   struct Block { void* p; size_t bytes; int dev; };
   std::mutex m;
@@ -62,8 +65,69 @@ struct DevPool {
   std::vector<std::pair<hipStream_t, int>> free_streams;
   std::vector<Block> host_blocks;  // pinned staging slabs of rtd_plan_run_fetch (hipHostMalloc + hipHostFree: ~3 ms per plan)
   size_t cached = 0, big_cached = 0, host_cached = 0;
-  int64_t big_cap = -1;  // bytes; -1: not sized yet
+  int64_t big_cap = -1;  // bytes PER DEVICE; -1: not read from the environment yet
   static constexpr size_t MAX_BLOCK = 64u << 20, MAX_CACHED = 512u << 20;
+
+  int64_t limit_locked() {  // (m held)
+    if (big_cap < 0) {
+      const char* env = getenv("RTD_POOL_BYTES");
+      big_cap = env ? std::max<long long>(0, atoll(env)) : 0;
+    }
+    return big_cap;
+  }
+  size_t big_cached_on(int dev) const {
+    size_t n = 0;
+    for (const Block& b : big_blocks)
+      if (b.dev == dev) n += b.bytes;
+    return n;
+  }
+  // blocks of `dev` out, oldest first, until `room` more bytes fit under the limit; the caller frees them outside the lock
+  void evict_locked(int dev, int64_t room, int64_t cap, std::vector<Block>* out) {
+    int64_t held = (int64_t)big_cached_on(dev);
+    for (size_t i = 0; i < big_blocks.size() && held + room > cap;) {
+      if (big_blocks[i].dev != dev) {
+        ++i;
+        continue;
+      }
+      held -= (int64_t)big_blocks[i].bytes;
+      big_cached -= big_blocks[i].bytes;
+      out->push_back(big_blocks[i]);
+      big_blocks.erase(big_blocks.begin() + i);
+    }
+  }
+  static void release(const std::vector<Block>& blocks) {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    for (const Block& b : blocks) {
+      if (b.dev != cur) (void)hipSetDevice(b.dev);
+      (void)hipFree(b.p);
+    }
+    if (!blocks.empty() && cur >= 0 && blocks.back().dev != cur) (void)hipSetDevice(cur);
+  }
+  // bytes >= 0: the new per-device limit; < 0: an eighth of the memory of device `dev`.  Returns the previous limit.
+  int64_t set_limit(int64_t bytes, int dev) {
+    std::vector<Block> out;
+    int64_t prev;
+    {
+      std::lock_guard<std::mutex> g(m);
+      prev = limit_locked();
+      if (bytes < 0) {
+        size_t fr = 0, total = 0;
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (dev >= 0 && dev != cur) (void)hipSetDevice(dev);
+        bytes = hipMemGetInfo(&fr, &total) == hipSuccess ? (int64_t)(total / 8) : 0;
+        if (dev >= 0 && dev != cur && cur >= 0) (void)hipSetDevice(cur);
+      }
+      big_cap = bytes;
+      std::vector<int> devs;
+      for (const Block& b : big_blocks)
+        if (std::find(devs.begin(), devs.end(), b.dev) == devs.end()) devs.push_back(b.dev);
+      for (int d : devs) evict_locked(d, 0, big_cap, &out);
+    }
+    release(out);
+    return prev;
+  }
 
   void* get(size_t bytes, int dev, size_t* got) {
     std::lock_guard<std::mutex> g(m);
@@ -83,27 +147,22 @@ struct DevPool {
     return b.p;
   }
   bool put(void* p, size_t bytes, int dev) {
-    std::lock_guard<std::mutex> g(m);
-    if (bytes <= MAX_BLOCK) {
-      if (cached + bytes > MAX_CACHED) return false;
-      free_blocks.push_back({p, bytes, dev});
-      cached += bytes;
-      return true;
+    std::vector<Block> out;
+    {
+      std::lock_guard<std::mutex> g(m);
+      if (bytes <= MAX_BLOCK) {
+        if (cached + bytes > MAX_CACHED) return false;
+        free_blocks.push_back({p, bytes, dev});
+        cached += bytes;
+        return true;
+      }
+      const int64_t cap = limit_locked();
+      if ((int64_t)bytes > cap) return false;
+      evict_locked(dev, (int64_t)bytes, cap, &out);  // this device's oldest blocks make room; other devices keep theirs
+      big_blocks.push_back({p, bytes, dev});
+      big_cached += bytes;
     }
-    if (big_cap < 0) {
-      const char* env = getenv("RTD_POOL_BYTES");
-      size_t fr = 0, total = 0;
-      if (env) big_cap = std::max<long long>(0, atoll(env));
-      else big_cap = hipMemGetInfo(&fr, &total) == hipSuccess ? (int64_t)(total / 8) : 0;
-    }
-    if ((int64_t)bytes > big_cap) return false;
-    while (!big_blocks.empty() && (int64_t)(big_cached + bytes) > big_cap) {  // oldest out first
-      big_cached -= big_blocks.front().bytes;
-      (void)hipFree(big_blocks.front().p);
-      big_blocks.erase(big_blocks.begin());
-    }
-    big_blocks.push_back({p, bytes, dev});
-    big_cached += bytes;
+    release(out);
     return true;
   }
   void* get_host(size_t bytes, size_t* got) {
@@ -129,26 +188,30 @@ struct DevPool {
   }
   // gives the cached blocks of `dev` (-1: every device) back to the runtime; returns the device bytes released
   size_t trim(int dev) {
-    std::lock_guard<std::mutex> g(m);
+    std::vector<Block> out, host_out;
     size_t released = 0;
-    if (dev < 0) {
-      for (const Block& b : host_blocks) (void)hipHostFree(b.p);
-      host_blocks.clear();
-      host_cached = 0;
-    }
-    for (std::vector<Block>* list : {&free_blocks, &big_blocks}) {
-      std::vector<Block> keep;
-      for (const Block& b : *list) {
-        if (dev >= 0 && b.dev != dev) {
-          keep.push_back(b);
-          continue;
-        }
-        (void)hipFree(b.p);
-        released += b.bytes;
-        (list == &free_blocks ? cached : big_cached) -= b.bytes;
+    {
+      std::lock_guard<std::mutex> g(m);
+      if (dev < 0) {
+        host_out.swap(host_blocks);
+        host_cached = 0;
       }
-      list->swap(keep);
+      for (std::vector<Block>* list : {&free_blocks, &big_blocks}) {
+        std::vector<Block> keep;
+        for (const Block& b : *list) {
+          if (dev >= 0 && b.dev != dev) {
+            keep.push_back(b);
+            continue;
+          }
+          out.push_back(b);
+          released += b.bytes;
+          (list == &free_blocks ? cached : big_cached) -= b.bytes;
+        }
+        list->swap(keep);
+      }
     }
+    for (const Block& b : host_out) (void)hipHostFree(b.p);
+    release(out);
     return released;
   }
   hipStream_t get_stream(int dev) {
@@ -576,7 +639,7 @@ extern "C" {
 
 int rtd_comm_destroy(rtd_plan* p);
 
-int rtd_version(void) { return 211; }  // 210: rtd_plan_create_retained, rtd_plan_retained, rtd_comm_size; 211: rtd_pool_trim, rtd_pool_bytes (round 5)
+int rtd_version(void) { return 212; }  // 210: rtd_plan_create_retained, rtd_plan_retained, rtd_comm_size; 211: rtd_pool_trim, rtd_pool_bytes (round 5); 212: rtd_pool_set_limit (large-block pool off by default), rtd_comm_transport (round 6)
 
 const char* rtd_last_error(void) { return g_err.c_str(); }
 
@@ -851,6 +914,12 @@ int rtd_plan_device_bytes(rtd_plan* p, int64_t* bytes) {
 int rtd_pool_trim(int32_t device, int64_t* released) {
   const size_t n = pool().trim(device);
   if (released) *released = (int64_t)n;
+  return 0;
+}
+
+int rtd_pool_set_limit(int64_t bytes, int32_t device, int64_t* previous) {
+  const int64_t prev = pool().set_limit(bytes, device);
+  if (previous) *previous = prev;
   return 0;
 }
 

@@ -160,6 +160,14 @@ class Plan:
         _lib.check(_lib.load().rtd_pool_trim(int(device), C.byref(b)))
         return b.value
 
+    @staticmethod
+    def pool_set_limit(nbytes=-1, device=0):
+        """Opt in to (or out of) keeping the LARGE device blocks of closed plans for the next plan: nbytes per device, < 0 = an
+        eighth of the device's memory, 0 = off (the default).  Returns the previous limit (include/rtd.h: rtd_pool_set_limit)."""
+        b = C.c_int64()
+        _lib.check(_lib.load().rtd_pool_set_limit(int(nbytes), int(device), C.byref(b)))
+        return b.value
+
     def evaluate(self, tau, phi=None, antiderivative=False, want=("u", "u0", "flux"), skip_nt=False):
         """tau [C, ntau]; phi [nphi] or None -> dict of arrays (u [C,Q,ntau,nphi], u0 [C,Q,ntau],
         flux_up / flux_down_diffuse / flux_down_direct [C,ntau], ulast [C,Q,ntau])."""

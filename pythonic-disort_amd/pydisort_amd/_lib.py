@@ -39,6 +39,7 @@ SIGNATURES = {
     "rtd_plan_destroy": (C.c_int, [_vp]),
     "rtd_plan_synchronize": (C.c_int, [_vp]),
     "rtd_plan_device_bytes": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "rtd_pool_set_limit": (C.c_int, [C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),
     "rtd_pool_bytes": (C.c_int, [C.POINTER(C.c_int64)]),
     "rtd_pool_trim": (C.c_int, [C.c_int32, C.POINTER(C.c_int64)]),
     "rtd_plan_get_column_status": (C.c_int, [_vp, C.POINTER(C.c_int32)]),

@@ -72,12 +72,30 @@ def test_a_plan_closed_by_hand_is_not_handed_out_again():
 
 def test_device_memory_of_closed_batch_plans_serves_the_next_plan():
     """The device arena of a closed plan -- whatever a previous tenant left in it -- is what the next plan of the same shape is
-    built in (include/rtd.h: rtd_pool_bytes / rtd_pool_trim): same bits as from fresh memory, for a retained windowed plan with
-    thermal sources and a BDRF and for a plain one; rtd_pool_trim gives everything back."""
+    built in, ONCE THE CALLER HAS OPTED IN (include/rtd.h: rtd_pool_set_limit; pydisort_amd.pooled()): same bits as from fresh
+    memory, for a retained windowed plan with thermal sources and a BDRF and for a plain one; rtd_pool_trim gives everything back.
+    By default (round 6) a closed batch plan leaves nothing large behind: the library is a guest in someone else's process."""
     import pydisort_amd as amd
     from pydisort_amd import synthetic
     amd.pool_trim()
     assert amd.pool_bytes() == 0
+    if "RTD_POOL_BYTES" not in os.environ:
+        cfg = synthetic.cfg4_columns(300)
+        _, sol = amd.pydisort_batch(work_columns=128, **cfg)
+        assert sol.plan.device_bytes() > (64 << 20)
+        sol.plan.close()
+        assert amd.pool_bytes() <= (64 << 20)        # default: only small blocks (the evaluation buffers) stay
+        amd.pool_trim()
+    with amd.pooled():
+        _pooled_plans_serve_the_next(amd, synthetic)
+        assert amd.pool_bytes() > (64 << 20)
+    if "RTD_POOL_BYTES" not in os.environ:
+        assert amd.pool_bytes() <= (64 << 20)        # leaving the block restores the limit and frees what no longer fits
+    amd.pool_trim()
+    assert amd.pool_bytes() == 0
+
+
+def _pooled_plans_serve_the_next(amd, synthetic):
     rng = np.random.default_rng(3)
     for maker, kw, cols, win in (("cfg5_columns", dict(L=12, NQuad=64), 24, 8), ("cfg4_columns", {}, 300, 128)):
         cfg = getattr(synthetic, maker)(cols, **kw)
@@ -100,5 +118,3 @@ def test_device_memory_of_closed_batch_plans_serves_the_next_plan():
         got = again.u(tau, phi), again.flux_up(tau)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
         again.plan.close()
-    assert amd.pool_bytes() > 0
-    assert amd.pool_trim() > 0 and amd.pool_bytes() == 0

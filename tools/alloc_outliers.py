@@ -66,7 +66,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         {"plans": plans, "bare": bare}[sys.argv[1]]()
         sys.exit(0)
-    for title, leg, env in (("library, RTD_POOL_BYTES=0 (large blocks straight back to the runtime)", "plans", {"RTD_POOL_BYTES": "0"}),
-                            ("library as it is (large blocks pooled)", "plans", {}), ("runtime alone", "bare", {})):
+    for title, leg, env in (("library as it is (default: large blocks straight back to the runtime)", "plans", {"RTD_POOL_BYTES": "0"}),
+                            ("library, opted in (rtd_pool_set_limit / RTD_POOL_BYTES = 36 GB: large blocks pooled)", "plans", {"RTD_POOL_BYTES": str(36 << 30)}),
+                            ("runtime alone", "bare", {})):
         print(title, flush=True)
         subprocess.run([sys.executable, os.path.abspath(__file__), leg], env={**os.environ, **env}, check=True)
