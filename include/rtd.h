@@ -46,6 +46,9 @@ typedef struct {
 int rtd_version(void);
 const char* rtd_last_error(void);
 int rtd_device_count(int32_t* count);
+/* free and total memory of a device right now (hipMemGetInfo; either pointer may be NULL): what a caller sizes a retention
+ * budget or a pool limit against */
+int rtd_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes);
 
 /* --- plan life cycle ---------------------------------------------------------------------- */
 /* Allocates every device buffer the path needs for `dims` on HIP device `device`.
@@ -66,9 +69,18 @@ int rtd_plan_create_windowed(const rtd_dims* dims, int32_t device, int32_t work_
  * eigenvector blocks Y, A, the eigenvalues, particular solutions and boundary-condition coefficients: 3.1 of the 8.4 MB of
  * intermediates of a 20-layer 32-stream column) is then held for ALL columns; only the boundary-condition workspace stays
  * windowed.  retain_bytes: budget for that state in bytes; < 0: three tenths of the device memory that is free at creation;
- * 0: never (= rtd_plan_create_windowed).  A batch whose state does not fit is created as a plain windowed plan, whose
- * rtd_plan_evaluate solves the windows again; rtd_plan_retained tells which it is (one-window plans: always 1). */
+ * 0: never (= rtd_plan_create_windowed).
+ * A batch whose full state does not fit the budget is created in the LEAN retained form when that fits (10 streams and up): only
+ * what cannot be recomputed cheaply is held for all columns -- the boundary-condition coefficients, k, E = exp(-k dtau), the beam
+ * and thermal particular solutions: 0.5 MB per 20-layer 32-stream column, 50 GB for BASELINE's 10^5-column batch -- and
+ * rtd_plan_evaluate re-runs the EIGEN stage (never the boundary-condition solve) for the layers its points touch, window by window,
+ * in the wavefront composition the solve had them in: results bit-identical to the full form; an evaluation at one depth per column
+ * costs about a tenth of a solve.  Else the plan is a plain windowed one, whose rtd_plan_evaluate solves the windows again.
+ * rtd_plan_retained tells which it is: 1 full (one-window plans: always), 2 lean, 0 neither.
+ * rtd_plan_create_retained_form: form 0 = as above (full, else lean, else neither), 1 = full or neither, 2 = lean or neither. */
 int rtd_plan_create_retained(const rtd_dims* dims, int32_t device, int32_t work_columns, int64_t retain_bytes, rtd_plan** plan);
+int rtd_plan_create_retained_form(const rtd_dims* dims, int32_t device, int32_t work_columns, int64_t retain_bytes, int32_t form,
+                                  rtd_plan** plan);
 int rtd_plan_retained(rtd_plan* plan, int32_t* retained);
 /* columns per window and number of windows of a plan */
 int rtd_plan_windows(rtd_plan* plan, int32_t* work_columns, int32_t* nwindows);

@@ -280,6 +280,13 @@ struct rtd_plan {
   // reference's closures do with GC_collect, K_collect, B_collect (_assemble_intensity_and_fluxes.py:170-262).  Only the
   // boundary-condition workspace Fws (5 of a cfg4 column's 8.4 MB) stays windowed.
   bool retained = false;
+  // Lean retained plan (round 6): what cannot be recomputed cheaply stays for ALL columns -- the boundary-condition coefficients,
+  // k, E, B and the thermal vectors (0.5 of a cfg4 column's 3.1 MB) -- while Y, A stay windowed; an evaluation re-runs the EIGEN
+  // stage for the wavefront chunks its points touch (same wavefront composition as in the solve: same bits), window by window,
+  // and never the boundary-condition solve.  10^5 cfg4 columns: 50 GB instead of 310 GB.
+  bool lean = false;
+  double* sel_buf = nullptr;  // chunk lists of one window [Cw][nsel] (ints), grown on demand
+  int64_t cap_sel = 0;
   bool fork_needed = true;               // inputs were (re)uploaded on `stream` since the last solve: the eigen stream must wait for them
   bool bc_recorded[2] = {false, false};  // ev_bc[slot] has been recorded by some earlier window (possibly of an earlier run)
   // Pipelined plans keep the device status words (status, col_status, sweeps) twice and alternate between them from solve to
@@ -401,15 +408,17 @@ RtdDev window_dev(const rtd_plan* p, int64_t c0, int cnt, int slot = 0) {
   RtdDev w = p->d;
   if (slot == 1) {
     const rtd_plan::HandOff& h = p->slot1;
-    w.Y0 = h.Y0; w.att = h.att; w.Ym = h.Ym; w.Am = h.Am; w.kk = h.kk; w.Bv = h.Bv; w.dq = h.dq; w.zneg = h.zneg; w.Ek = h.Ek; w.vb = h.vb;
+    w.Ym = h.Ym; w.Am = h.Am;
+    if (!p->lean) { w.Y0 = h.Y0; w.att = h.att; w.kk = h.kk; w.Bv = h.Bv; w.dq = h.dq; w.zneg = h.zneg; w.Ek = h.Ek; w.vb = h.vb; }
   }
   if (p->tables_cached) {  // the window's part of the all-columns tables
     w.Y0 = p->Y0_all + c0 * (int64_t)p->d.M * p->d.P;
     w.att = p->att_all + c0 * ((int64_t)p->d.L + 1);
   }
   const int64_t L = w.L, M = w.M, P = w.P, NP = w.NP, Ns = w.Ns, NB = w.NBDRF;
-  if (p->retained) {  // every column has its own place in the hand-off arrays and the coefficients
-    w.Ym += c0 * M * L * NP * NP; w.Am += c0 * M * L * NP * NP; w.kk += c0 * M * L * NP; w.Ek += c0 * M * L * NP;
+  if (p->retained || p->lean) {  // every column has its own place in the hand-off arrays and the coefficients
+    if (p->retained) { w.Ym += c0 * M * L * NP * NP; w.Am += c0 * M * L * NP * NP; }  // (lean: Y, A stay windowed)
+    w.kk += c0 * M * L * NP; w.Ek += c0 * M * L * NP;
     w.Bv += c0 * M * L * 2 * NP; w.coef += c0 * M * L * 2 * NP; w.dq += c0 * L * Ns * 2 * NP; w.zneg += c0 * L * NP;
     if (Ns > 0) w.vb += c0 * L * 4 * NP;
   }
@@ -439,6 +448,31 @@ RtdNt window_nt(const rtd_plan* p, int64_t c0) {
   w.wfull += c0 * L * w.nleg_all; w.f += c0 * L; w.ims_coef += c0 * w.nleg_all; w.ims_par += c0 * 2;
   w.R += c0 * 4 * p->d.NP * L;
   return w;
+}
+
+// Lean retained plans: which wavefront chunks of the eigen stage the evaluation points of a column touch.  One thread per
+// column: the layer of every point exactly as the evaluation kernel finds it (rtd_eval.hip: argmax(tau <= tau_arr),
+// _assemble_intensity_and_fluxes.py:185), its slot in the column's layer order lperm, slot / gpw = the chunk; the list
+// sel[c][0 .. nsel) holds each touched chunk once, -1 beyond.
+__global__ void rtd_chunk_select_kernel(RtdDev d, const double* tau, int ntau, int gpw, int nsel, int* sel) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d.C) return;
+  int* out = sel + (long)c * nsel;
+  const double* tau_arr = d.tau + (long)c * d.L;
+  const int* perm = d.lperm + (long)c * d.L;
+  int n = 0;
+  for (int t = 0; t < ntau; ++t) {
+    const double x = tau[(long)c * ntau + t];
+    int l = 0;
+    while (l < d.L - 1 && !(x <= tau_arr[l])) ++l;
+    int slot = 0;
+    while (slot < d.L - 1 && perm[slot] != l) ++slot;
+    const int chunk = slot / gpw;
+    bool have = false;
+    for (int k = 0; k < n; ++k) have = have || out[k] == chunk;
+    if (!have && n < nsel) out[n++] = chunk;
+  }
+  for (int k = n; k < nsel; ++k) out[k] = -1;
 }
 
 // Solve (and optionally evaluate) every window.  after_window(w, c0, cnt) is called once window w's kernels are
@@ -554,6 +588,32 @@ int launch_windows(rtd_plan* p, bool with_solve, const RtdEval* ev, bool with_nt
       mark(5);
       rtd_launch_bc(d, s, 1);
     }
+    if (!with_solve && ev && p->lean && p->nwin > 1) {
+      // Lean retained plan, evaluation only: Y, A of this window's columns are not resident -- the eigen stage is run again for
+      // the wavefront chunks the evaluation points touch (every chunk when the points touch most of them, or for the
+      // one-lane-per-problem kernel of 2 ... 8 streams, whose wavefronts span columns), into hand-off slot 0; k, E, B and the
+      // thermal vectors are rewritten in their retained places with the bits they had; the coefficients are kept: no
+      // boundary-condition solve.  Everything queued on the plan's stream: the solve's eigen stream is behind ev_eig already.
+      if (p->tables_cached && !p->tables_valid) {  // (rtd_plan_invalidate_tables since the solve)
+        RtdDev all = p->d;
+        all.Y0 = p->Y0_all;
+        all.att = p->att_all;
+        rtd_launch_tables(all, s, !p->quad_tables_valid);
+        p->quad_tables_valid = p->tables_valid = true;
+      }
+      RtdDev dsel = d;
+      const int gpw = 64 / d.NP, nchunk = (d.L + gpw - 1) / gpw;
+      const int nsel = d.NP == 4 || 2 * ev->ntau >= nchunk ? 0 : ev->ntau;
+      if (nsel > 0) {
+        int rc = grow(p, &p->sel_buf, &p->cap_sel, ((int64_t)p->Cw * nsel + 1) / 2 + 1);
+        if (rc) return rc;
+        int* sel = reinterpret_cast<int*>(p->sel_buf);
+        hipLaunchKernelGGL(rtd_chunk_select_kernel, dim3((cnt + 127) / 128), dim3(128), 0, s, d, ev->tau + c0 * ev->ntau, ev->ntau, gpw, nsel, sel);
+        dsel.chunk_sel = sel;
+        dsel.nsel = nsel;
+      }
+      rtd_launch_eig(dsel, s, 1);
+    }
     mark(6);
     if (ev) {
       // (a gather of the previous run's results may still be in flight: it reads its own snapshot, not these buffers)
@@ -654,7 +714,7 @@ int rtd_device_count(int32_t* count) {
   return 0;
 }
 
-static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t work_columns, int64_t retain_bytes) {
+static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t work_columns, int64_t retain_bytes, int32_t form) {
   const int N = dims->nquad / 2;
   p->dims = *dims;
   p->device = device;
@@ -711,7 +771,10 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   p->pipelined = p->nwin > 1 && may_pipeline;
   // Retained evaluator state (rtd_plan_create_retained): everything but the boundary-condition workspace for ALL columns, when
   // that fits the caller's budget (< 0: three tenths of the device memory that is free now)
+  // that fits the caller's budget; else (or when the caller asks for it: form 2) the LEAN form: the same without Y, A -- what an
+  // evaluation can recompute from the inputs without solving the boundary-condition system again (see rtd_plan::lean)
   const int64_t retain_col = handoff_col + 8 * (M * L * Q2);  // + coef
+  const int64_t lean_col = retain_col - 8 * (2 * M * L * NP * NP);
   if (p->nwin > 1 && retain_bytes != 0) {
     double cap = (double)retain_bytes;
     if (retain_bytes < 0) {
@@ -720,9 +783,12 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
       HIP_TRY(hipMemGetInfo(&free_b, &total_b));
       cap = 0.3 * (double)free_b;
     }
-    p->retained = (double)C * (double)retain_col <= cap;
+    p->retained = form != 2 && (double)C * (double)retain_col <= cap;
+    // (not below 10 streams: the one-lane-per-problem eigen kernel's wavefronts span columns, and its matrices are 128 bytes)
+    p->lean = !p->retained && form != 1 && NP > 4 && (double)C * (double)lean_col <= cap;
   }
-  const int64_t Ch = p->retained ? C : Cw;  // columns the hand-off arrays and the coefficients cover
+  const int64_t Ch = p->retained || p->lean ? C : Cw;  // columns the coefficients, k, E, B and the thermal vectors cover
+  const int64_t Cy = p->retained ? C : Cw;             // columns Y, A cover
   rtd_plan::HandOff& h1 = p->slot1;
   double *mu = nullptr, *w = nullptr, *invmu = nullptr, *S = nullptr, *T = nullptr, *omega = nullptr, *tau = nullptr,
          *taus0 = nullptr, *scale = nullptr, *wleg = nullptr, *mu0 = nullptr, *I0 = nullptr, *phi0 = nullptr,
@@ -750,13 +816,16 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
     A(bpos, C * M * NP) A(bneg, C * M * NP) A(spoly, C * L * Ns) A(bq, C * NB * NP * NP) A(bq0, C * NB * NP)
     // intermediates: one window of Cw columns
     A(d.Y0, Ch * M * P) A(d.att, Ch * (L + 1))
-    A(d.Ym, Ch * M * L * NP * NP) A(d.Am, Ch * M * L * NP * NP) A(d.kk, Ch * M * L * NP) A(d.Bv, Ch * M * L * Q2)
+    A(d.Ym, Cy * M * L * NP * NP) A(d.Am, Cy * M * L * NP * NP) A(d.kk, Ch * M * L * NP) A(d.Bv, Ch * M * L * Q2)
     A(d.dq, Ch * L * Ns * Q2) A(d.zneg, Ch * L * NP) A(d.vb, Ns > 0 ? Ch * L * 4 * NP : 1) A(d.coef, Ch * M * L * Q2)
     A(d.Fws, Cw * M * (L - 1) * Q2 * Q2) A(d.Ek, Ch * M * L * NP) A(d.need_split, Cw * M)
     A(d.sweeps, 1) A(d.status, 1) A(d.split_any, 1)
     if (p->pipelined && !p->retained) {
-      A(h1.Y0, Cw * M * P) A(h1.att, Cw * (L + 1)) A(h1.Ym, Cw * M * L * NP * NP) A(h1.Am, Cw * M * L * NP * NP)
-      A(h1.kk, Cw * M * L * NP) A(h1.Bv, Cw * M * L * Q2) A(h1.dq, Cw * L * Ns * Q2) A(h1.zneg, Cw * L * NP) A(h1.vb, Ns > 0 ? Cw * L * 4 * NP : 1) A(h1.Ek, Cw * M * L * NP)
+      A(h1.Ym, Cw * M * L * NP * NP) A(h1.Am, Cw * M * L * NP * NP)
+      if (!p->lean) {  // (a lean plan keeps these per column: window_dev)
+        A(h1.Y0, Cw * M * P) A(h1.att, Cw * (L + 1))
+        A(h1.kk, Cw * M * L * NP) A(h1.Bv, Cw * M * L * Q2) A(h1.dq, Cw * L * Ns * Q2) A(h1.zneg, Cw * L * NP) A(h1.vb, Ns > 0 ? Cw * L * 4 * NP : 1) A(h1.Ek, Cw * M * L * NP)
+      }
     }
     if (p->pipelined) {
       A(p->status2[1], 1) A(p->col_status2[1], C) A(p->sweeps2[1], 1)
@@ -778,7 +847,7 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   d.omega = omega; d.tau = tau; d.taus0 = taus0; d.scale = scale; d.wleg = wleg;
   d.mu0 = mu0; d.I0 = I0; d.phi0 = phi0; d.rescale = rescale; d.bpos = bpos; d.bneg = bneg;
   d.spoly = spoly; d.bdrfq = bq; d.bdrfq0 = bq0; d.lperm = lperm;
-  if (p->nwin == 1 || p->retained) {
+  if (p->nwin == 1 || p->retained || p->lean) {
     p->Y0_all = d.Y0;
     p->att_all = d.att;
     p->tables_cached = true;
@@ -800,7 +869,7 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
   }
   HIP_TRY(hipMemsetAsync(d.Bv, 0, (size_t)(reinterpret_cast<char*>(d.dq) - reinterpret_cast<char*>(d.Bv)) + (Ns > 0 ? (size_t)(Ch * L * Ns * Q2) * 8 : 0), p->stream));
   if (p->pipelined) {
-    if (!p->retained) {
+    if (!p->retained && !p->lean) {
       HIP_TRY(hipMemsetAsync(h1.Bv, 0, (size_t)(Cw * M * L * Q2) * 8, p->stream));
       if (Ns > 0) HIP_TRY(hipMemsetAsync(h1.dq, 0, (size_t)(Cw * L * Ns * Q2) * 8, p->stream));
     }
@@ -816,8 +885,14 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
 }
 
 int rtd_plan_create_retained(const rtd_dims* dims, int32_t device, int32_t work_columns, int64_t retain_bytes, rtd_plan** out) {
+  return rtd_plan_create_retained_form(dims, device, work_columns, retain_bytes, 0, out);
+}
+
+int rtd_plan_create_retained_form(const rtd_dims* dims, int32_t device, int32_t work_columns, int64_t retain_bytes, int32_t form,
+                                  rtd_plan** out) {
   if (!dims || !out) return fail(RTD_ERR_ARG, "null argument");
   *out = nullptr;
+  if (form < 0 || form > 2) return fail(RTD_ERR_ARG, "retained form: 0 (full, else lean), 1 (full only) or 2 (lean)");
   const int N = dims->nquad / 2;
   if (dims->ncols < 1 || dims->nlayers < 1 || dims->nquad < 2 || (dims->nquad & 1) || dims->nleg < 1 ||
       dims->nfourier < 1 || dims->nfourier > dims->nleg || dims->nscoeffs < 0 || dims->nbdrf < 0)
@@ -829,7 +904,7 @@ int rtd_plan_create_retained(const rtd_dims* dims, int32_t device, int32_t work_
   if (N > 64) return fail(RTD_ERR_ARG, "NQuad > 128 is not supported by this build (N = NQuad/2 <= 64)");
   HIP_TRY(hipSetDevice(device));
   rtd_plan* p = new rtd_plan();
-  const int rc = plan_build(p, dims, device, work_columns, retain_bytes);
+  const int rc = plan_build(p, dims, device, work_columns, retain_bytes, form);
   if (rc) {
     const std::string keep = g_err;  // rtd_plan_destroy must not lose the message
     rtd_plan_destroy(p);
@@ -846,7 +921,7 @@ int rtd_plan_create_windowed(const rtd_dims* dims, int32_t device, int32_t work_
 
 int rtd_plan_retained(rtd_plan* p, int32_t* retained) {
   if (!p || !retained) return fail(RTD_ERR_ARG, "null argument");
-  *retained = p->nwin == 1 || p->retained ? 1 : 0;
+  *retained = p->nwin == 1 || p->retained ? 1 : p->lean ? 2 : 0;
   return 0;
 }
 
@@ -914,6 +989,15 @@ int rtd_plan_device_bytes(rtd_plan* p, int64_t* bytes) {
 int rtd_pool_trim(int32_t device, int64_t* released) {
   const size_t n = pool().trim(device);
   if (released) *released = (int64_t)n;
+  return 0;
+}
+
+int rtd_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes) {
+  size_t fr = 0, total = 0;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemGetInfo(&fr, &total));
+  if (free_bytes) *free_bytes = (int64_t)fr;
+  if (total_bytes) *total_bytes = (int64_t)total;
   return 0;
 }
 
@@ -1382,7 +1466,7 @@ int rtd_plan_evaluate(rtd_plan* p, int32_t ntau, const double* tau, int32_t nphi
   // one window, or a retained plan (rtd_plan_create_retained): what the evaluators need of the solve is resident for every
   // column, only the evaluation kernels run.  Several windows without retention: they are solved again, window by window,
   // with the evaluation behind each (the throughput form rtd_plan_run is the intended entry point for such batches).
-  const bool solve_again = p->nwin > 1 && !p->retained;
+  const bool solve_again = p->nwin > 1 && !p->retained && !p->lean;
   rc = launch_windows(p, solve_again, &e, p->have_nt && !skip_nt, [](int, int64_t, int) { return 0; }, false);
   if (rc) return rc;
   if (p->pipelined && !solve_again) p->fork_needed = true;  // the next solve's eigen stream must not overwrite what this pass still reads
@@ -1442,6 +1526,15 @@ int rtd_plan_get_tensors(rtd_plan* p, int32_t column, double* GC, double* K, dou
   if (p->nwin > 1 && p->retained) {  // the column's own place in the retained arrays
     d = window_dev(p, column, 1);
     local = 0;
+  } else if (p->nwin > 1 && p->lean) {  // lean: the column's Y, A again (a wavefront of the eigen stage never spans columns from
+    //                                      8 streams up; below, one column on its own is what a one-column plan computes), coefficients kept
+    d = window_dev(p, column, 1);
+    local = 0;
+    if (!p->tables_valid) {
+      rtd_launch_tables(d, s, !p->quad_tables_valid);
+      p->quad_tables_valid = true;
+    }
+    for (int part = 0; part < 3; ++part) rtd_launch_eig(d, s, part);
   } else if (p->nwin > 1) {  // the column is solved again on its own (its window's intermediates may have been overwritten)
     d = window_dev(p, column, 1);
     local = 0;

@@ -27,6 +27,12 @@ struct RtdDev {
   // layer shard of the eigen stage (the north star's "all-gather to stitch the boundary-condition
   // system"): only the layers [l0, l0 + ln) are decomposed by this launch; l0 = 0, ln = L without shards
   int l0, ln;
+  // Chunk selection of the eigen stage (lean retained plans, rtd_api.hip): nsel > 0 -> only the wavefront chunks
+  // chunk_sel[c][0 .. nsel) of column c are decomposed (a chunk = the 64/NP consecutive slots of the layer order lperm that share a
+  // wavefront in the full launch; -1: nothing) -- the layers an evaluation touches, recomputed in the SAME wavefront composition as
+  // the solve had them, hence to the same bits.  nsel = 0: every chunk.
+  const int* chunk_sel;
+  int nsel;
   int flags;  // bit 2: every chain of rtd_bc_mfma_kernel takes the register-resident pivoted elimination (RTD_BC_FORCE_PIVOT=2); bit 1: the tiled fused BC kernel hands every third chain to the pivoted kernels (RTD_BC_FORCE_HANDOVER); bit 0: the fused BC kernel skips its speculative elimination (test hook, env RTD_BC_FORCE_PIVOT)
   // quadrature (padded to NP)
   const double *mu, *w, *invmu, *S, *T;  // S = sqrt(w/mu), T = sqrt(w*mu) (1 for padding)

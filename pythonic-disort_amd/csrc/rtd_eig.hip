@@ -448,10 +448,11 @@ __device__ __forceinline__ ProbId locate(const RtdDev& d, const int tx = threadI
   // One wavefront = the 64/NP consecutive layers of ONE (column, mode): c and m depend on blockIdx only, so
   // they are wave-uniform and the Legendre-table reads (indexed by m and l only) become scalar loads.
   constexpr int GPW = 64 / NP;
-  // layer shard (rtd_plan_solve_layers): only the layers [l0, l0 + ln) are decomposed; ln = L without shards
-  const int nchunk = (d.ln + GPW - 1) / GPW;
+  // layer shard (rtd_plan_solve_layers): only the layers [l0, l0 + ln) are decomposed; ln = L without shards.
+  // chunk selection (lean retained plans): the wavefront takes entry blockIdx % nsel of its column's chunk list
+  const int nchunk = d.nsel > 0 ? d.nsel : (d.ln + GPW - 1) / GPW;
   const long cmi_b = (long)blockIdx.x / nchunk;
-  const int chunk = (int)((long)blockIdx.x % nchunk);
+  int chunk = (int)((long)blockIdx.x % nchunk);
   ProbId p;
   // Workgroups are handed out mode by mode (all columns of mode 0, then of mode 1, ...): the sweep count falls with the Fourier mode
   // (5.8 sweeps at m = 0, 1.8 at m = 31 on cfg4), so the longest problems start first and the launch ends on its shortest ones
@@ -465,7 +466,8 @@ __device__ __forceinline__ ProbId locate(const RtdDev& d, const int tx = threadI
 #endif
   p.mg = d.m0 + d.mstep * p.m;
   const long cmi = (long)p.c * d.M + p.m;
-  const int slot = chunk * GPW + tx / NP;
+  if (d.nsel > 0) chunk = d.chunk_sel[(long)p.c * d.nsel + chunk];  // (wave-uniform) -1: this entry of the list is empty
+  const int slot = chunk < 0 ? d.ln : chunk * GPW + tx / NP;
   p.valid = slot < d.ln;
   const int sl = p.valid ? slot : d.ln - 1;  // invalid groups redo the last slot and skip the stores
   p.l = d.ln == d.L ? d.lperm[(long)p.c * d.L + sl] : d.l0 + sl;
@@ -774,7 +776,9 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
     typedef double v4d __attribute__((ext_vector_type(4)));
     typedef unsigned int u2 __attribute__((ext_vector_type(2)));
     const int tx = threadIdx.x, i16 = tx & 15, k4 = tx >> 4;
-    const int chunk = (int)((long)blockIdx.x % ((d.ln + GPW - 1) / GPW));  // as locate(): layer shards decompose [l0, l0 + ln)
+    int chunk = (int)((long)blockIdx.x % (d.nsel > 0 ? d.nsel : (d.ln + GPW - 1) / GPW));  // as locate(): layer shards decompose [l0, l0 + ln)
+    if (d.nsel > 0) chunk = d.chunk_sel[(long)c * d.nsel + chunk];
+    if (chunk < 0) chunk = (d.ln + GPW - 1) / GPW;  // (an empty entry: every slot past the end, as in locate())
     // "shortcut" (:119): per problem, multiple scattering is switched off when max_l |omega w_l / 2| <= 1e-8
     double cm_ = 0.0;
     for (int ell = id.mg + j; ell < P; ell += NP) cm_ = fmax(cm_, fabs(0.5 * om * wl[ell]));
@@ -1537,7 +1541,8 @@ void rtd_launch_eig(const RtdDev& d, hipStream_t s, int part) {
   // One fused kernel (launched as part 1; parts 0 and 2 are the empty timing slots of the earlier three-kernel form).
   if (part != 1) return;
   const int gpw = 64 / d.NP;
-  const dim3 grid((unsigned)((long)d.C * d.M * ((d.ln + gpw - 1) / gpw)));
+  // (d.nsel > 0: the chunk lists of a lean retained plan's evaluation; the caller leaves it 0 for the one-lane-per-problem kernel)
+  const dim3 grid((unsigned)((long)d.C * d.M * (d.nsel > 0 ? d.nsel : (d.ln + gpw - 1) / gpw)));
   // RTD_EIG_MFMA=1: the assembly of Pm, Qm on the matrix cores (NP = 16; A/B runs and a regression test)
   static const bool mfma = getenv("RTD_EIG_MFMA") != nullptr;
 #ifndef RTD_EIG_LDS_PAD

@@ -12,11 +12,13 @@ def _f64(a):
 
 
 class Plan:
-    def __init__(self, prep, device=0, work_columns=0, retain_bytes=0):
+    def __init__(self, prep, device=0, work_columns=0, retain_bytes=0, retain_form=0):
         """prep: dict from _prepare.prepare_columns.  work_columns: columns whose intermediates are resident at a time
         (0: sized by the library, include/rtd.h: rtd_plan_create_windowed).  retain_bytes: budget for keeping what the
         evaluators need of a solve for ALL columns of a plan of several windows, so that evaluate() does not solve again
-        (include/rtd.h: rtd_plan_create_retained; -1: automatic, 0: never -- the throughput form)."""
+        (include/rtd.h: rtd_plan_create_retained; -1: three tenths of the free device memory, 0: never -- the throughput form).
+        retain_form: 0 the full state, else the lean one (coefficients, k, E, B; Y, A recomputed per evaluation), 1 full only,
+        2 lean (rtd_plan_create_retained_form)."""
         lib = _lib.load()
         self._lib = lib
         self.prep = prep
@@ -25,7 +27,7 @@ class Plan:
         dims = _lib.rtd_dims(prep["C"], prep["L"], 2 * prep["N"], prep["P"], prep["M"], prep["Ns"],
                              prep["NBDRF"], int(prep["beam"]))
         h = C.c_void_p()
-        _lib.check(lib.rtd_plan_create_retained(C.byref(dims), device, int(work_columns), int(retain_bytes), C.byref(h)))
+        _lib.check(lib.rtd_plan_create_retained_form(C.byref(dims), device, int(work_columns), int(retain_bytes), int(retain_form), C.byref(h)))
         self._h = h
         mu, w = _f64(prep["mu"]), _f64(prep["W"])
         _lib.check(lib.rtd_plan_set_quadrature(h, _lib.dptr(mu), _lib.dptr(w)))
@@ -161,6 +163,13 @@ class Plan:
         return b.value
 
     @staticmethod
+    def free_device_bytes(device=0):
+        """Free memory of the device right now (include/rtd.h: rtd_device_memory)."""
+        b = C.c_int64()
+        _lib.check(_lib.load().rtd_device_memory(int(device), C.byref(b), None))
+        return b.value
+
+    @staticmethod
     def pool_set_limit(nbytes=-1, device=0):
         """Opt in to (or out of) keeping the LARGE device blocks of closed plans for the next plan: nbytes per device, < 0 = an
         eighth of the device's memory, 0 = off (the default).  Returns the previous limit (include/rtd.h: rtd_pool_set_limit)."""
@@ -211,6 +220,14 @@ class Plan:
         r = C.c_int32()
         _lib.check(self._lib.rtd_plan_retained(self._h, C.byref(r)))
         return bool(r.value)
+
+    def retained_form(self):
+        """"full" (one window, or everything the evaluators read is resident for every column), "lean" (coefficients, k, E, B
+        resident; evaluate() re-runs the eigen stage for the layers its points touch, never the boundary-condition solve) or
+        None (evaluate() solves the windows again)."""
+        r = C.c_int32()
+        _lib.check(self._lib.rtd_plan_retained(self._h, C.byref(r)))
+        return {0: None, 1: "full", 2: "lean"}[r.value]
 
     def windows(self):
         """(columns per window, number of windows) of the plan's work arena."""

@@ -31,9 +31,11 @@ SIGNATURES = {
     "rtd_version": (C.c_int, []),
     "rtd_last_error": (C.c_char_p, []),
     "rtd_device_count": (C.c_int, [C.POINTER(C.c_int32)]),
+    "rtd_device_memory": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rtd_plan_create": (C.c_int, [C.POINTER(rtd_dims), C.c_int32, C.POINTER(_vp)]),
     "rtd_plan_create_windowed": (C.c_int, [C.POINTER(rtd_dims), C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "rtd_plan_create_retained": (C.c_int, [C.POINTER(rtd_dims), C.c_int32, C.c_int32, C.c_int64, C.POINTER(_vp)]),
+    "rtd_plan_create_retained_form": (C.c_int, [C.POINTER(rtd_dims), C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(_vp)]),
     "rtd_plan_retained": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "rtd_plan_windows": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rtd_plan_destroy": (C.c_int, [_vp]),

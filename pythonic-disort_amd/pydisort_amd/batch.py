@@ -7,6 +7,9 @@ from . import _nt
 from ._prepare import double_gauss, prepare_columns
 
 
+DEFAULT_RETAIN_BYTES = 16 << 30  # pydisort_batch(retain=..., retain_bytes=None): what a call may keep on the device for its evaluators
+
+
 class BatchSolution:
     """Evaluators over all columns; arrays carry a leading column axis."""
 
@@ -43,7 +46,7 @@ class BatchSolution:
 def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLeg=None, NFourier=None,
                    b_pos=0, b_neg=0, only_flux=False, f_arr=0, NT_cor=False, bdrf_q=None, bdrf_q0=None,
                    s_poly_coeffs=None, device=0, bdrf_samples=None, NBDRF=None, mode_shard=None, work_columns=0,
-                   device_prepare=False, numeric_errors="raise", retain="auto", _defer_solve=False):
+                   device_prepare=False, numeric_errors="raise", retain="auto", retain_bytes=None, _defer_solve=False):
     """Like ``pydisort`` with a leading column axis on every atmospheric input:
     tau_arr, omega_arr, f_arr [C, L]; Leg_coeffs_all [C, L, NLeg_all]; mu0, I0, phi0 [C];
     b_pos / b_neg: scalar, [C], [C, N] or [C, N, NFourier]; s_poly_coeffs [C, L, Ns];
@@ -65,9 +68,15 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
     larger than that are solved window by window (include/rtd.h: rtd_plan_create_windowed).
     retain: the returned evaluators keep what they need of the solve for EVERY column -- as the reference's closures keep
     GC_collect, K_collect, B_collect (_assemble_intensity_and_fluxes.py:170-262) -- so that calling them again costs an
-    evaluation, not a solve, also for a batch of several windows (include/rtd.h: rtd_plan_create_retained; 3.1 MB per
-    20-layer 32-stream column).  "auto" (default): while that fits three tenths of the free device memory; an int: that many
-    bytes; False: never (every call of an evaluator on a batch of several windows then solves them again).
+    evaluation, not a solve, also for a batch of several windows (include/rtd.h: rtd_plan_create_retained).  Two forms: "full"
+    (3.1 MB per 20-layer 32-stream column: an evaluator call only evaluates) and "lean" (0.5 MB per such column: coefficients,
+    eigenvalues and particular solutions stay, an evaluator call re-runs the eigen stage -- not the boundary-condition solve -- for
+    the layers its points touch; same bits, about a tenth of a solve for one depth per column; 10 streams and up).  "auto"
+    (default): full while it fits the budget, else lean while that fits, else neither; "full" / "lean": that form or neither;
+    False: never (every call of an evaluator on a batch of several windows then solves them again).
+    retain_bytes: the budget in bytes.  None (default): DEFAULT_RETAIN_BYTES = 16 GiB, and never more than three tenths of the
+    free device memory -- the library is a guest on the GPU; a caller that wants BASELINE's 10^5-column batch retained passes what
+    it is willing to give (50 GB lean).
     All columns share NQuad, NLeg, NFourier and the layer count.  Returns (mu_arr, BatchSolution)."""
     tau_arr = np.atleast_2d(np.asarray(tau_arr, float))
     C, L = tau_arr.shape
@@ -147,15 +156,19 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
         NT_cor = NT_cor and r == 0
     if numeric_errors not in ("raise", "nan"):
         raise ValueError('numeric_errors must be "raise" or "nan".')
-    if retain == "auto":
-        retain_bytes = 0 if _defer_solve else -1  # (the throughput callers drive plan.run() themselves: nothing to keep)
-    elif retain is True:
-        retain_bytes = -1
-    elif retain is False or retain is None:
-        retain_bytes = 0
+    form = {"auto": 0, True: 0, "full": 1, "lean": 2}.get(retain if isinstance(retain, (str, bool)) else "auto")
+    if retain is False or retain is None or (retain == "auto" and _defer_solve):
+        budget = 0  # (the throughput callers drive plan.run() themselves: nothing to keep)
+    elif form is None:
+        raise ValueError('retain must be "auto", "full", "lean", False or a number of bytes.')
+    elif isinstance(retain, (int, np.integer)) and not isinstance(retain, bool):
+        budget = int(retain)  # (an int: that many bytes, the round-5 spelling of retain_bytes)
     else:
-        retain_bytes = int(retain)
-    plan = Plan(prep, device=device, work_columns=work_columns, retain_bytes=retain_bytes)
+        budget = DEFAULT_RETAIN_BYTES if retain_bytes is None else int(retain_bytes)
+        if budget > 0:
+            free = Plan.free_device_bytes(device)
+            budget = max(1, min(budget, int(0.3 * free))) if retain_bytes is None else budget
+    plan = Plan(prep, device=device, work_columns=work_columns, retain_bytes=budget, retain_form=form or 0)
     plan.numeric_errors = numeric_errors
     if bdrf_samples is not None:
         plan.set_bdrf_samples(bdrf_samples[0], bdrf_samples[1] if np.any(I0 > 0) else None)
