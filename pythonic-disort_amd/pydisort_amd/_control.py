@@ -27,7 +27,11 @@ class ControlError(RuntimeError):
 def rendezvous_key(environ=None):
     """The name ranks of one launch share: MASTER_PORT (unique per launch on a node) + the elastic run id when there is one."""
     e = os.environ if environ is None else environ
-    return f"rtd-ctl-{e.get('MASTER_ADDR', '127.0.0.1')}-{e.get('MASTER_PORT', '0')}-{e.get('TORCHELASTIC_RUN_ID', 'none')}"
+    # a per-launch nonce on top: bench.py's launcher gives its ranks a run directory of their own (RTD_BENCH_RUN_DIR); without a
+    # MASTER_PORT the launcher's pid stands in (the ranks of one launch share a parent), so two launches on a node never meet
+    nonce = os.path.basename(e.get("RTD_BENCH_RUN_DIR", "")) or "none"
+    port = e.get("MASTER_PORT") or f"ppid{os.getppid()}"
+    return f"rtd-ctl-{e.get('MASTER_ADDR', '127.0.0.1')}-{port}-{e.get('TORCHELASTIC_RUN_ID', 'none')}-{nonce}"
 
 
 def _address(key):
@@ -82,22 +86,37 @@ class ControlPlane:
             ls.bind(addr)
             ls.listen(self.world)
             self._listener = ls
-            while len(self.peers) < self.world - 1:
-                left = deadline - time.monotonic()
-                missing = sorted(set(range(1, self.world)) - set(self.peers))
-                if left <= 0:
-                    raise ControlError(f"control plane: ranks {missing} of {self.world} never joined within {self.timeout:.0f} s")
-                r, _, _ = select.select([ls], [], [], min(left, 1.0))
-                if not r:
-                    continue
-                c, _ = ls.accept()
-                hello = _recv(c, deadline, "hello")
-                if hello.get("world") != self.world or not (0 < hello.get("rank", -1) < self.world) or hello["rank"] in self.peers:
+            try:
+                while len(self.peers) < self.world - 1:
+                    left = deadline - time.monotonic()
+                    missing = sorted(set(range(1, self.world)) - set(self.peers))
+                    if left <= 0:
+                        raise ControlError(f"control plane: ranks {missing} of {self.world} never joined within {self.timeout:.0f} s")
+                    r, _, _ = select.select([ls], [], [], min(left, 1.0))
+                    if not r:
+                        continue
+                    c, _ = ls.accept()
+                    # a connection that says nothing for 5 s, hangs up, or says something that is not a rank of this run (any local
+                    # process can connect to the socket) is dropped; the join goes on and ends on its own deadline, naming who is missing
+                    try:
+                        hello = _recv(c, min(deadline, time.monotonic() + 5.0), "hello")
+                        ok = isinstance(hello, dict) and hello.get("world") == self.world and isinstance(hello.get("rank"), int) \
+                            and 0 < hello["rank"] < self.world and hello["rank"] not in self.peers
+                    except (TimeoutError, ConnectionError, ValueError, struct.error, UnicodeDecodeError):
+                        ok = False
+                    if not ok:
+                        c.close()
+                        continue
+                    self.peers[hello["rank"]] = c
+                for c in self.peers.values():
+                    _send(c, {"joined": self.world})
+            except BaseException:
+                for c in self.peers.values():
                     c.close()
-                    raise ControlError(f"control plane: unexpected hello {hello} (this run has {self.world} ranks)")
-                self.peers[hello["rank"]] = c
-            for c in self.peers.values():
-                _send(c, {"joined": self.world})
+                self.peers = {}
+                ls.close()
+                self._listener = None
+                raise
         else:
             while True:
                 s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)

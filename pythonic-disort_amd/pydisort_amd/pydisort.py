@@ -22,7 +22,10 @@ from ._prepare import double_gauss, prepare_columns
 # stream) and the quadrature upload are a third of a one-column call's latency.  A plan is never shared: it is handed out
 # when no closure of an earlier call refers to it any more (CPython frees the closures of `res = pydisort(...)` as soon as `res` is
 # rebound), holds at most _IDLE_MAX plans, and a plan that was closed by hand is dropped.
-_IDLE, _IDLE_LOCK, _IDLE_MAX = {}, threading.Lock(), 8
+# The lock is re-entrant and nothing is allocated while it is held: _release runs from _Closures.__del__, which the cyclic garbage
+# collector may call on this very thread while another _release / _plan_for is inside the lock (round-5 advice).
+_IDLE, _IDLE_LOCK, _IDLE_MAX = {}, threading.RLock(), 8
+_IDLE_COUNT = [0]  # plans in _IDLE (kept as a counter: no generator under the lock)
 
 
 def _plan_for(prep, device):
@@ -31,6 +34,8 @@ def _plan_for(prep, device):
         with _IDLE_LOCK:
             lst = _IDLE.get(key)
             plan = lst.pop() if lst else None
+            if plan is not None:
+                _IDLE_COUNT[0] -= 1
         if plan is None:
             break
         if getattr(plan, "_h", None):
@@ -52,10 +57,24 @@ def _release(plan):
     if not getattr(plan, "_h", None):
         return
     key = getattr(plan, "_idle_key", None)
-    with _IDLE_LOCK:
-        if key is not None and sum(len(v) for v in _IDLE.values()) < _IDLE_MAX:
-            _IDLE.setdefault(key, []).append(plan)
-            return
+    if key is not None:
+        with _IDLE_LOCK:
+            lst = _IDLE.get(key)
+            if _IDLE_COUNT[0] < _IDLE_MAX and lst is not None:
+                lst.append(plan)
+                _IDLE_COUNT[0] += 1
+                return
+        if lst is None:  # first plan of this shape: the list is made outside the lock, then published under it
+            fresh = [plan]
+            with _IDLE_LOCK:
+                if _IDLE_COUNT[0] < _IDLE_MAX and key not in _IDLE:
+                    _IDLE[key] = fresh
+                    _IDLE_COUNT[0] += 1
+                    return
+                if _IDLE_COUNT[0] < _IDLE_MAX:
+                    _IDLE[key].append(plan)
+                    _IDLE_COUNT[0] += 1
+                    return
     plan.close()
 
 
@@ -211,7 +230,11 @@ def pydisort(
                       " (this excludes the zeroth index coefficient which must be 1) which may cause numerical instability.")
 
     plan = _plan_for(prep, device)
-    plan.solve()
+    try:
+        plan.solve()
+    except BaseException:  # a plan whose solve could not even be queued is not handed to the next call: closed here, not left to __del__
+        plan.close()
+        raise
     sol = _Closures(plan, prep, tau_arr, NFourier, beam, mu0, I0)
 
     if only_flux:

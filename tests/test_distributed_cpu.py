@@ -14,6 +14,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 import tempfile
 
 import numpy as np
@@ -108,6 +109,67 @@ def test_a_rank_that_leaves_or_falls_out_of_step_is_named(how, expect):
     for p in procs:
         p.join(timeout=30)
     assert expect in got[0], got
+
+
+def _stray_then_join(key, q):
+    """A local process that is not a rank of the run: connects and says nothing, connects and says nonsense, connects as a rank
+    of a different world -- then the real rank 1 joins."""
+    import socket
+    import struct
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "pythonic-disort_amd")]
+    from pydisort_amd import _control
+    addr = _control._address(key)
+    deadline = time.time() + 20
+    strays = []
+    while time.time() < deadline:
+        s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        try:
+            s.connect(addr)
+            strays.append(s)
+            break
+        except (FileNotFoundError, ConnectionRefusedError):
+            s.close()
+            time.sleep(0.02)
+    silent = strays[0]                                        # never says hello
+    junk = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    junk.connect(addr)
+    junk.sendall(struct.pack("<I", 5) + b"\xff\xfenot")       # not JSON
+    other = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    other.connect(addr)
+    _control._send(other, {"rank": 1, "world": 7})            # a rank of some other run
+    ctl = _control.ControlPlane(1, 2, key=key, timeout=30)
+    q.put(("joined", ctl.allreduce(5, "sum")))
+    ctl.close()
+    for s in (silent, junk, other):
+        s.close()
+
+
+def test_stray_connections_do_not_stall_or_abort_the_join():
+    """round-5 advice: rank 0 used to block on the first connection's hello and to abort the run on a malformed one.  A silent
+    connection, a garbage one and a hello of another world are dropped (the silent one after 5 s); the real rank joins."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "pythonic-disort_amd")]
+    from pydisort_amd import _control
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    key = f"rtd-test-{os.getpid()}-{_free_port()}"
+    p = ctx.Process(target=_stray_then_join, args=(key, q))
+    p.start()
+    t0 = time.time()
+    ctl = _control.ControlPlane(0, 2, key=key, timeout=30)
+    assert ctl.allreduce(3, "sum") == 8
+    assert q.get(timeout=30) == ("joined", 8)
+    ctl.close()
+    p.join(timeout=30)
+    assert p.exitcode == 0 and time.time() - t0 < 25
+
+
+def test_two_launches_without_a_master_port_do_not_share_a_rendezvous():
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "pythonic-disort_amd")]
+    from pydisort_amd import _control
+    a = _control.rendezvous_key({"RTD_BENCH_RUN_DIR": "/tmp/rtd_bench_run_aaa"})
+    b = _control.rendezvous_key({"RTD_BENCH_RUN_DIR": "/tmp/rtd_bench_run_bbb"})
+    assert a != b and f"ppid{os.getppid()}" in a
+    assert _control.rendezvous_key({"MASTER_PORT": "29500"}) == _control.rendezvous_key({"MASTER_PORT": "29500"})
 
 
 def test_ranks_that_never_join_are_listed():
