@@ -60,11 +60,11 @@ def algorithmic_flops(nlayers=L, nquad=NQUAD, nmodes=None, ntau=NTAU):
 
 
 def measured_traffic(kernel, columns_per_launch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this round (profiles/r05_pmc_traffic.json:
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this round (profiles/r06_pmc_traffic.json:
     FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as read; separate passes), or None when that file was taken at
     another window size than this run's."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")) as f:
             rec = json.load(f)
         if int(rec.get("columns_per_launch", 0)) != int(columns_per_launch):
             return None
@@ -78,14 +78,14 @@ def north_star_evidence(columns_per_launch, seconds_per_window, live=None):
     path is compute-bound) of all kernels of a window from the committed PMC passes over this run's time per
     window, and the matrix-pipe / vector-issue busy fractions of the two main kernels from the same passes."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")) as f:
             rec = json.load(f)
         if int(rec.get("columns_per_launch", 0)) != int(columns_per_launch):
             return None
         total = float(sum(live.values())) if live else float(rec["total_hbm_bytes_per_step"])
         out = {"hbm_bytes_per_window": total, "traffic_measured_in_this_run": bool(live), "hbm_GB_per_s": total / seconds_per_window / 1e9,
                "frac_of_8_TB_per_s": total / seconds_per_window / 8e12,
-               "what": "measured traffic (FETCH_SIZE x 2 + WRITE_SIZE of every kernel of a window, profiles/r05_pmc_traffic.json) / "
+               "what": "measured traffic (FETCH_SIZE x 2 + WRITE_SIZE of every kernel of a window, profiles/r06_pmc_traffic.json) / "
                        "this run's time per window; NOT algorithmic bytes (22.5 KB per column: 0.003 % of 8 TB/s)"}
         for k, name in (("rtd_eigen_kernel", "eigen"), ("rtd_bc_mfma_kernel", "bc")):
             v = rec["kernels"][k]
@@ -169,10 +169,10 @@ def cpu_baseline(seconds=20.0, min_cols=16):
                sample=f"{done} cfg4 columns (L=20, NQuad=32, 32 Fourier modes, u at 21 tau x 3 phi + fluxes), "
                       f"{len(cpus)} processes pinned one per physical core x 1 BLAS thread, {wall:.1f} s")
     try:  # ratio oracle / reference on identical hardware and inputs, measured in the build container
-        with open(os.path.join(ROOT, "profiles", "r02_cpu_calibration.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "archive", "r02_cpu_calibration.json")) as f:
             cal = json.load(f)
         out["calibration"] = dict(r=cal["r"], meaning="oracle rate / reference (PythonicDISORT) rate, same inputs, same core",
-                                  source="profiles/r02_cpu_calibration.json (tools/calibrate_cpu_baseline.py)")
+                                  source="profiles/archive/r02_cpu_calibration.json (tools/calibrate_cpu_baseline.py)")
     except Exception:
         pass
     return out
@@ -1267,7 +1267,7 @@ def run_rank(a, rank, world, local):
             roof["traffic"] = live_main.get(tkey) if live_main and tkey in live_main else measured_traffic(tkey, a.columns)
             roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation (child process, "
                                       "32 windows, windows one after the other)" if live_main and tkey in live_main else
-                                      "profiles/r05_pmc_traffic.json (committed passes)")
+                                      "profiles/r06_pmc_traffic.json (committed passes)")
             if live_main:
                 roof["traffic_all_kernels_per_window"] = float(sum(live_main.values()))
                 ok_ = roof.get("other_kernel")

@@ -265,7 +265,7 @@ struct rtd_plan {
   // Window pipeline (plans of more than one window): the hand-off buffers of the eigen stage exist twice, and the tables +
   // eigen kernel of window w + 1 run on eig_stream while the boundary-condition + evaluation kernels of window w run on
   // `stream`.  The eigen kernel is bound by vector-instruction issue, the boundary-condition kernel by the latency of its
-  // dependent chains: wavefronts of both kinds resident on a SIMD fill each other's bubbles (profiles/r03_window_pipeline.json).
+  // dependent chains: wavefronts of both kinds resident on a SIMD fill each other's bubbles (profiles/archive/r03_window_pipeline.json).
   struct HandOff { double *Y0, *att, *Ym, *Am, *kk, *Bv, *dq, *zneg, *Ek, *vb; } slot1{};
   // Legendre tables at -mu0 and beam attenuations of ALL columns, kept from run to run (they depend on the inputs and the
   // mode shard only): one launch after the inputs change instead of one per window and run (19 us of 1.17 ms per 256-column
@@ -873,7 +873,7 @@ static int plan_build(rtd_plan* p, const rtd_dims* dims, int32_t device, int32_t
       HIP_TRY(hipMemsetAsync(h1.Bv, 0, (size_t)(Cw * M * L * Q2) * 8, p->stream));
       if (Ns > 0) HIP_TRY(hipMemsetAsync(h1.dq, 0, (size_t)(Cw * L * Ns * Q2) * 8, p->stream));
     }
-    // (stream priorities either way changed nothing: profiles/r03_experiments.json)
+    // (stream priorities either way changed nothing: profiles/archive/r03_experiments.json)
     p->eig_stream = pool().get_stream(device);
     if (!p->eig_stream) HIP_TRY(hipStreamCreateWithFlags(&p->eig_stream, hipStreamNonBlocking));
     for (hipEvent_t* e : {&p->ev_eig[0], &p->ev_eig[1], &p->ev_bc[0], &p->ev_bc[1], &p->ev_fork})

@@ -666,7 +666,7 @@ __global__ __launch_bounds__(64, 4) void rtd_bc_mfma_kernel(RtdDev d) {
   // the environment): the chains read the eigen stage's hand-off of only 32 chains (bit 0: 2.6 MB, served by the L2s) or of
   // 2 048 chains (bit 1: 168 MB, served by the Infinity Cache); with both bits the factors H, s, rho_b of the forward sweep
   // are aliased to 32 chains as well.  What the kernel takes then is the floor that any scheme for cutting its HBM traffic
-  // can approach (profiles/r03_experiments.json: bc_traffic_floor).
+  // can approach (profiles/archive/r03_experiments.json: bc_traffic_floor).
   const long cmr = (RTD_BC_ALIAS_EXPERIMENT & 1) ? cm % 32 : (RTD_BC_ALIAS_EXPERIMENT & 2) ? cm % 2048 : cm;
   const long cmw = ((RTD_BC_ALIAS_EXPERIMENT & 3) == 3) ? cm % 32 : cm;
 #else

@@ -15,7 +15,7 @@ namespace {
 // Fused boundary-condition kernel for 2 ... 16 streams (NP = 4, 8; round 4): what rtd_iface_kernel + rtd_sweep_kernel +
 // the evaluation kernel did in three launches with Wp, Wq, S through HBM, in one.  NP lanes per (column, mode) chain, 64/NP
 // chains per wavefront, lane j = row j of the carry system (the elimination is GjStep, as in rtd_sweep_kernel).  Measured on
-// cfg3 (8 layers, 16 streams, 1 024 columns; profiles/r04_small_stream_path.json): the interface kernel was HBM-bound (310 MB
+// cfg3 (8 layers, 16 streams, 1 024 columns; profiles/archive/r04_small_stream_path.json): the interface kernel was HBM-bound (310 MB
 // in 65 us), the sweep kernel a chain of memory latencies (every layer waited for Wp, Wq right after asking for them; 2
 // wavefronts per SIMD: 121 us whatever the batch), the evaluation kernel read Y, A of every point's layer again (92 us).
 // Here:

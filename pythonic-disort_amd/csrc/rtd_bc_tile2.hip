@@ -7,7 +7,7 @@
 //   rtd_bc_tile_kernel<2> keeps six operand matrices in registers (layers l, l + 1 and the prefetch of l + 2: 192 of its 472
 //   VGPRs), the inputs of the running elimination in a 17 KB LDS save area (read back only when the speculation fails) and the
 //   chain's small vectors in an 18 KB LDS window: ONE wavefront per SIMD, whose dependency stalls nothing hides (VALU issue
-//   30 % + matrix pipe 22 % of the SIMD cycles, profiles/r03_pmc_traffic_cfg5.json), and no room for an eigen-stage wavefront
+//   30 % + matrix pipe 22 % of the SIMD cycles, profiles/archive/r03_pmc_traffic_cfg5.json), and no room for an eigen-stage wavefront
 //   of the next window beside it.  Here no operand matrix lives across an elimination in more than 64 registers, and a failed
 //   speculation RECOMPUTES its inputs -- from the H, s of the layer above, which the forward sweep stores anyway -- and eliminates
 //   them again with column pivoting IN REGISTERS (GjPivT): no save area.  <= 256 VGPRs and 20 KB of LDS: two chains per SIMD

@@ -54,7 +54,7 @@ __device__ __forceinline__ double readlane_f64(const double v, const int lane) {
 // k-step's operands in flight while this one's are used.  (The first version was a row-per-lane FMA loop whose uniform factors
 // came through scalar loads: the same 64 multiply-adds per instruction slot -- FP64 MFMA and FMA share the DP ALUs -- but eighty
 // SGPRs hold ONE row of operands, and the kernel waited for scalar loads five cycles in six: 4.9 against 2.65 ms per 76 800
-// interfaces, profiles/r04_pmc_many_streams.txt.)  Workgroups go to the eight XCDs round robin and every XCD has its own L2: the two
+// interfaces, profiles/archive/r04_pmc_many_streams.txt.)  Workgroups go to the eight XCDs round robin and every XCD has its own L2: the two
 // halves of an interface (same A_l, Y_l) and the neighbouring interfaces of a chain (Y', A' of one are Y_l, A_l of the next) are
 // made to meet in ONE L2 by giving XCD x the x-th contiguous eighth of the work items (the grid is rounded up to a multiple of
 // eight workgroups; work items beyond the last interface leave at once).  rho rides along in the first wavefront of an interface.

@@ -725,7 +725,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
   // the wavefront's two problems), their coefficients and the beam factors, staged by coalesced loads that are all in
   // flight together.  Read as scalar loads inside the loop (the form that suits 3 wavefronts per SIMD at NP <= 16) every
   // row cost a full memory latency at 2 wavefronts per SIMD: the two assembly loops were 35 % of the kernel's time at
-  // low Fourier modes (s_memtime stamps, -DRTD_EIG_STAMPS, profiles/r03_eigen32_phases.txt).
+  // low Fourier modes (s_memtime stamps, -DRTD_EIG_STAMPS, profiles/archive/r03_eigen32_phases.txt).
   constexpr int TROWS = NP == 32 ? 32 : 1;
   __shared__ double sTab[NP == 32 ? TROWS * NP : 1];
   __shared__ double sCoef[NP == 32 ? GPW * TROWS : 1];
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(64, (NP <= 16 ? RTD_EIGEN_WAVES : NP == 32 ? RTD_EI
   const double invmu_j = d.invmu[j], S_j = d.S[j];
   if constexpr (JV == 3 && NP == 16) {
     // Assembly on the matrix cores (the north star's "MFMA for the batched dense GEMMs in matrix assembly"); RTD_EIG_MFMA=1.
-    // Measured (profiles/r02_eigen_mfma_assembly.json, same box): 2.346 G VALU instructions per launch instead of 2.421 G,
+    // Measured (profiles/archive/r02_eigen_mfma_assembly.json, same box): 2.346 G VALU instructions per launch instead of 2.421 G,
     // SQ_VALU_MFMA_BUSY_CYCLES 0.42 G, kernel 5.48 ms instead of 5.17 ms: the four dependent MFMA per accumulator and the
     // lane-row transposes behind them sit on the critical path of a kernel that was not short of issue slots there.  Kept as
     // a selectable, tested variant; not the default.

@@ -8,7 +8,7 @@
 // sweeps): at 32 streams that is what keeps an eigenproblem in registers.  At NP = 8 the per-step overhead that does not
 // shrink with NP -- the rotation parameters (~28 instructions, computed by both lanes of a pair), the cross-lane moves, the
 // convergence votes -- is most of a step: 3 100 vector instructions per wavefront of 8 problems, VALU issue 86-88 % of the SIMD
-// cycles (profiles/r04_small_stream_path.json): issue-bound at 387 instructions per problem.  Here a lane owns a whole
+// cycles (profiles/archive/r04_small_stream_path.json): issue-bound at 387 instructions per problem.  Here a lane owns a whole
 // problem: an 8 x 8 matrix is 64 registers, every loop is compile-time, nothing crosses lanes, symmetric matrices are packed
 // (36 entries), a rotation's parameters are computed once per pair, and the table rows Ybar_l^m(mu_i) are wave-uniform scalar
 // loads (a wavefront takes ONE Fourier mode and 64 (column, layer) pairs; that also keeps the spread of the sweep counts inside

@@ -111,7 +111,7 @@ def test_truth_with_nakajima_tanaka_terms_agrees_with_the_reference_on_the_well_
 def test_arbiter_agrees_with_the_reference_itself_on_well_conditioned_goldens(name):
     """The 40-digit machinery against outputs the builder did not write: PythonicDISORT's own captured results
     (tests/golden/ref, made by importing the reference in the build container).  tools/arbiter_check.py does this for every
-    captured call of all golden cases (profiles/r04_arbiter_vs_reference.json: 34 cases within 8e-11 of the reference, the other
+    captured call of all golden cases (profiles/archive/r04_arbiter_vs_reference.json: 34 cases within 8e-11 of the reference, the other
     seven are the omega = 1 - 1e-6 / conservative test problems where the reference's float64 result is itself at 1e-9 ... 4e-8);
     four quick ones here: isotropic beam case, the 6-layer mixed-source case, a thermal case, a BDRF flux-only case."""
     import importlib.util

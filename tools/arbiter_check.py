@@ -12,7 +12,7 @@ returned:
 Well-conditioned calls must agree to ~1e-12 (two float64-vs-40-digit roundoff levels); where they do not, the case is one of
 the near-conservative / 8ARTS ones whose float64 conditioning the docs discuss, and the number is printed as it is.
 
-Writes profiles/r04_arbiter_vs_reference.json.  Usage (build container, ~1 h on 6 processes):
+Writes profiles/archive/r04_arbiter_vs_reference.json.  Usage (build container, ~1 h on 6 processes):
     python3 tools/arbiter_check.py [--budget-seconds 3600] [case ...]
 """
 import json
@@ -28,7 +28,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")]
 import goldens  # noqa: E402
 import hp_truth_case as H  # noqa: E402
 
-OUT = os.path.join(ROOT, "profiles", "r04_arbiter_vs_reference.json")
+OUT = os.path.join(ROOT, "profiles", "archive", "r04_arbiter_vs_reference.json")
 
 
 def _one(job):

@@ -5,7 +5,7 @@ bench.py times the oracle (oracle/disort_oracle.py, the NumPy/SciPy restatement 
 box's host cores, because the reference itself cannot travel there.  This script runs in the BUILD container, where
 /root/reference is present: the oracle and the reference (PythonicDISORT.pydisort) solve the same seeded cfg4 columns on
 the same core, one BLAS thread, interleaved column by column; the ratio of their rates goes to
-profiles/r02_cpu_calibration.json, which bench.py copies into its cpu_baseline object ("calibration").
+profiles/archive/r02_cpu_calibration.json, which bench.py copies into its cpu_baseline object ("calibration").
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python3 tools/calibrate_cpu_baseline.py [columns]
 """
@@ -58,7 +58,7 @@ def main(ncols):
                         "same core, reference and oracle interleaved",
                host=dict(cpus=os.cpu_count(), numpy=np.__version__),
                meaning="r = oracle rate / reference rate: cpu_baseline.value / r is what the reference would do on the GPU box's cores")
-    path = os.path.join(ROOT, "profiles", "r02_cpu_calibration.json")
+    path = os.path.join(ROOT, "profiles", "archive", "r02_cpu_calibration.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))

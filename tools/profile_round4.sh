@@ -14,7 +14,7 @@ unset RTD_NO_PIPELINE
 RTD_EXTRA_PMC="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES" bash tools/profile_pmc.sh prof_r4_cfg5 python3 tools/profile_config.py cfg5 128 0 2 > gpurun_out/prof_r4_cfg5.txt 2>&1
 RTD_BC_TILE_V1=1 bash tools/profile_pmc.sh prof_r4_cfg5_v1 python3 tools/profile_config.py cfg5 128 0 2 > gpurun_out/prof_r4_cfg5_v1.txt 2>&1
 python bench.py --steps 20 --warmup 5 > gpurun_out/r04_bench_prof.json 2> gpurun_out/r04_bench_prof.err
-#  d) the 66 ... 128-stream path (profiles/r04_many_streams.json, r04_many_stream_kernel_stats.csv, r04_pmc_many_streams.txt):
+#  d) the 66 ... 128-stream path (profiles/archive/r04_many_streams.json, r04_many_stream_kernel_stats.csv, r04_pmc_many_streams.txt):
 #     stage times with the round's kernels and with the row-per-lane BC kernels, kernel stats and counters of 24 columns of 128 x 50 x 64
 python tools/many_stream_timing.py 24 > gpurun_out/many_stream_new.txt 2>&1
 RTD_BC_WIDE_V1=1 python tools/many_stream_timing.py 24 > gpurun_out/many_stream_v1.txt 2>&1
