@@ -45,11 +45,14 @@ for pl in range(nplans):
     wc = int(rng.choice([0, 1, max(1, C // 3), max(1, C // 2), C]))
     raw = bool(rng.random() < 0.5)
     th, bc = bool(rng.random() < 0.4), bool(rng.random() < 0.4)
-    tag = f"plan {pl}: NQuad {NQuad} C {C} L {L} M {M} work_columns {wc} raw {raw}"
+    # round 6: the long-lived plan in a retained form (full / lean: evaluations after a run read retained state, the lean form
+    # re-runs the eigen stage for the chunks the points touch); the fresh plan it is compared with never is
+    retain = (False, "full", "lean")[int(rng.integers(0, 3))]
+    tag = f"plan {pl}: NQuad {NQuad} C {C} L {L} M {M} work_columns {wc} raw {raw} retain {retain}"
     try:
         cfg = make_inputs(rng, C, L, NQuad, th, bc)
         cfg["NFourier"] = M
-        _, sol = pydisort_amd.pydisort_batch(work_columns=wc, device_prepare=raw, _defer_solve=True, **cfg)
+        _, sol = pydisort_amd.pydisort_batch(work_columns=wc, device_prepare=raw, retain=retain, _defer_solve=True, **cfg)
         plan = sol.plan
         tau, phi = points(rng, cfg, True)
         have_points = False
