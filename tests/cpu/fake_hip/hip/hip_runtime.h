@@ -65,6 +65,15 @@ inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return hipSuccess; }
 
+// inter-process handles do not exist here: the tests' stand-in transport (tests/stub/rccl_stub.cpp), built against this header for
+// the CPU, finds its IPC probe failing and stages through shared memory instead
+typedef struct { char reserved[64]; } hipIpcMemHandle_t;
+enum { hipIpcMemLazyEnablePeerAccess = 1 };
+inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t*, void*) { return hipErrorInvalidValue; }
+inline hipError_t hipIpcOpenMemHandle(void**, hipIpcMemHandle_t, unsigned) { return hipErrorInvalidValue; }
+inline hipError_t hipIpcCloseMemHandle(void*) { return hipSuccess; }
+inline hipError_t hipMemGetAddressRange(hipDeviceptr_t*, size_t*, hipDeviceptr_t) { return hipErrorInvalidValue; }
+
 // a kernel of the translation unit itself runs here, one thread after the other (none of rtd_api.hip's kernels synchronises)
 template <typename K, typename... A>
 inline void fake_launch(K kernel, dim3 grid, dim3 block, A... args) {

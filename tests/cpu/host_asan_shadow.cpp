@@ -159,15 +159,23 @@ void rtd_launch_eval(const RtdDev& d, const RtdEval& e, hipStream_t) {
     rd(d.Ym, CML * NP * NP); rd(d.Am, CML * NP * NP); rd(d.kk, CML * NP); rd(d.coef, CML * Q2); rd(d.Bv, CML * Q2);
     if (d.Ns > 0) rd(d.dq, C * L * d.Ns * Q2);
   }
-  if (e.u) wr(e.u, C * Qr * nt * np);
+  // Values that carry the column's identity (its first single-scattering albedo) and the position inside the column's block: a
+  // slot of a gathered array that holds another rank's or another column's results is then a VALUE mismatch in the two-rank
+  // CPU test (tests/test_host_asan.py), not only an address error
+  if (e.u)
+    for (long c = 0; c < C; ++c)
+      for (long k = 0; k < Qr * nt * np; ++k) e.u[c * Qr * nt * np + k] = d.omega[c * L] + 1e-3 * (double)k;
   // self-test of the harness (tests/test_host_asan.py): 32 KB past the end of the window's u, as a wrong window offset or a
   // short evaluation buffer would produce -- the sanitizer must stop the run
   if (e.u && getenv("FAKE_HIP_FAULT") && std::strcmp(getenv("FAKE_HIP_FAULT"), "eval_u_overrun") == 0) wr(e.u + C * Qr * nt * np, 1 << 12);
   if (e.u0) wr(e.u0, C * Qr * nt);
   if (e.ulast) wr(e.ulast, C * Qr * nt);
-  if (e.fup) wr(e.fup, C * nt);
-  if (e.fdn) wr(e.fdn, C * nt);
-  if (e.fdir) wr(e.fdir, C * nt);
+  for (long c = 0; c < C; ++c)
+    for (long k = 0; k < nt; ++k) {
+      if (e.fup) e.fup[c * nt + k] = 2.0 * d.omega[c * L] + 1e-3 * (double)k;
+      if (e.fdn) e.fdn[c * nt + k] = 3.0 * d.omega[c * L] + 1e-3 * (double)k;
+      if (e.fdir) e.fdir[c * nt + k] = 4.0 * d.omega[c * L] + 1e-3 * (double)k;
+    }
   rdi(d.status, 1);
 }
 
