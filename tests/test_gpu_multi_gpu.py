@@ -159,6 +159,31 @@ def test_bench_with_eight_ranks_over_the_stub_transport():
     assert out["config"]["ranks_verified"] == 8 and out["config"]["collective"].startswith("rccl ncclAllGather")
 
 
+def test_bench_under_the_drivers_own_launcher_with_four_ranks_over_the_stub_transport():
+    """The driver's N > 1 command line, verbatim -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- with the GPU data plane underneath (4 rank processes on
+    device 0 over the stand-in transport): the launcher is PyTorch's, its store holds MASTER_PORT, the ranks meet over the socket
+    control plane without importing torch, build a communicator of 4, gather and verify."""
+    pytest.importorskip("torch")
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extras", "--total-columns", "4096"], env=_clean_env(True), capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["steps"] == 2 and out["warmup"] == 1 and out["transport"].startswith("stub:") and out["not_a_rate"] is True
+    assert out["config"]["rccl_nranks"] == 4 and out["config"]["gather_verified"] is True and out["config"]["ranks_verified"] == 4
+    assert out["config"]["global_columns_per_step"] == 4096 and [p["rank"] for p in out["per_rank"]] == [0, 1, 2, 3]
+    assert out["control_plane"].endswith("torch imported: False")
+
+
 def test_bench_verifies_what_it_gathers_before_it_reports():
     """bench.py --gpus 2: the N > 1 line carries gather_verified / ranks_verified = 2 and the compute-only, all-gather and
     root-only rates of the same run (>= 2 devices); a one-rank --force-dist run carries the same fields on any box."""
