@@ -1291,6 +1291,15 @@ def run_rank(a, rank, world, local):
             if ev:
                 out["measured_hbm_and_mfma"] = ev
         out["cpu_baseline"] = cpu
+        if not multi:
+            out["multi_gpu"] = {
+                "this_line": "one GPU; the scaling curve (N = 1, 2, 4, 8 over RCCL / xGMI) is the driver's to measure: python -m torch.distributed.run "
+                             "--nproc-per-node N bench.py --gpus N (or bench.py --gpus N alone: it starts the ranks itself)",
+                "n_rank_data_plane_executed": "with 2, 4 and 8 rank processes on ONE GPU over the tests' stand-in transport (tests/stub/rccl_stub.cpp, "
+                                              "RTD_RCCL_STUB): tests/test_gpu_multi_gpu.py -- all four partitions, bench.py --gpus 8 and the driver's "
+                                              "torch.distributed.run command line end to end, every gathered slot verified bit for bit; evidence "
+                                              "profiles/r06_bench_stub_8ranks.json (transport = stub, not_a_rate = true: never a throughput)",
+                "over_rccl": "one-rank communicator on every box (tests/test_gpu_distributed.py); two-rank tests where two GPUs are visible"}
         out.update(extras)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())

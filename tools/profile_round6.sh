@@ -5,8 +5,9 @@
 #  a) cfg4 headline workload, windows one after the other (RTD_NO_PIPELINE=1): rocprofv3 --kernel-trace --stats per-kernel
 #     averages (they must agree with the HIP-event pass of the bench line) + the --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ busy /
 #     wait counters, FP64 instruction counters)
-#  b) cfg5 (64 streams): the same for 12 windows of 128 columns -- 2 warm-up + 10 measured launches per kernel, so that the
-#     committed summary reproduces the bench line's figure (round-5 verdict: 3 launches incl. the cold one were not a summary)
+#  b) cfg5 (64 streams): the same for the bench line's own workload -- 10^4 columns in 79 windows of 128, three passes: 237 launches
+#     per kernel, long enough for the chip to settle at the clock it sustains -- so that the committed summary reproduces the bench
+#     line's figure (round-5 verdict: 3 launches incl. the cold one were not a summary; a 24-launch run from a cool chip read 4 % fast)
 #  c) the bench line itself
 set -uo pipefail
 cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
@@ -28,7 +29,7 @@ pmc() {  # pmc <outdir under gpurun_out> <log> <program ...>
 }
 export RTD_NO_PIPELINE=1
 step cfg4_serial_profile 1 pmc r06/cfg4_serial $out/cfg4_serial.txt python3 bench.py --no-cpu-baseline --no-extras --no-live-traffic --steps 2 --warmup 1 --total-columns 16384
-step cfg5_profile 1 pmc r06/cfg5 $out/cfg5.txt python3 tools/profile_config.py cfg5 1536 128 1
+step cfg5_profile 1 pmc r06/cfg5 $out/cfg5.txt python3 tools/profile_config.py cfg5 10000 128 2
 unset RTD_NO_PIPELINE
 if [ -s $out/cfg4_serial/pmc1.txt ]; then
   step cfg4_traffic_json 1 python3 tools/pmc_to_json.py $out/pmc_traffic.json "rocprofv3 --pmc passes of tools/profile_round6.sh (cfg4, windows of 256 columns one after the other)" --columns-per-launch 256 $out/cfg4_serial/pmc*.txt
