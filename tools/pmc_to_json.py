@@ -19,7 +19,14 @@ for path in files:
         m = re.match(r"(rtd_\w+) grid=(\d+) vgpr=(\d+) (\{.*\}) n=(\d+)", line)
         if not m:
             continue
-        k = kern.setdefault(m.group(1), {"grid": int(m.group(2)), "launches_averaged": int(m.group(5))})
+        # a kernel launched on several grid sizes in one run (the short last window of a batch): the LARGEST grid -- the full
+        # window -- is the one reported, with its own launch count
+        grid, n = int(m.group(2)), int(m.group(5))
+        k = kern.get(m.group(1))
+        if k is None or grid > k["grid"]:
+            k = kern[m.group(1)] = {**{c: v for c, v in (k or {}).items() if False}, "grid": grid, "launches_averaged": n}
+        elif grid < k["grid"]:
+            continue
         k.update(ast.literal_eval(m.group(4)))
 total = 0.0
 for name, k in kern.items():
