@@ -165,9 +165,14 @@ def pydisort_batch(tau_arr, omega_arr, NQuad, Leg_coeffs_all, mu0, I0, phi0, NLe
         budget = int(retain)  # (an int: that many bytes, the round-5 spelling of retain_bytes)
     else:
         budget = DEFAULT_RETAIN_BYTES if retain_bytes is None else int(retain_bytes)
-        if budget > 0:
-            free = Plan.free_device_bytes(device)
-            budget = max(1, min(budget, int(0.3 * free))) if retain_bytes is None else budget
+        if budget > 0 and retain_bytes is None:
+            # the default never takes more than three tenths of what is free -- asked of the runtime only when the batch is large
+            # enough for it to matter (hipMemGetInfo costs a small call a noticeable fraction of its time)
+            NP = 4
+            while NP < N:
+                NP *= 2
+            if C * NFourier * L * (2 * NP * NP + 8 * NP) * 8 > (256 << 20):
+                budget = max(1, min(budget, int(0.3 * Plan.free_device_bytes(device))))
     plan = Plan(prep, device=device, work_columns=work_columns, retain_bytes=budget, retain_form=form or 0)
     plan.numeric_errors = numeric_errors
     if bdrf_samples is not None:
