@@ -20,6 +20,14 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-save-temps=obj",
          "-Wno-unused-command-line-argument"] + os.environ.get("RTD_EXTRA_FLAGS", "").split()
 HAZARD_CHECK = os.path.join(HERE, "..", "tools", "check_dpp_hazards.py")
+# flags of single translation units: what was measured to pay for that unit's kernels (and only there), plus RTD_EXTRA_FLAGS_<stem>
+# from the environment for A/B builds (tools/build_variant.py)
+PER_SOURCE_FLAGS = {}
+
+
+def _flags_for(src):
+    stem = src.replace(".hip", "")
+    return FLAGS + PER_SOURCE_FLAGS.get(src, []) + os.environ.get("RTD_EXTRA_FLAGS_" + stem, "").split()
 
 
 def _stale(target, deps):
@@ -44,7 +52,7 @@ def _compile(src):
                     os.remove(os.path.join(OBJ_DIR, f))
 
         try:
-            subprocess.run([HIPCC] + FLAGS + ["-c", path, "-o", tmp], check=True, cwd=OBJ_DIR)
+            subprocess.run([HIPCC] + _flags_for(src) + ["-c", path, "-o", tmp], check=True, cwd=OBJ_DIR)
             # the kernels update registers with v_fmac_f64_dpp from inline asm: the compiler's hazard recogniser cannot
             # see those writes, so the generated ISA is scanned for a DPP read that follows one too closely
             dev_asm = [os.path.join(OBJ_DIR, f) for f in os.listdir(OBJ_DIR)
