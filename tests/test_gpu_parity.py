@@ -1029,6 +1029,13 @@ def test_alternative_kernel_paths_stay_correct(switch):
                               + (" or beyond_64 or random_128 or random_many" if switch == "RTD_BC_WIDE_V1" else "")],
                        env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    if switch in ("RTD_EIG_MFMA", "RTD_NO_PIPELINE", "RTD_BC_TILE_V1", "RTD_BC_WIDE_V1"):
+        # round 6: the retained forms under the switches that change the eigen stage (RTD_EIG_MFMA has its own reading of the lean
+        # form's chunk lists), the window pipeline, or the consumers of the hand-off at 64 / 96 streams
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                            os.path.join(os.path.dirname(__file__), "test_gpu_retained.py"), "-k", "windowed_plan or lean_plan or auto_retention"],
+                           env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu
