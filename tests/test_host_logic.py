@@ -48,6 +48,27 @@ def test_stub_transport_is_test_infrastructure_with_the_entry_points_librtd_bind
     assert "RTD_RCCL_STUB" not in open(os.path.join(ROOT, "__graft_entry__.py")).read()
 
 
+def test_header_is_plain_c_and_the_c_example_links():
+    """include/rtd.h is the drop-in boundary: plain C (C99, -pedantic -Werror), usable without C++ or Python -- and
+    examples/solve_columns.c, a whole solve driven from C, compiles against it and links to librtd.so (it runs on the GPU box:
+    tests/test_gpu_c_example.py)."""
+    import shutil
+    import subprocess
+    import tempfile
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    libdir = os.path.join(ROOT, "pythonic-disort_amd", "pydisort_amd")
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "t.c"), "w") as f:
+            f.write('#include "rtd.h"\nint main(void) { rtd_dims d; rtd_inputs in; (void)d; (void)in; return rtd_version() > 0 ? 0 : 1; }\n')
+        subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(d, "t.c")], check=True)
+        subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-O2", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "solve_columns.c"), os.path.join(libdir, "librtd.so"), "-lm", "-Wl,-rpath," + libdir,
+                        "-o", os.path.join(d, "solve_columns")], check=True)
+
+
 def test_product_never_imports_oracle_or_reference():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "pythonic-disort_amd")):
         for f in files:
