@@ -629,6 +629,43 @@ def all_cloud_leg(device, columns=16384, window=256, passes=3):
                                                         "note": "the float64 oracle (= the reference's algorithm) on the same two columns"}}}
 
 
+def lean_retention_leg(device, cfg):
+    """Evaluators that outlive the solve on the headline batch itself (round-5 verdict, item 6): the lean retained form keeps the
+    boundary-condition coefficients, k, E, B and the thermal vectors of EVERY column (0.5 MB per cfg4 column; the full evaluator
+    state would be 3.1 MB: 310 GB for 10^5 columns) and re-runs the eigen stage -- never the boundary-condition solve -- for the
+    layers a requested depth touches.  Timed: the solve of the batch, then `sol.u(tau, phi)` at ONE non-interface depth per column;
+    checked: bit-identity with a full-retention plan on a slice of the batch.  The reference's closures re-evaluate from
+    GC_collect, K_collect, B_collect (_assemble_intensity_and_fluxes.py:170-262)."""
+    import pydisort_amd
+    C = cfg["tau_arr"].shape[0]
+    rng = np.random.default_rng(17)
+    tau = rng.uniform(0.02, 0.98, (C, 1)) * cfg["tau_arr"][:, -1:]
+    phi = np.array([0.5, 2.0])
+    _, sol = pydisort_amd.pydisort_batch(device=device, work_columns=256, retain="auto", retain_bytes=64 << 30, **cfg)
+    form, held = sol.plan.retained_form(), sol.plan.device_bytes()
+    sol.plan.synchronize()
+    t0 = time.perf_counter()
+    sol.plan.solve()
+    sol.plan.synchronize()
+    t_solve = time.perf_counter() - t0
+    first = sol.u(tau, phi)  # (grows the evaluation buffers)
+    t0 = time.perf_counter()
+    again = sol.u(tau, phi)
+    t_eval = time.perf_counter() - t0
+    n = min(C, 1024)
+    sub = {k: (v[:n] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == C else v) for k, v in cfg.items()}
+    _, full = pydisort_amd.pydisort_batch(device=device, work_columns=256, retain="full", retain_bytes=8 << 30, **sub)
+    same = bool(np.array_equal(full.u(tau[:n], phi), first[:n]) and np.array_equal(first, again))
+    full_form = full.plan.retained_form()
+    full.plan.close()
+    sol.plan.close()
+    return {"columns": C, "retained_form": form, "device_bytes": held, "solve_seconds": t_solve, "evaluate_seconds": t_eval,
+            "evaluate_over_solve": t_eval / t_solve, "bit_identical_to_full_retention": same, "full_form_of_the_slice": full_form,
+            "what": "sol.u(tau, phi) at one non-interface depth per column and 2 azimuths on the whole batch, from the lean retained state "
+                    "(coefficients, k, E, B per column; Y, A of the touched wavefront chunks recomputed); compared bit for bit with a "
+                    f"full-retention plan of the first {n} columns"}
+
+
 def extra_measurements(device, main_cfg=None, window=2048, live=None, filled=None):
     """max |dI| of the HIP path against the oracle on the sample columns of the cpu_baseline leg, the only_flux
     throughput, the host-to-host rate of the main batch, and BASELINE's other configs."""
@@ -667,6 +704,11 @@ def extra_measurements(device, main_cfg=None, window=2048, live=None, filled=Non
                         "workload": "cfg4 with only_flux=True (one Fourier mode), 16384 columns per pass"}
     plan.close()
     out["e2e"] = end_to_end(device, main_cfg, window)
+    if main_cfg is not None:
+        try:
+            out["retention"] = lean_retention_leg(device, main_cfg)
+        except Exception as e:  # (a box with less free memory than the leg wants: reported, not fatal)
+            out["retention"] = {"error": repr(e)}
     out["other_configs"] = {
         "cfg2_cloudC1_Q32_single_column": single_column_leg(device),
         "cfg3_L6_Q8_x1024": config_leg("cfg3: Test Problem 9c (6 layers, 8 streams, thermal + beam + Lambertian surface) x 1024 perturbed columns",
