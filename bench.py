@@ -666,6 +666,37 @@ def lean_retention_leg(device, cfg):
                     f"full-retention plan of the first {n} columns"}
 
 
+def n_rank_check(ranks=4, columns=4096):
+    """NOT a measurement: a check, inside the N = 1 run, that the N-rank data plane of THIS build executes -- `bench.py --gpus 4` as
+    a child process with all rank processes on device 0 over the tests' stand-in transport (tests/stub/librccl_stub.so, selected by
+    RTD_RCCL_STUB; RCCL itself refuses two ranks on one GPU): socket control plane, communicator of 4, both collectives tried, every
+    rank's slot of the gathered arrays verified bit for bit.  Only what it proved is kept; its rate is not (ranks sharing one GPU
+    over a synchronous transport)."""
+    stub_lib = os.path.join(ROOT, "tests", "stub", "librccl_stub.so")
+    if not os.path.exists(stub_lib):
+        return {"ran": False, "why": "tests/stub/librccl_stub.so is not built (python tests/stub/build_stub.py)"}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RTD_RCCL_STUB=stub_lib, RTD_BENCH_TIMEOUT="240")
+    env.setdefault("RCCL_STUB_TIMEOUT_S", "120")
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                            "--no-extras", "--total-columns", str(columns)], env=env, capture_output=True, text=True, timeout=300)
+        line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+        if r.returncode != 0 or line is None:
+            return {"ran": True, "ok": False, "exit_code": r.returncode, "stderr_tail": r.stderr[-600:]}
+        d = json.loads(line)
+        return {"ran": True, "ok": bool(d["config"].get("gather_verified")) and d["config"].get("ranks_verified") == ranks,
+                "ranks": d["n_gpus"], "devices_used": d.get("devices_used"), "transport": d.get("transport"), "not_a_rate": d.get("not_a_rate"),
+                "rccl_nranks": d["config"].get("rccl_nranks"), "gather_verified": d["config"].get("gather_verified"),
+                "ranks_verified": d["config"].get("ranks_verified"), "collective_chosen": d.get("gather_rates", {}).get("chosen"),
+                "columns": columns, "seconds": round(time.perf_counter() - t0, 1),
+                "what": f"bench.py --gpus {ranks} as a child of this run, {ranks} rank processes on device 0 over the tests' stand-in transport: "
+                        "the N-rank control and data plane executed and every gathered slot equals a local solve, bit for bit"}
+    except Exception as e:
+        return {"ran": True, "ok": False, "error": repr(e)}
+
+
 def extra_measurements(device, main_cfg=None, window=2048, live=None, filled=None):
     """max |dI| of the HIP path against the oracle on the sample columns of the cpu_baseline leg, the only_flux
     throughput, the host-to-host rate of the main batch, and BASELINE's other configs."""
@@ -1342,6 +1373,8 @@ def run_rank(a, rank, world, local):
                                               "torch.distributed.run command line end to end, every gathered slot verified bit for bit; evidence "
                                               "profiles/r06_bench_stub_8ranks.json (transport = stub, not_a_rate = true: never a throughput)",
                 "over_rccl": "one-rank communicator on every box (tests/test_gpu_distributed.py); two-rank tests where two GPUs are visible"}
+            if not a.no_extras and not stub:
+                out["multi_gpu"]["n_rank_check"] = n_rank_check()
         out.update(extras)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
